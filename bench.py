@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched SingleRoom step/render path on MI355X.
+
+A "step" is one pass of the hot path (dynamics -> cast -> project -> frame fill,
+RCW.act!(env, a) SR:333-340 minus the top view) over one batch of agents.  Workload at
+every N: BASELINE.json configs[1] per GPU (SingleRoom 8x8, 256 view columns, 4096 agents,
+H_cam = 256), agents sharded by rank with no data-path collective (weak scaling).
+State, actions and observations are resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HBM write
+roofline of the step kernel, HIP-event timed on the kernel's own stream) and
+`cpu_baseline` (the CPU oracle — a C restatement of the reference, kind "port" — timed on
+this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+WORKLOADS = {
+    # name: (kwargs, agents per GPU)
+    "cfg2": (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256), 4096),
+    "cfg3": (dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=512), 16384),
+    "cfg4": (dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=256), 8192),
+    "cfg5": (dict(height_tile_map_tu=32, width_tile_map_tu=32, num_rays=1024), 8192),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(kw, batch_hint, target_seconds=12.0):
+    """Time the CPU oracle (all host cores, OpenMP over agents) on a bounded sample."""
+    from oracle import oracle as O
+
+    threads = O.num_threads()
+    agents = min(batch_hint, 512)
+    orc = O.OracleBatch(agents, seed=0, auto_reset=1, **kw)
+    rng = np.random.default_rng(0)
+    acts = rng.integers(1, 5, (64, agents)).astype(np.uint8)
+    t0 = time.perf_counter()
+    for s in range(4):
+        orc.step(acts[s])
+    per_step = (time.perf_counter() - t0) / 4
+    steps = int(max(8, min(20000, target_seconds / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for s in range(steps):
+        orc.step(acts[s & 63])
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {
+        "value": agents * steps / dt,
+        "unit": "env-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{agents} agents x {steps} steps of the same workload (C restatement of the reference "
+                  f"camera path, OpenMP over agents, {dt:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="agents per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raycastworlds_jl_amd as RCW
+
+    kw, per_gpu = WORKLOADS[args.workload]
+    B = args.batch or per_gpu
+    N, Hc = kw["num_rays"], 256
+    env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=0, device=local_rank, auto_reset=not args.no_auto_reset,
+                                          agent_id_offset=rank * B, **kw)
+    # U{1..4} actions per agent per step (test/runtests.jl:28), pre-generated on the device
+    total = args.warmup + args.steps
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    actions = torch.randint(1, 5, (total, B), dtype=torch.uint8, device="cuda", generator=gen)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for s in range(args.warmup):
+        RCW.act_(env, actions[s])
+    env.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    env.timer_start()
+    for s in range(args.warmup, total):
+        RCW.act_(env, actions[s])
+    kernel_ms = env.timer_stop()   # HIP events on the stream the kernels run on
+    env.sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        frame_bytes = 4 * Hc * N                          # bytes per env-step
+        bytes_per_launch = frame_bytes * B                # one launch = B agents
+        launch_s = kernel_ms / 1e3 / args.steps
+        achieved = bytes_per_launch / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    t = json.load(f)
+                if t.get("workload") == args.workload and t.get("batch") == B:
+                    traffic = t.get("write_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node) + frames/sec, SingleRoom batch=4096 cols=256",
+            "value": world * B * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SingleRoom {kw['height_tile_map_tu']}x{kw['width_tile_map_tu']}, {N} view columns, "
+                            f"H_cam {Hc}, {B} agents per GPU ({args.workload}; BASELINE.json configs[1] is cfg2)",
+                "agents_per_gpu": B,
+                "global_batch": world * B,
+                "auto_reset": not args.no_auto_reset,
+                "actions": "uniform 1..4 per agent per step, device resident",
+                "sharding": f"agents by rank x{world}, no data-path collective",
+            },
+            "frames_per_s": world * B * args.steps / dt,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "rcw_step_kernel",
+                "bytes_per_launch": bytes_per_launch,
+                "launch_ms": launch_s * 1e3,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kw, B)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

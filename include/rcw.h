@@ -1,0 +1,231 @@
+/*
+ * rcw.h — C ABI of librcw_hip: batched SingleRoom step/render on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of RayCastWorlds.jl: the SingleRoom
+ * step/render hot path.  The reference has no FFI of its own on this path (it is
+ * Julia calling Julia), so each entry point below cites the reference method it
+ * replaces (paths relative to the reference tree; SR = src/single_room.jl).
+ * The Julia-side binding a maintainer would add is shown in INTEGRATION.md and
+ * shipped in julia/BatchedSingleRoom.jl.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types.
+ *   - Every call returns RCW_OK (0) or a negative RCW_ERR_* code; the message for the
+ *     last failure on the calling thread is available from rcw_last_error().
+ *   - One caller thread per handle (the reference is single threaded).  All work of a
+ *     handle is ordered on one HIP stream.  rcw_step, rcw_reset and rcw_set_state may
+ *     return before the GPU has finished; every getter and rcw_sync() waits.
+ *   - There is NO CPU fallback in this library: rcw_create fails with
+ *     RCW_ERR_NO_DEVICE when no gfx950 device is usable.
+ *   - Indices handed over the boundary are the reference's: tiles are 1-based (i, j),
+ *     actions are 1..4, directions are 0..num_directions-1.
+ *   - Batched layouts are the reference's single-agent (column-major) layouts with a
+ *     trailing batch axis, i.e. what a Julia caller would unsafe_wrap:
+ *       camera_view  UInt32 (H_cam, N, B)          SR:300
+ *       tile_map     BitArray{3}(2, H, W).chunks   SR:54   -> UInt64 (nchunks, B)
+ *       position     Float32 (2, B)                SR:24
+ *       rays         Int64 (2, N, B), Int64 (N, B), Float32 (N, B), Float32 (2, N, B)
+ *                                                   SR:29-31,39
+ */
+#ifndef RCW_H
+#define RCW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCW_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define RCW_API __attribute__((visibility("default")))
+#else
+#define RCW_API
+#endif
+
+/* ---- error codes ------------------------------------------------------------------ */
+#define RCW_OK                    0
+#define RCW_ERR_INVALID_ARGUMENT -1  /* NULL pointer, bad size, bad config value          */
+#define RCW_ERR_INVALID_ACTION   -2  /* action outside 1..4 (stands in for @assert SR:140) */
+#define RCW_ERR_NO_DEVICE        -3  /* no usable gfx950 device / HIP runtime failure      */
+#define RCW_ERR_OUT_OF_MEMORY    -4
+#define RCW_ERR_OUT_OF_BOUNDS    -5  /* a tile index left the map (Julia: BoundsError at
+                                        collision_detection.jl:35 or inside cast_ray)      */
+#define RCW_ERR_HIP              -6  /* any other HIP error; text in rcw_last_error()      */
+#define RCW_ERR_UNSUPPORTED      -7
+
+/* ---- objects, actions (SR:16-19) --------------------------------------------------- */
+#define RCW_NUM_OBJECTS 2
+#define RCW_WALL        1
+#define RCW_GOAL        2
+#define RCW_NUM_ACTIONS 4
+#define RCW_ACTION_MOVE_FORWARD  1   /* SR:486 get_action_names */
+#define RCW_ACTION_MOVE_BACKWARD 2
+#define RCW_ACTION_TURN_LEFT     3
+#define RCW_ACTION_TURN_RIGHT    4
+
+/* Column colour ids used by the compact per-column descriptor (SR:417-429). */
+#define RCW_COLOUR_WALL_DIM_1 0
+#define RCW_COLOUR_WALL_DIM_2 1
+#define RCW_COLOUR_GOAL_DIM_1 2
+#define RCW_COLOUR_GOAL_DIM_2 3
+
+/* The three choices inside the un-vendored dependencies that the reference's own tests
+ * do not pin (DESIGN.md "parity unpinned").  They live here, in ONE
+ * place, so a maintainer with a Julia toolchain can flip them without touching code. */
+#define RCW_DDA_TIE_X_FIRST_ON_LT 0  /* step in x when side_x <  side_y (default)          */
+#define RCW_DDA_TIE_X_FIRST_ON_LE 1  /* step in x when side_x <= side_y                    */
+#define RCW_DDA_DIST_SIDE_MINUS_DELTA 0 /* distance = side - delta after the step (default) */
+#define RCW_DDA_DIST_PRE_INCREMENT    1 /* distance = side before it was incremented       */
+#define RCW_NORMALIZE_INV_NORM_TIMES 0  /* inv(norm(v)) * v  (StaticArrays 1.2, default)    */
+#define RCW_NORMALIZE_DIVIDE         1  /* v / norm(v)                                      */
+
+/* Mirrors the keyword arguments of SingleRoom(; ...) SR:258-272 and the colour
+ * constants SR:288-296.  Fill with rcw_config_default() and then override. */
+typedef struct rcw_config {
+    int32_t  abi_version;             /* RCW_ABI_VERSION                                   */
+    int32_t  height_tile_map_tu;      /* SR:260  default 8  (x axis, index i)              */
+    int32_t  width_tile_map_tu;       /* SR:261  default 16 (y axis, index j)              */
+    int32_t  num_directions;          /* SR:262  default 128                               */
+    int32_t  num_rays;                /* SR:268  default 512 (= camera view width)         */
+    int32_t  height_camera_view_pu;   /* SR:271  default 256                               */
+    int32_t  pu_per_tu;               /* SR:269  default 32 (top view only; kept for ABI)  */
+    float    player_radius_wu;        /* SR:263  default 1/8, must be in (0, 0.5)          */
+    float    position_increment_wu;   /* SR:264  default 1/8                               */
+    float    semi_field_of_view_wu;   /* SR:267  default Float32(2/3)                      */
+    float    camera_height_tile_wu;   /* SR:270  default 1                                 */
+    float    goal_reward;             /* SR:86   one(R)                                    */
+    uint32_t floor_color;             /* SR:291  0x00404040                                */
+    uint32_t ceiling_color;           /* SR:292  0x00FFFFFF                                */
+    uint32_t wall_dim_1_color;        /* SR:293  0x00808080                                */
+    uint32_t wall_dim_2_color;        /* SR:294  0x00c0c0c0                                */
+    uint32_t goal_dim_1_color;        /* SR:295  0x00800000                                */
+    uint32_t goal_dim_2_color;        /* SR:296  0x00c00000                                */
+    int32_t  dda_tie_break;           /* RCW_DDA_TIE_*                                     */
+    int32_t  dda_distance;            /* RCW_DDA_DIST_*                                    */
+    int32_t  normalize_mode;          /* RCW_NORMALIZE_*                                   */
+    int32_t  auto_reset;              /* 0 (reference behaviour: none) | 1: an agent whose
+                                         `done` is set is re-sampled by the NEXT step call
+                                         (its action is ignored, reward 0, done false)     */
+    int64_t  agent_id_offset;         /* global id of local agent 0 (multi-GPU sharding);
+                                         keys the reset RNG so results do not depend on
+                                         how agents are sharded                            */
+    int32_t  write_columns;           /* 1: also keep the compact per-column descriptor
+                                         (height_line_pu, colour id) in device memory      */
+    int32_t  reserved[7];
+} rcw_config;
+
+typedef struct rcw_handle rcw_handle;   /* opaque */
+
+/* Reference defaults of SingleRoom(; ...) SR:258-272, SR:288-296. */
+RCW_API int rcw_config_default(rcw_config* cfg);
+
+/* SingleRoom(; kwargs...) SR:258-324 for `batch` independent agents on HIP device
+ * `device` (>= 0).  Allocates structure-of-arrays state, the per-(direction, ray) table
+ * (SR:65-69, SR:214-221) and the UInt32 (H_cam, N, B) observation batch in HBM.
+ * The initial state is rcw_reset(h, NULL, seed). */
+RCW_API int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t seed,
+               rcw_handle** out);
+RCW_API int rcw_destroy(rcw_handle* h);
+
+/* Replace the direction table directions_wu (SR:65-69) by a caller-computed one
+ * (Float32 (2, num_directions)), e.g. Julia's own cos/sin, and rebuild the ray table. */
+RCW_API int rcw_set_direction_table(rcw_handle* h, const float* directions_wu);
+
+/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the
+ * handle's own stream.  The caller keeps the stream alive. */
+RCW_API int rcw_set_stream(rcw_handle* h, void* hip_stream);
+/* Render into a caller-owned DEVICE buffer of B*N*H_cam UInt32 instead of the
+ * library's (NULL restores it).  Takes effect at the next render. */
+RCW_API int rcw_bind_obs(rcw_handle* h, void* device_ptr);
+
+/* RCW.reset!(env) SR:326-331 -> SR:110-137 for the agents whose mask byte is non-zero
+ * (mask == NULL: all).  Sampling is done on the device with a counter-based generator
+ * keyed (seed, global agent id, episode number): goal uniform on interior tiles
+ * (SR:120), player uniform on empty tiles by rejection (utils.jl:23-58) at the tile
+ * centre (SR:125), heading uniform on 0..nd-1 (SR:128); reward 0, done false
+ * (SR:131-132); rays cast and camera view rendered (SR:134, SR:329).
+ * The stream is the build's own (Julia's RNG streams are not reproducible across
+ * Julia versions): parity with the reference is in distribution only. */
+RCW_API int rcw_reset(rcw_handle* h, const uint8_t* mask_host, uint64_t seed);
+
+/* Inject the post-reset state the reference would have after SR:118-132 (this is how
+ * "identical seeds" is realised): goal_ij Int32 (2, B) 1-based,
+ * position_wu Float32 (2, B), direction_au Int32 (B); mask as above.  Clears the old
+ * goal bit, sets the new one, zeroes reward/done, casts and renders. */
+RCW_API int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_wu,
+                  const int32_t* direction_au, const uint8_t* mask_host);
+
+/* RCW.act!(env, action) SR:333-340 (minus update_top_view!) for every agent:
+ * dynamics SR:139-191 -> cast_rays! SR:195-231 -> update_camera_view! SR:374-444.
+ * actions: UInt8 (B), values 1..4, in HOST memory.  Any value outside 1..4 returns
+ * RCW_ERR_INVALID_ACTION and NO agent is mutated (@assert SR:140). */
+RCW_API int rcw_step(rcw_handle* h, const uint8_t* actions_host);
+/* Same with actions already in DEVICE memory (stream-ordered, no host round trip).
+ * Validation runs on the device before the step; on an invalid action no agent is
+ * mutated and the error is returned by the next rcw_sync()/getter (sticky until
+ * rcw_clear_error). */
+RCW_API int rcw_step_device(rcw_handle* h, const uint8_t* actions_device);
+
+RCW_API int rcw_sync(rcw_handle* h);
+RCW_API int rcw_clear_error(rcw_handle* h);
+
+/* RLBase.state(env) SR:576: the camera view batch, aliased — the pointer is stable for
+ * the handle's lifetime (or until rcw_bind_obs) and is overwritten by the next step. */
+RCW_API int rcw_obs_device_ptr(rcw_handle* h, void** device_ptr);
+/* Copy frames of agents [first, first+count) to host: UInt32 (H_cam, N, count). */
+RCW_API int rcw_obs_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count);
+/* RLBase.reward SR:583 / RLBase.is_terminated SR:584 */
+RCW_API int rcw_reward(rcw_handle* h, float* out_host /* (B) */);
+RCW_API int rcw_done(rcw_handle* h, uint8_t* out_host /* (B) */);
+RCW_API int rcw_reward_device_ptr(rcw_handle* h, void** device_ptr);
+RCW_API int rcw_done_device_ptr(rcw_handle* h, void** device_ptr);
+/* world.player_position_wu SR:24, world.player_direction_au SR:25, world.goal_position SR:32 */
+RCW_API int rcw_position(rcw_handle* h, float* out_host /* (2, B) */);
+RCW_API int rcw_direction(rcw_handle* h, int32_t* out_host /* (B) */);
+RCW_API int rcw_goal(rcw_handle* h, int32_t* out_host /* (2, B), 1-based */);
+RCW_API int rcw_episode(rcw_handle* h, uint32_t* out_host /* (B): resets seen by each agent */);
+/* world.tile_map SR:22 as BitArray{3}(2, H, W).chunks per agent: UInt64 (nchunks, B),
+ * nchunks = rcw_tile_map_num_chunks(). Bit (o-1) + 2(i-1) + 2H(j-1), LSB first. */
+RCW_API int rcw_tile_map_num_chunks(rcw_handle* h, int32_t* out);
+RCW_API int rcw_tile_map_chunks(rcw_handle* h, uint64_t* out_host);
+/* world.ray_stop_position_tu / ray_hit_dimension / ray_distance_wu / ray_directions_wu
+ * SR:29-31,39 for agents [first, first+count), recomputed from the current state by a
+ * cast-only kernel (the step itself does not spend HBM bandwidth on them).
+ * Any output pointer may be NULL. */
+RCW_API int rcw_rays(rcw_handle* h, int32_t first, int32_t count,
+             int64_t* stop_ij /* (2, N, count) */, int64_t* hit_dimension /* (N, count) */,
+             float* distance_wu /* (N, count) */, float* directions_wu /* (2, N, count) */);
+/* Compact per-column descriptor of the current frames, indexed by image column k
+ * (k = N - i + 1, SR:431): height_line_pu SR:408-411 (Int32, saturated) and colour id.
+ * Needs cfg.write_columns = 1. */
+RCW_API int rcw_columns(rcw_handle* h, int32_t first, int32_t count,
+                int32_t* height_line_pu /* (N, count) */, uint8_t* colour_id /* (N, count) */);
+RCW_API int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** colour_id);
+/* Expand descriptors (DEVICE pointers, e.g. gathered from another GPU) into frames
+ * UInt32 (H_cam, N, count) in DEVICE memory, with this handle's colours and H_cam:
+ * the receiving side of the compact observation gather. */
+RCW_API int rcw_expand_columns(rcw_handle* h, const int32_t* height_line_pu_device,
+                       const uint8_t* colour_id_device, int32_t count, void* frames_device);
+
+/* The (direction, ray) table the kernels use, for inspection and parity tests:
+ * Float32 (N, 5, num_directions) = per direction [dx | dy | |1/dx| | |1/dy| | dir.ray]. */
+RCW_API int rcw_ray_table(rcw_handle* h, float* out_host);
+RCW_API int rcw_direction_table(rcw_handle* h, float* out_host /* (2, nd) */);
+
+/* HIP-event timing on the handle's stream (what bench.py reads the kernel time from). */
+RCW_API int rcw_timer_start(rcw_handle* h);
+RCW_API int rcw_timer_stop(rcw_handle* h, float* elapsed_ms);
+
+/* Introspection */
+RCW_API int rcw_batch(rcw_handle* h, int32_t* out);
+RCW_API int rcw_get_config(rcw_handle* h, rcw_config* out);
+RCW_API int rcw_device_name(rcw_handle* h, char* buf, int32_t buflen);
+RCW_API const char* rcw_last_error(void);
+RCW_API int rcw_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCW_H */

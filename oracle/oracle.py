@@ -1,0 +1,318 @@
+"""ctypes front end of the CPU oracle (oracle/rcw_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — see the header of rcw_oracle.c.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product package.
+PARITY UNPINNED for cast_ray / normalize / LinRange (no Julia toolchain, no golden vectors
+in the reference); pinned by tests/golden/ hand-derived vectors and oracle/pyref.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "librcw_oracle.so")
+
+
+class RcwConfig(C.Structure):
+    """Mirror of `rcw_config` (include/rcw.h); kwargs of SingleRoom(; ...) SR:258-272."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("height_tile_map_tu", C.c_int32),
+        ("width_tile_map_tu", C.c_int32),
+        ("num_directions", C.c_int32),
+        ("num_rays", C.c_int32),
+        ("height_camera_view_pu", C.c_int32),
+        ("pu_per_tu", C.c_int32),
+        ("player_radius_wu", C.c_float),
+        ("position_increment_wu", C.c_float),
+        ("semi_field_of_view_wu", C.c_float),
+        ("camera_height_tile_wu", C.c_float),
+        ("goal_reward", C.c_float),
+        ("floor_color", C.c_uint32),
+        ("ceiling_color", C.c_uint32),
+        ("wall_dim_1_color", C.c_uint32),
+        ("wall_dim_2_color", C.c_uint32),
+        ("goal_dim_1_color", C.c_uint32),
+        ("goal_dim_2_color", C.c_uint32),
+        ("dda_tie_break", C.c_int32),
+        ("dda_distance", C.c_int32),
+        ("normalize_mode", C.c_int32),
+        ("auto_reset", C.c_int32),
+        ("agent_id_offset", C.c_int64),
+        ("write_columns", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+def default_config(**overrides) -> RcwConfig:
+    """Reference defaults SR:258-272, SR:288-296 (restated, not read from the product)."""
+    cfg = RcwConfig()
+    cfg.abi_version = 1
+    cfg.height_tile_map_tu = 8
+    cfg.width_tile_map_tu = 16
+    cfg.num_directions = 128
+    cfg.num_rays = 512
+    cfg.height_camera_view_pu = 256
+    cfg.pu_per_tu = 32
+    cfg.player_radius_wu = np.float32(1 / 8)
+    cfg.position_increment_wu = np.float32(1 / 8)
+    cfg.semi_field_of_view_wu = np.float32(2 / 3)
+    cfg.camera_height_tile_wu = 1.0
+    cfg.goal_reward = 1.0
+    cfg.floor_color = 0x00404040
+    cfg.ceiling_color = 0x00FFFFFF
+    cfg.wall_dim_1_color = 0x00808080
+    cfg.wall_dim_2_color = 0x00C0C0C0
+    cfg.goal_dim_1_color = 0x00800000
+    cfg.goal_dim_2_color = 0x00C00000
+    cfg.write_columns = 1
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k!r}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc, strict IEEE).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "rcw_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "rcw.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(RcwConfig), C.c_int32, C.c_uint64, C.c_int, C.POINTER(vp)]
+        L.orc_create.restype = C.c_int
+        L.orc_destroy.argtypes = [vp]
+        L.orc_destroy.restype = None
+        L.orc_reset.argtypes = [vp, vp, C.c_uint64]
+        L.orc_set_state.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_set_direction_table.argtypes = [vp, vp]
+        L.orc_step.argtypes = [vp, vp]
+        L.orc_tile_map_chunks.argtypes = [vp, vp]
+        L.orc_tile_map_chunks.restype = None
+        L.orc_num_chunks.argtypes = [vp]
+        L.orc_num_chunks.restype = C.c_int32
+        L.orc_direction_table.argtypes = [C.c_int32, vp]
+        L.orc_direction_table.restype = None
+        L.orc_ray_fan.argtypes = [C.POINTER(RcwConfig), vp, vp]
+        L.orc_ray_fan.restype = None
+        L.orc_cast_ray.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        L.orc_is_player_colliding.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                              C.c_float]
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads.restype = None
+        for name in ("camera_view", "reward", "done", "position", "direction", "goal", "episode",
+                     "status", "ray_stop", "ray_dim", "ray_dist", "ray_dirs", "col_height",
+                     "col_colour", "directions", "ray_table"):
+            f = getattr(L, "orc_" + name)
+            f.argtypes = [vp]
+            f.restype = vp
+        _lib = L
+    return _lib
+
+
+def _view(ptr, dtype, shape):
+    n = int(np.prod(shape))
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleBatch:
+    """B independent reference worlds stepped on the CPU.  Arrays are returned with the
+    BATCH AXIS FIRST (numpy C order of the Julia column-major layouts): camera_view is
+    (B, N, H_cam) == Julia (H_cam, N, B)."""
+
+    def __init__(self, batch: int, seed: int = 0, render: bool = True, config: RcwConfig | None = None,
+                 **overrides):
+        self.cfg = config if config is not None else default_config(**overrides)
+        self.B = int(batch)
+        self._h = C.c_void_p()
+        rc = lib().orc_create(C.byref(self.cfg), self.B, seed, 1 if render else 0, C.byref(self._h))
+        if rc != 0:
+            raise ValueError(f"orc_create failed: {rc}")
+        self.render = render
+        self.N = self.cfg.num_rays
+        self.Hc = self.cfg.height_camera_view_pu
+        self.H = self.cfg.height_tile_map_tu
+        self.W = self.cfg.width_tile_map_tu
+        self.nd = self.cfg.num_directions
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- RCW.reset! / act! ---------------------------------------------------------
+    def reset(self, mask=None, seed: int = 0):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        rc = lib().orc_reset(self._h, _p(m), seed)
+        if rc:
+            raise ValueError(rc)
+
+    def set_state(self, goal_ij, position_wu, direction_au, mask=None):
+        g = np.ascontiguousarray(goal_ij, dtype=np.int32).reshape(self.B, 2)
+        p = np.ascontiguousarray(position_wu, dtype=np.float32).reshape(self.B, 2)
+        d = np.ascontiguousarray(direction_au, dtype=np.int32).reshape(self.B)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        rc = lib().orc_set_state(self._h, _p(g), _p(p), _p(d), _p(m))
+        if rc:
+            raise ValueError(f"orc_set_state: {rc}")
+
+    def set_direction_table(self, dirs):
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(self.nd, 2)
+        lib().orc_set_direction_table(self._h, _p(d))
+
+    def step(self, actions) -> int:
+        a = np.ascontiguousarray(actions, dtype=np.uint8).reshape(self.B)
+        return lib().orc_step(self._h, _p(a))
+
+    # --- state ---------------------------------------------------------------------
+    def _g(self, name, dtype, shape):
+        return _view(getattr(lib(), "orc_" + name)(self._h), dtype, shape)
+
+    @property
+    def camera_view(self):
+        assert self.render
+        return self._g("camera_view", np.uint32, (self.B, self.N, self.Hc))
+
+    @property
+    def reward(self):
+        return self._g("reward", np.float32, (self.B,))
+
+    @property
+    def done(self):
+        return self._g("done", np.uint8, (self.B,))
+
+    @property
+    def position(self):
+        return self._g("position", np.float32, (self.B, 2))
+
+    @property
+    def direction(self):
+        return self._g("direction", np.int32, (self.B,))
+
+    @property
+    def goal(self):
+        return self._g("goal", np.int32, (self.B, 2))
+
+    @property
+    def episode(self):
+        return self._g("episode", np.uint32, (self.B,))
+
+    @property
+    def status(self):
+        return self._g("status", np.int32, (self.B,))
+
+    @property
+    def ray_stop(self):
+        return self._g("ray_stop", np.int64, (self.B, self.N, 2))
+
+    @property
+    def ray_dim(self):
+        return self._g("ray_dim", np.int64, (self.B, self.N))
+
+    @property
+    def ray_dist(self):
+        return self._g("ray_dist", np.float32, (self.B, self.N))
+
+    @property
+    def ray_dirs(self):
+        return self._g("ray_dirs", np.float32, (self.B, self.N, 2))
+
+    @property
+    def col_height(self):
+        return self._g("col_height", np.int32, (self.B, self.N))
+
+    @property
+    def col_colour(self):
+        return self._g("col_colour", np.uint8, (self.B, self.N))
+
+    @property
+    def directions(self):
+        return self._g("directions", np.float32, (self.nd, 2))
+
+    @property
+    def ray_table(self):
+        """(nd, N, 2) normalized ray directions per heading."""
+        return self._g("ray_table", np.float32, (self.nd, self.N, 2))
+
+    def tile_map_chunks(self):
+        n = lib().orc_num_chunks(self._h)
+        out = np.zeros((self.B, n), dtype=np.uint64)
+        lib().orc_tile_map_chunks(self._h, _p(out))
+        return out
+
+
+def direction_table(nd: int) -> np.ndarray:
+    out = np.zeros((nd, 2), dtype=np.float32)
+    lib().orc_direction_table(nd, _p(out))
+    return out
+
+
+def ray_fan(cfg: RcwConfig, direction) -> np.ndarray:
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    out = np.zeros((cfg.num_rays, 2), dtype=np.float32)
+    lib().orc_ray_fan(C.byref(cfg), _p(d), _p(out))
+    return out
+
+
+def cast_ray(obstacle_map, x, y, dx, dy, tie_break=0, dist_mode=0):
+    """obstacle_map: bool array indexed [i-1, j-1] (shape (H, W))."""
+    om = np.asfortranarray(np.asarray(obstacle_map, dtype=np.uint8))
+    H, W = om.shape
+    i = C.c_int64(); j = C.c_int64(); dim = C.c_int64(); dist = C.c_float()
+    rc = lib().orc_cast_ray(om.ctypes.data_as(C.c_void_p), H, W, x, y, dx, dy, tie_break, dist_mode,
+                            C.addressof(i), C.addressof(j), C.addressof(dim), C.addressof(dist))
+    if rc:
+        raise IndexError("BoundsError")
+    return i.value, j.value, dim.value, np.float32(dist.value)
+
+
+def is_player_colliding(layer, px, py, radius) -> bool:
+    lm = np.asfortranarray(np.asarray(layer, dtype=np.uint8))
+    H, W = lm.shape
+    rc = lib().orc_is_player_colliding(lm.ctypes.data_as(C.c_void_p), H, W, px, py, radius)
+    if rc < 0:
+        raise IndexError("BoundsError")
+    return bool(rc)
+
+
+def set_num_threads(n: int):
+    lib().orc_set_num_threads(n)
+
+
+def num_threads() -> int:
+    return lib().orc_num_threads()

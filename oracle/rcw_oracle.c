@@ -1,0 +1,553 @@
+/*
+ * rcw_oracle.c — CPU restatement of the RayCastWorlds.jl SingleRoom step/render path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as the
+ * checker / the reported CPU baseline.  The product (librcw_hip.so) never links, loads
+ * or falls back to anything in oracle/.
+ *
+ * PARITY UNPINNED.  The reference is Julia and there is no Julia toolchain here, and its
+ * tests hold no golden vectors for this path (test/runtests.jl:15-44 checks invariants
+ * only).  Three pieces of arithmetic live in un-vendored dependencies and are restated
+ * from their published algorithms: RayCaster.cast_ray (RayCaster 0.1.x, call site
+ * src/single_room.jl:223), StaticArrays 1.2 `normalize` (SR:221) and Julia Base
+ * `LinRange` indexing (SR:218,221).  Each such choice is marked UNPINNED below and is
+ * switchable through rcw_config (include/rcw.h).  What pins this file is (1) the
+ * hand-derived known-answer vectors in tests/golden/ (derived from the reference text,
+ * SURVEY.md §8c) and (2) an independent second restatement in oracle/pyref.py.
+ *
+ * Every function cites the reference lines it follows (SR = src/single_room.jl,
+ * CD = src/collision_detection.jl, UT = src/utils.jl).  All arithmetic is Float32 with
+ * one IEEE rounding per operation and no fused multiply-add (build with
+ * -ffp-contract=off), except the Float64 lerp of LinRange.
+ *
+ * Layouts are the reference's column-major ones with a trailing batch axis
+ * (include/rcw.h).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rcw.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------
+ * Counter-based generator used by reset (the build's own; Julia's streams are not
+ * reproducible).  Restated independently in csrc/rcw_rng.h — the spec is
+ * DESIGN.md "Reset generator".
+ * ---------------------------------------------------------------------------------- */
+static uint64_t orc_mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL;
+    z ^= z >> 27; z *= 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return z;
+}
+static uint64_t orc_episode_key(uint64_t seed, uint64_t agent, uint64_t episode)
+{
+    uint64_t k = orc_mix64(seed + 0x9e3779b97f4a7c15ULL * (agent + 1));
+    return orc_mix64(k ^ (episode * 0xd1b54a32d192ed03ULL));
+}
+static uint64_t orc_draw(uint64_t key, uint64_t n)
+{
+    return orc_mix64(key + 0x9e3779b97f4a7c15ULL * (n + 1));
+}
+/* uniform integer on 0..range-1: high 64 bits of u*range */
+static uint64_t orc_below(uint64_t u, uint64_t range)
+{
+    return (uint64_t)(((__uint128_t)u * (__uint128_t)range) >> 64);
+}
+
+/* ------------------------------------------------------------------------------------
+ * A.1 direction table  (SR:65-69)
+ * ---------------------------------------------------------------------------------- */
+ORC_EXPORT void orc_direction_table(int32_t nd, float* out /* (2, nd) */)
+{
+    for (int32_t i = 1; i <= nd; ++i) {
+        /* theta_wu = (i - 1) * 2 * pi / num_directions, left to right, Float64 (SR:67) */
+        double theta = (double)((int64_t)(i - 1) * 2) * 3.141592653589793 / (double)nd;
+        out[2 * (i - 1) + 0] = (float)cos(theta);   /* convert(T, cos(theta)) SR:68 */
+        out[2 * (i - 1) + 1] = (float)sin(theta);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A.3 ray fan for one heading  (SR:193, SR:214-221)
+ * ---------------------------------------------------------------------------------- */
+ORC_EXPORT void orc_ray_fan(const rcw_config* cfg, const float* dir /* (2) */,
+                            float* rays /* (2, N) */)
+{
+    const int32_t N = cfg->num_rays;
+    const float fov = cfg->semi_field_of_view_wu;
+    const float d1 = dir[0], d2 = dir[1];
+    /* rotate_minus_90(vec) = (vec[2], -vec[1])  SR:193,215 */
+    const float c1 = d2, c2 = -d1;
+    /* first = dir + fov * cam ; last = dir - fov * cam   SR:216-217 */
+    const float f1 = d1 + fov * c1, f2 = d2 + fov * c2;
+    const float l1 = d1 - fov * c1, l2 = d2 - fov * c2;
+    /* UNPINNED (Julia Base range.jl): range(first, last, length=N) on SVector is a
+     * LinRange; element i is lerpi(i-1, max(N-1,1), first, last) =
+     * T((1-t)*first + t*last) with t = (i-1)/lendiv in Float64.  SR:218,221 */
+    const int32_t lendiv = (N - 1 > 1) ? N - 1 : 1;
+    for (int32_t i = 1; i <= N; ++i) {
+        const double t = (double)(i - 1) / (double)lendiv;
+        const float u1 = (float)((1.0 - t) * (double)f1 + t * (double)l1);
+        const float u2 = (float)((1.0 - t) * (double)f2 + t * (double)l2);
+        /* UNPINNED (StaticArrays): normalize(a) = inv(norm(a)) * a, norm = sqrt(sum abs2) */
+        const float n = sqrtf(u1 * u1 + u2 * u2);
+        float r1, r2;
+        if (cfg->normalize_mode == RCW_NORMALIZE_DIVIDE) {
+            r1 = u1 / n; r2 = u2 / n;
+        } else {
+            const float inv = 1.0f / n;
+            r1 = inv * u1; r2 = inv * u2;
+        }
+        rays[2 * (i - 1) + 0] = r1;
+        rays[2 * (i - 1) + 1] = r2;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A.4 RayCaster.cast_ray  (external package; call site SR:223).  UNPINNED: canonical
+ * grid DDA.  obst is Bool (H, W) column-major, 1 byte per tile.  Returns 0, or
+ * RCW_ERR_OUT_OF_BOUNDS where Julia would raise BoundsError on obstacle_map[i, j].
+ * ---------------------------------------------------------------------------------- */
+ORC_EXPORT int orc_cast_ray(const uint8_t* obst, int32_t H, int32_t W, float x, float y,
+                            float dx, float dy, int32_t tie_break, int32_t dist_mode,
+                            int64_t* i_hit, int64_t* j_hit, int64_t* hit_dim, float* dist)
+{
+    int64_t i = (int64_t)floorf(x) + 1;   /* wu_to_tu UT:5 */
+    int64_t j = (int64_t)floorf(y) + 1;
+    const float ddx = fabsf(1.0f / dx);
+    const float ddy = fabsf(1.0f / dy);
+    int64_t si, sj;
+    float sx, sy;
+    if (dx < 0.0f) { si = -1; sx = (x - (float)(i - 1)) * ddx; }
+    else           { si = +1; sx = ((float)i - x) * ddx; }
+    if (dy < 0.0f) { sj = -1; sy = (y - (float)(j - 1)) * ddy; }
+    else           { sj = +1; sy = ((float)j - y) * ddy; }
+    int64_t dim = 0;
+    float d = 0.0f;
+    for (;;) {
+        if (i < 1 || i > H || j < 1 || j > W) return RCW_ERR_OUT_OF_BOUNDS;
+        if (obst[(i - 1) + (int64_t)H * (j - 1)]) break;
+        const int x_first = (tie_break == RCW_DDA_TIE_X_FIRST_ON_LE) ? (sx <= sy) : (sx < sy);
+        if (x_first) { d = sx; sx = sx + ddx; i += si; dim = 1; }
+        else         { d = sy; sy = sy + ddy; j += sj; dim = 2; }
+    }
+    if (dist_mode == RCW_DDA_DIST_SIDE_MINUS_DELTA) {
+        if (dim == 1) d = sx - ddx;
+        else if (dim == 2) d = sy - ddy;
+    }
+    *i_hit = i; *j_hit = j; *hit_dim = dim; *dist = d;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * A.2 is_player_colliding  (CD:1-42).  layer is Bool (H, W) column-major.
+ * Returns 0/1, or RCW_ERR_OUT_OF_BOUNDS for Julia's BoundsError at CD:35.
+ * ---------------------------------------------------------------------------------- */
+ORC_EXPORT int orc_is_player_colliding(const uint8_t* layer, int32_t H, int32_t W,
+                                       float px, float py, float radius)
+{
+    const float half = 0.5f;                           /* StdSquare(0.5) CD:24 */
+    const int64_t it = (int64_t)floorf(px) + 1;        /* wu_to_tu CD:27-28, UT:5 */
+    const int64_t jt = (int64_t)floorf(py) + 1;
+    for (int64_t j = jt - 1; j <= jt + 1; ++j) {       /* CD:30 */
+        for (int64_t i = it - 1; i <= it + 1; ++i) {   /* CD:31 */
+            const float cx = (float)i - half;          /* CD:33-34 */
+            const float cy = (float)j - half;
+            if (i < 1 || i > H || j < 1 || j > W) return RCW_ERR_OUT_OF_BOUNDS;
+            if (layer[(i - 1) + (int64_t)H * (j - 1)]) {   /* && short-circuit CD:35 */
+                const float qx = px - cx, qy = py - cy;    /* position .- tile CD:35 */
+                /* get_projection: clamp.(q, -h, h) CD:9-12 */
+                const float sx = qx < -half ? -half : (qx > half ? half : qx);
+                const float sy = qy < -half ? -half : (qy > half ? half : qy);
+                const float vx = qx - sx, vy = qy - sy;    /* CD:16 */
+                if (vx * vx + vy * vy < radius * radius) return 1;   /* CD:18 */
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Batched world: B independent SingleRoomWorld + SingleRoom (SR:21-40, SR:241-256)
+ * ---------------------------------------------------------------------------------- */
+typedef struct orc_batch {
+    rcw_config cfg;
+    int32_t B, H, W, N, nd, Hc, nchunks;
+    uint64_t seed;
+    float* directions;      /* (2, nd) */
+    float* ray_table;       /* (2, N, nd) normalized ray directions per heading */
+    uint8_t* wall;          /* (H, W, B) Bool layer WALL */
+    uint8_t* goalmap;       /* (H, W, B) Bool layer GOAL */
+    float* pos;             /* (2, B) */
+    int32_t* dir;           /* (B) */
+    int32_t* goal;          /* (2, B) 1-based */
+    float* reward;          /* (B) */
+    uint8_t* done;          /* (B) */
+    uint32_t* episode;      /* (B) */
+    int32_t* status;        /* (B) sticky per-agent error */
+    /* ray buffers SR:29-31,39 */
+    int64_t* ray_stop;      /* (2, N, B) */
+    int64_t* ray_dim;       /* (N, B) */
+    float* ray_dist;        /* (N, B) */
+    float* ray_dirs;        /* (2, N, B) */
+    /* camera view + compact descriptors */
+    uint32_t* camera_view;  /* (Hc, N, B) */
+    int32_t* col_height;    /* (N, B) indexed by image column k */
+    uint8_t* col_colour;    /* (N, B) */
+    int render;             /* 0: skip the pixel fill (descriptor only) */
+} orc_batch;
+
+ORC_EXPORT void orc_destroy(orc_batch* b)
+{
+    if (!b) return;
+    free(b->directions); free(b->ray_table); free(b->wall); free(b->goalmap); free(b->pos);
+    free(b->dir); free(b->goal); free(b->reward); free(b->done); free(b->episode);
+    free(b->status); free(b->ray_stop); free(b->ray_dim); free(b->ray_dist);
+    free(b->ray_dirs); free(b->camera_view); free(b->col_height); free(b->col_colour);
+    free(b);
+}
+
+static void orc_build_ray_table(orc_batch* b)
+{
+    for (int32_t d = 0; d < b->nd; ++d)
+        orc_ray_fan(&b->cfg, b->directions + 2 * d, b->ray_table + (size_t)2 * b->N * d);
+}
+
+/* cast_rays!(world)  SR:195-231 for agent a */
+static void orc_cast_rays_agent(orc_batch* b, int32_t a)
+{
+    const int32_t H = b->H, W = b->W, N = b->N;
+    const size_t HW = (size_t)H * W;
+    /* obstacle_map = any(tile_map, dims = 1)  SR:209 */
+    uint8_t obst_stack[1024];
+    uint8_t* obst = HW <= sizeof obst_stack ? obst_stack : (uint8_t*)malloc(HW);
+    for (size_t t = 0; t < HW; ++t) obst[t] = b->wall[HW * a + t] | b->goalmap[HW * a + t];
+    const float x = b->pos[2 * a], y = b->pos[2 * a + 1];
+    const float* fan = b->ray_table + (size_t)2 * N * b->dir[a];   /* SR:214-221 */
+    for (int32_t i = 0; i < N; ++i) {                               /* SR:220 */
+        const float dx = fan[2 * i], dy = fan[2 * i + 1];
+        int64_t ih = 0, jh = 0, dim = 0; float dist = 0.0f;
+        int rc = orc_cast_ray(obst, H, W, x, y, dx, dy, b->cfg.dda_tie_break,
+                              b->cfg.dda_distance, &ih, &jh, &dim, &dist);   /* SR:223 */
+        if (rc != 0) { b->status[a] = rc; ih = 1; jh = 1; dim = 0; dist = 0.0f; }
+        const size_t r = (size_t)N * a + i;
+        b->ray_dirs[2 * r] = dx; b->ray_dirs[2 * r + 1] = dy;       /* SR:222 */
+        b->ray_stop[2 * r] = ih; b->ray_stop[2 * r + 1] = jh;       /* SR:224-225 */
+        b->ray_dim[r] = dim;                                        /* SR:226 */
+        b->ray_dist[r] = dist;                                      /* SR:227 */
+    }
+    if (obst != obst_stack) free(obst);
+}
+
+/* update_camera_view!(env)  SR:374-444 for agent a */
+static void orc_update_camera_view_agent(orc_batch* b, int32_t a)
+{
+    const int32_t H = b->H, N = b->N, Hc = b->Hc;
+    const size_t HW = (size_t)H * b->W;
+    const rcw_config* c = &b->cfg;
+    const float p1 = b->directions[2 * b->dir[a]], p2 = b->directions[2 * b->dir[a] + 1]; /* SR:400 */
+    uint32_t* view = b->camera_view + (size_t)Hc * N * a;
+    for (int32_t i = 1; i <= N; ++i) {                              /* SR:401 */
+        const size_t r = (size_t)N * a + (i - 1);
+        const float r1 = b->ray_dirs[2 * r], r2 = b->ray_dirs[2 * r + 1];
+        /* projected = dist * sum(dir .* ray)  SR:404 */
+        const float dot = p1 * r1 + p2 * r2;
+        const float projected = b->ray_dist[r] * dot;
+        /* height_line = camh * num_rays / (2 * fov * projected)  SR:406 (left assoc.) */
+        const float num = c->camera_height_tile_wu * (float)N;
+        const float den = (2.0f * c->semi_field_of_view_wu) * projected;
+        const float height_line = num / den;
+        int64_t h;
+        if (isfinite(height_line)) {                                /* SR:407-411 */
+            const float fl = floorf(height_line);
+            /* floor(Int, x): Julia raises InexactError outside Int64; saturate instead */
+            if (fl >= 9.2233720368547758e18f) h = INT64_MAX;
+            else if (fl <= -9.2233720368547758e18f) h = INT64_MIN;
+            else h = (int64_t)fl;
+        } else {
+            h = Hc;
+        }
+        const int64_t dim = b->ray_dim[r];
+        const int64_t ih = b->ray_stop[2 * r], jh = b->ray_stop[2 * r + 1];
+        const int is_wall = b->wall[HW * a + (size_t)(ih - 1) + (size_t)H * (jh - 1)]; /* SR:417 */
+        uint32_t colour; uint8_t cid;
+        if (is_wall) {                                              /* SR:417-423 */
+            if (dim == 1) { colour = c->wall_dim_1_color; cid = RCW_COLOUR_WALL_DIM_1; }
+            else          { colour = c->wall_dim_2_color; cid = RCW_COLOUR_WALL_DIM_2; }
+        } else {                                                    /* SR:424-429 */
+            if (dim == 1) { colour = c->goal_dim_1_color; cid = RCW_COLOUR_GOAL_DIM_1; }
+            else          { colour = c->goal_dim_2_color; cid = RCW_COLOUR_GOAL_DIM_2; }
+        }
+        const int32_t k = N - i + 1;                                /* SR:431 */
+        b->col_height[(size_t)N * a + (k - 1)] =
+            h > INT32_MAX ? INT32_MAX : (h < INT32_MIN ? INT32_MIN : (int32_t)h);
+        b->col_colour[(size_t)N * a + (k - 1)] = cid;
+        if (!b->render) continue;
+        uint32_t* col = view + (size_t)Hc * (k - 1);
+        if (h >= Hc - 1) {                                          /* SR:433-434 */
+            for (int32_t q = 0; q < Hc; ++q) col[q] = colour;
+        } else {
+            const int64_t pad = (Hc - h) / 2;                       /* SR:436 */
+            /* 1-based rows 1:pad, pad+1:Hc-pad, Hc-pad+1:Hc  SR:437-439; a negative h
+             * (unreachable: distances are positive) would make Julia throw BoundsError,
+             * clamp to the frame instead */
+            const int64_t top = pad > Hc ? Hc : pad;
+            const int64_t bot = Hc - pad < 0 ? 0 : Hc - pad;
+            for (int64_t q = 0; q < top; ++q) col[q] = c->ceiling_color;
+            for (int64_t q = top; q < bot; ++q) col[q] = colour;
+            for (int64_t q = bot > top ? bot : top; q < Hc; ++q) col[q] = c->floor_color;
+        }
+    }
+}
+
+static void orc_render_agent(orc_batch* b, int32_t a)
+{
+    orc_cast_rays_agent(b, a);            /* SR:336 / SR:134 */
+    orc_update_camera_view_agent(b, a);   /* SR:338 / SR:329 */
+}
+
+/* reset!(world)  SR:110-137 with the build's generator */
+static void orc_reset_agent(orc_batch* b, int32_t a, uint64_t seed)
+{
+    const int32_t H = b->H, W = b->W;
+    const size_t HW = (size_t)H * W;
+    const uint64_t key = orc_episode_key(seed, (uint64_t)(b->cfg.agent_id_offset + a),
+                                         (uint64_t)b->episode[a]);
+    uint64_t n = 0;
+    uint8_t* gm = b->goalmap + HW * a;
+    const uint8_t* wm = b->wall + HW * a;
+    /* tile_map[GOAL, goal_position] = false  SR:118 */
+    gm[(b->goal[2 * a] - 1) + (size_t)H * (b->goal[2 * a + 1] - 1)] = 0;
+    /* CartesianIndex(rand(2:H-1), rand(2:W-1))  SR:120 */
+    const int32_t gi = 2 + (int32_t)orc_below(orc_draw(key, n++), (uint64_t)(H - 2));
+    const int32_t gj = 2 + (int32_t)orc_below(orc_draw(key, n++), (uint64_t)(W - 2));
+    b->goal[2 * a] = gi; b->goal[2 * a + 1] = gj;                    /* SR:121 */
+    gm[(gi - 1) + (size_t)H * (gj - 1)] = 1;                         /* SR:122 */
+    /* sample_empty_position(rng, tile_map)  UT:52-58 -> UT:23-37 */
+    const uint64_t max_tries = (uint64_t)1024 * H * W;
+    uint64_t lin = orc_below(orc_draw(key, n++), (uint64_t)HW);      /* UT:24 */
+    for (uint64_t t = 0; t < max_tries; ++t) {                       /* UT:26 */
+        if (wm[lin] | gm[lin]) lin = orc_below(orc_draw(key, n++), (uint64_t)HW); /* UT:27-28 */
+        else break;
+    }
+    const int32_t pi = (int32_t)(lin % (uint64_t)H) + 1, pj = (int32_t)(lin / (uint64_t)H) + 1;
+    b->pos[2 * a] = (float)((double)pi - 0.5);                       /* SR:125 */
+    b->pos[2 * a + 1] = (float)((double)pj - 0.5);
+    b->dir[a] = (int32_t)orc_below(orc_draw(key, n++), (uint64_t)b->nd);   /* SR:128 */
+    b->reward[a] = 0.0f; b->done[a] = 0;                             /* SR:131-132 */
+    b->episode[a] += 1;
+    orc_render_agent(b, a);                                          /* SR:134, SR:329 */
+}
+
+ORC_EXPORT int orc_create(const rcw_config* cfg, int32_t batch, uint64_t seed, int render,
+                          orc_batch** out)
+{
+    if (!cfg || !out || batch < 1) return RCW_ERR_INVALID_ARGUMENT;
+    const int32_t H = cfg->height_tile_map_tu, W = cfg->width_tile_map_tu;
+    if (H < 3 || W < 3 || cfg->num_rays < 1 || cfg->num_directions < 1 ||
+        cfg->height_camera_view_pu < 1)
+        return RCW_ERR_INVALID_ARGUMENT;
+    orc_batch* b = (orc_batch*)calloc(1, sizeof *b);
+    if (!b) return RCW_ERR_OUT_OF_MEMORY;
+    b->cfg = *cfg; b->B = batch; b->H = H; b->W = W; b->N = cfg->num_rays;
+    b->nd = cfg->num_directions; b->Hc = cfg->height_camera_view_pu; b->seed = seed;
+    b->nchunks = (2 * H * W + 63) / 64; b->render = render;
+    const size_t B = (size_t)batch, HW = (size_t)H * W, N = (size_t)b->N;
+    b->directions = (float*)malloc(sizeof(float) * 2 * b->nd);
+    b->ray_table = (float*)malloc(sizeof(float) * 2 * N * b->nd);
+    b->wall = (uint8_t*)calloc(HW * B, 1);
+    b->goalmap = (uint8_t*)calloc(HW * B, 1);
+    b->pos = (float*)calloc(2 * B, sizeof(float));
+    b->dir = (int32_t*)calloc(B, sizeof(int32_t));
+    b->goal = (int32_t*)calloc(2 * B, sizeof(int32_t));
+    b->reward = (float*)calloc(B, sizeof(float));
+    b->done = (uint8_t*)calloc(B, 1);
+    b->episode = (uint32_t*)calloc(B, sizeof(uint32_t));
+    b->status = (int32_t*)calloc(B, sizeof(int32_t));
+    b->ray_stop = (int64_t*)calloc(2 * N * B, sizeof(int64_t));
+    b->ray_dim = (int64_t*)calloc(N * B, sizeof(int64_t));
+    b->ray_dist = (float*)calloc(N * B, sizeof(float));
+    b->ray_dirs = (float*)calloc(2 * N * B, sizeof(float));
+    b->camera_view = (uint32_t*)calloc(render ? (size_t)b->Hc * N * B : 1, sizeof(uint32_t));
+    b->col_height = (int32_t*)calloc(N * B, sizeof(int32_t));
+    b->col_colour = (uint8_t*)calloc(N * B, 1);
+    if (!b->directions || !b->ray_table || !b->wall || !b->goalmap || !b->pos || !b->dir ||
+        !b->goal || !b->reward || !b->done || !b->episode || !b->status || !b->ray_stop ||
+        !b->ray_dim || !b->ray_dist || !b->ray_dirs || !b->camera_view || !b->col_height ||
+        !b->col_colour) { orc_destroy(b); return RCW_ERR_OUT_OF_MEMORY; }
+    orc_direction_table(b->nd, b->directions);
+    orc_build_ray_table(b);
+    for (size_t a = 0; a < B; ++a) {
+        uint8_t* wm = b->wall + HW * a;
+        /* wall ring SR:57-60 */
+        for (int32_t i = 0; i < H; ++i) { wm[i] = 1; wm[i + (size_t)H * (W - 1)] = 1; }
+        for (int32_t j = 0; j < W; ++j) { wm[(size_t)H * j] = 1; wm[(H - 1) + (size_t)H * j] = 1; }
+        b->goal[2 * a] = 2; b->goal[2 * a + 1] = 2;   /* placeholder cleared by reset */
+    }
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < batch; ++a) orc_reset_agent(b, a, seed);
+    *out = b;
+    return RCW_OK;
+}
+
+ORC_EXPORT int orc_set_direction_table(orc_batch* b, const float* dirs)
+{
+    memcpy(b->directions, dirs, sizeof(float) * 2 * b->nd);
+    orc_build_ray_table(b);
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < b->B; ++a) orc_render_agent(b, a);
+    return RCW_OK;
+}
+
+ORC_EXPORT int orc_reset(orc_batch* b, const uint8_t* mask, uint64_t seed)
+{
+    b->seed = seed;
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < b->B; ++a)
+        if (!mask || mask[a]) orc_reset_agent(b, a, seed);
+    return RCW_OK;
+}
+
+ORC_EXPORT int orc_set_state(orc_batch* b, const int32_t* goal_ij, const float* pos,
+                             const int32_t* dir, const uint8_t* mask)
+{
+    const int32_t H = b->H, W = b->W;
+    const size_t HW = (size_t)H * W;
+    for (int32_t a = 0; a < b->B; ++a) {
+        if (mask && !mask[a]) continue;
+        const int32_t gi = goal_ij[2 * a], gj = goal_ij[2 * a + 1];
+        if (gi < 2 || gi > H - 1 || gj < 2 || gj > W - 1) return RCW_ERR_INVALID_ARGUMENT;
+        if (dir[a] < 0 || dir[a] >= b->nd) return RCW_ERR_INVALID_ARGUMENT;
+        if (!isfinite(pos[2 * a]) || !isfinite(pos[2 * a + 1])) return RCW_ERR_INVALID_ARGUMENT;
+        if (!(pos[2 * a] >= 1.0f && pos[2 * a] < (float)(H - 1) && pos[2 * a + 1] >= 1.0f &&
+              pos[2 * a + 1] < (float)(W - 1))) return RCW_ERR_INVALID_ARGUMENT;
+    }
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < b->B; ++a) {
+        if (mask && !mask[a]) continue;
+        uint8_t* gm = b->goalmap + HW * a;
+        gm[(b->goal[2 * a] - 1) + (size_t)H * (b->goal[2 * a + 1] - 1)] = 0;   /* SR:118 */
+        b->goal[2 * a] = goal_ij[2 * a]; b->goal[2 * a + 1] = goal_ij[2 * a + 1];
+        gm[(b->goal[2 * a] - 1) + (size_t)H * (b->goal[2 * a + 1] - 1)] = 1;   /* SR:122 */
+        b->pos[2 * a] = pos[2 * a]; b->pos[2 * a + 1] = pos[2 * a + 1];        /* SR:126 */
+        b->dir[a] = dir[a];                                                     /* SR:129 */
+        b->reward[a] = 0.0f; b->done[a] = 0;                                    /* SR:131-132 */
+        orc_render_agent(b, a);
+    }
+    return RCW_OK;
+}
+
+/* act!(world, action)  SR:139-191 for agent a */
+static void orc_act_agent(orc_batch* b, int32_t a, int action)
+{
+    const int32_t H = b->H, W = b->W, nd = b->nd;
+    const size_t HW = (size_t)H * W;
+    if (action <= 2) {                                              /* SR:150 */
+        const float d1 = b->directions[2 * b->dir[a]], d2 = b->directions[2 * b->dir[a] + 1];
+        const float inc = b->cfg.position_increment_wu;
+        float nx, ny;
+        if (action == 1) { nx = b->pos[2 * a] + inc * d1; ny = b->pos[2 * a + 1] + inc * d2; } /* UT:16 */
+        else             { nx = b->pos[2 * a] - inc * d1; ny = b->pos[2 * a + 1] - inc * d2; } /* UT:17 */
+        const int g = orc_is_player_colliding(b->goalmap + HW * a, H, W, nx, ny,
+                                              b->cfg.player_radius_wu);          /* SR:162 */
+        const int w = orc_is_player_colliding(b->wall + HW * a, H, W, nx, ny,
+                                              b->cfg.player_radius_wu);          /* SR:163 */
+        if (g < 0 || w < 0) {   /* Julia: BoundsError before any mutation */
+            b->status[a] = RCW_ERR_OUT_OF_BOUNDS;
+            return;
+        }
+        if (g || w) {                                               /* SR:165 */
+            if (g) { b->reward[a] = b->cfg.goal_reward; b->done[a] = 1; }   /* SR:166-168 */
+            else   { b->reward[a] = 0.0f; b->done[a] = 0; }                 /* SR:170-171 */
+        } else {
+            b->pos[2 * a] = nx; b->pos[2 * a + 1] = ny;             /* SR:174 */
+            b->reward[a] = 0.0f; b->done[a] = 0;                    /* SR:175-176 */
+        }
+    } else {
+        int32_t d = b->dir[a];
+        if (action == 3) d = (d + 1) % nd;                          /* turn_left UT:13 */
+        else             d = ((d - 1) % nd + nd) % nd;              /* turn_right UT:14 (floored mod) */
+        b->dir[a] = d;                                              /* SR:185 */
+        b->reward[a] = 0.0f; b->done[a] = 0;                        /* SR:186-187 */
+    }
+}
+
+/* act!(env, action)  SR:333-340 (minus update_top_view!) for the whole batch */
+ORC_EXPORT int orc_step(orc_batch* b, const uint8_t* actions)
+{
+    for (int32_t a = 0; a < b->B; ++a)                              /* @assert SR:140 */
+        if (actions[a] < 1 || actions[a] > RCW_NUM_ACTIONS) return RCW_ERR_INVALID_ACTION;
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < b->B; ++a) {
+        if (b->cfg.auto_reset && b->done[a]) {
+            orc_reset_agent(b, a, b->seed);
+            continue;
+        }
+        orc_act_agent(b, a, actions[a]);    /* SR:335 */
+        orc_render_agent(b, a);             /* SR:336, SR:338 */
+    }
+    return RCW_OK;
+}
+
+/* ---- getters ----------------------------------------------------------------------- */
+ORC_EXPORT const uint32_t* orc_camera_view(orc_batch* b) { return b->camera_view; }
+ORC_EXPORT const float* orc_reward(orc_batch* b) { return b->reward; }
+ORC_EXPORT const uint8_t* orc_done(orc_batch* b) { return b->done; }
+ORC_EXPORT const float* orc_position(orc_batch* b) { return b->pos; }
+ORC_EXPORT const int32_t* orc_direction(orc_batch* b) { return b->dir; }
+ORC_EXPORT const int32_t* orc_goal(orc_batch* b) { return b->goal; }
+ORC_EXPORT const uint32_t* orc_episode(orc_batch* b) { return b->episode; }
+ORC_EXPORT const int32_t* orc_status(orc_batch* b) { return b->status; }
+ORC_EXPORT const int64_t* orc_ray_stop(orc_batch* b) { return b->ray_stop; }
+ORC_EXPORT const int64_t* orc_ray_dim(orc_batch* b) { return b->ray_dim; }
+ORC_EXPORT const float* orc_ray_dist(orc_batch* b) { return b->ray_dist; }
+ORC_EXPORT const float* orc_ray_dirs(orc_batch* b) { return b->ray_dirs; }
+ORC_EXPORT const int32_t* orc_col_height(orc_batch* b) { return b->col_height; }
+ORC_EXPORT const uint8_t* orc_col_colour(orc_batch* b) { return b->col_colour; }
+ORC_EXPORT const float* orc_directions(orc_batch* b) { return b->directions; }
+ORC_EXPORT const float* orc_ray_table(orc_batch* b) { return b->ray_table; }
+ORC_EXPORT int32_t orc_num_chunks(orc_batch* b) { return b->nchunks; }
+
+/* tile_map as BitArray{3}(2, H, W).chunks per agent: UInt64 (nchunks, B)  SR:54 */
+ORC_EXPORT void orc_tile_map_chunks(orc_batch* b, uint64_t* out)
+{
+    const int32_t H = b->H, W = b->W;
+    const size_t HW = (size_t)H * W;
+    memset(out, 0, sizeof(uint64_t) * (size_t)b->nchunks * b->B);
+    for (int32_t a = 0; a < b->B; ++a)
+        for (int32_t j = 0; j < W; ++j)
+            for (int32_t i = 0; i < H; ++i) {
+                const size_t t = (size_t)i + (size_t)H * j;
+                const size_t bit = 2 * t;
+                uint64_t* ch = out + (size_t)b->nchunks * a;
+                if (b->wall[HW * a + t])    ch[bit >> 6] |= 1ULL << (bit & 63);
+                if (b->goalmap[HW * a + t]) ch[(bit + 1) >> 6] |= 1ULL << ((bit + 1) & 63);
+            }
+}
+
+ORC_EXPORT int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORC_EXPORT void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,158 @@
+"""ctypes binding of librcw_hip.so (include/rcw.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at load
+time, and `rcw_create` itself fails on a machine without a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "librcw_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "rcw.h")
+
+RCW_OK = 0
+RCW_ERR_INVALID_ARGUMENT = -1
+RCW_ERR_INVALID_ACTION = -2
+RCW_ERR_NO_DEVICE = -3
+RCW_ERR_OUT_OF_MEMORY = -4
+RCW_ERR_OUT_OF_BOUNDS = -5
+RCW_ERR_HIP = -6
+RCW_ERR_UNSUPPORTED = -7
+
+
+class RcwConfig(C.Structure):
+    """`rcw_config` (include/rcw.h): kwargs of SingleRoom(; ...) SR:258-272 + colours SR:288-296."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("height_tile_map_tu", C.c_int32),
+        ("width_tile_map_tu", C.c_int32),
+        ("num_directions", C.c_int32),
+        ("num_rays", C.c_int32),
+        ("height_camera_view_pu", C.c_int32),
+        ("pu_per_tu", C.c_int32),
+        ("player_radius_wu", C.c_float),
+        ("position_increment_wu", C.c_float),
+        ("semi_field_of_view_wu", C.c_float),
+        ("camera_height_tile_wu", C.c_float),
+        ("goal_reward", C.c_float),
+        ("floor_color", C.c_uint32),
+        ("ceiling_color", C.c_uint32),
+        ("wall_dim_1_color", C.c_uint32),
+        ("wall_dim_2_color", C.c_uint32),
+        ("goal_dim_1_color", C.c_uint32),
+        ("goal_dim_2_color", C.c_uint32),
+        ("dda_tie_break", C.c_int32),
+        ("dda_distance", C.c_int32),
+        ("normalize_mode", C.c_int32),
+        ("auto_reset", C.c_int32),
+        ("agent_id_offset", C.c_int64),
+        ("write_columns", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class RcwError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"librcw_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_u64 = C.c_uint64
+
+# name -> argtypes; every function returns int unless listed in _RESTYPE
+SIGNATURES = {
+    "rcw_abi_version": [],
+    "rcw_last_error": [],
+    "rcw_config_default": [C.POINTER(RcwConfig)],
+    "rcw_create": [C.POINTER(RcwConfig), _i32, _i32, _u64, C.POINTER(_vp)],
+    "rcw_destroy": [_vp],
+    "rcw_set_direction_table": [_vp, _vp],
+    "rcw_set_stream": [_vp, _vp],
+    "rcw_bind_obs": [_vp, _vp],
+    "rcw_reset": [_vp, _vp, _u64],
+    "rcw_set_state": [_vp, _vp, _vp, _vp, _vp],
+    "rcw_step": [_vp, _vp],
+    "rcw_step_device": [_vp, _vp],
+    "rcw_sync": [_vp],
+    "rcw_clear_error": [_vp],
+    "rcw_obs_device_ptr": [_vp, C.POINTER(_vp)],
+    "rcw_obs_copy": [_vp, _vp, _i32, _i32],
+    "rcw_reward": [_vp, _vp],
+    "rcw_done": [_vp, _vp],
+    "rcw_reward_device_ptr": [_vp, C.POINTER(_vp)],
+    "rcw_done_device_ptr": [_vp, C.POINTER(_vp)],
+    "rcw_position": [_vp, _vp],
+    "rcw_direction": [_vp, _vp],
+    "rcw_goal": [_vp, _vp],
+    "rcw_episode": [_vp, _vp],
+    "rcw_tile_map_num_chunks": [_vp, C.POINTER(_i32)],
+    "rcw_tile_map_chunks": [_vp, _vp],
+    "rcw_rays": [_vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "rcw_columns": [_vp, _i32, _i32, _vp, _vp],
+    "rcw_columns_device_ptr": [_vp, C.POINTER(_vp), C.POINTER(_vp)],
+    "rcw_expand_columns": [_vp, _vp, _vp, _i32, _vp],
+    "rcw_ray_table": [_vp, _vp],
+    "rcw_direction_table": [_vp, _vp],
+    "rcw_timer_start": [_vp],
+    "rcw_timer_stop": [_vp, C.POINTER(C.c_float)],
+    "rcw_batch": [_vp, C.POINTER(_i32)],
+    "rcw_get_config": [_vp, C.POINTER(RcwConfig)],
+    "rcw_device_name": [_vp, C.c_char_p, _i32],
+}
+_RESTYPE = {"rcw_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load librcw_hip.so; loud failure when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            f"(or `make -C raycastworlds.jl_amd/csrc`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.rcw_abi_version() != 1:
+        raise ImportError(f"librcw_hip ABI {lib.rcw_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().rcw_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> None:
+    if rc == RCW_OK:
+        return
+    msg = last_error()
+    if rc == RCW_ERR_INVALID_ACTION:
+        # the reference raises AssertionError("Invalid action: ...") at SR:140
+        raise AssertionError(msg or "Invalid action")
+    if rc == RCW_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    if rc == RCW_ERR_OUT_OF_BOUNDS:
+        raise IndexError(msg)   # Julia: BoundsError
+    if rc == RCW_ERR_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise RcwError(rc, msg)
+
+
+def default_config() -> RcwConfig:
+    cfg = RcwConfig()
+    check(load().rcw_config_default(C.byref(cfg)))
+    return cfg

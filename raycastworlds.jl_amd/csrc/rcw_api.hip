@@ -1,0 +1,655 @@
+// C ABI of librcw_hip (include/rcw.h): handle, HBM-resident state, host-built tables.
+// Host code in this file that does floating point follows the reference operation for
+// operation and must be compiled with -ffp-contract=off (see Makefile).
+#include "../../include/rcw.h"
+#include "rcw_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RCW_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                 \
+    } while (0)
+
+}  // namespace
+
+struct rcw_handle {
+    rcw_config cfg{};
+    int32_t B = 0, device = 0, nchunks = 0;
+    RcwDev dev{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // device allocations
+    void* d_pos = nullptr; void* d_dir = nullptr; void* d_goal = nullptr; void* d_reward = nullptr;
+    void* d_done = nullptr; void* d_episode = nullptr; void* d_tile_map = nullptr;
+    void* d_dir_table = nullptr; void* d_ray_table = nullptr; void* d_obs = nullptr;
+    void* d_col_h = nullptr; void* d_col_c = nullptr; void* d_err = nullptr;
+    void* d_actions = nullptr; void* d_mask = nullptr;
+    void* d_in_goal = nullptr; void* d_in_pos = nullptr; void* d_in_dir = nullptr;
+    int32_t* h_err = nullptr;   // pinned
+    uint8_t* h_actions[2] = {nullptr, nullptr};   // pinned staging ring for rcw_step
+    hipEvent_t ev_actions[2] = {nullptr, nullptr};
+    int action_slot = 0;
+    std::vector<float> dir_table;   // (2, nd)
+    std::vector<float> ray_table;   // (N, 5, nd)
+};
+
+namespace {
+
+void free_all(rcw_handle* h)
+{
+    void** ptrs[] = {&h->d_pos, &h->d_dir, &h->d_goal, &h->d_reward, &h->d_done, &h->d_episode,
+                     &h->d_tile_map, &h->d_dir_table, &h->d_ray_table, &h->d_obs, &h->d_col_h,
+                     &h->d_col_c, &h->d_err, &h->d_actions, &h->d_mask, &h->d_in_goal,
+                     &h->d_in_pos, &h->d_in_dir};
+    for (void** p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (h->h_err) (void)hipHostFree(h->h_err);
+    h->h_err = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        if (h->h_actions[k]) (void)hipHostFree(h->h_actions[k]);
+        if (h->ev_actions[k]) (void)hipEventDestroy(h->ev_actions[k]);
+        h->h_actions[k] = nullptr;
+        h->ev_actions[k] = nullptr;
+    }
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    h->ev_start = h->ev_stop = nullptr;
+    h->own_stream = nullptr;
+}
+
+// directions_wu  SR:65-69: theta = (i-1)*2*pi/nd in Float64, components rounded to Float32
+void build_direction_table(int nd, std::vector<float>& out)
+{
+    out.resize((size_t)2 * nd);
+    for (int i = 1; i <= nd; ++i) {
+        const double theta = (double)((long long)(i - 1) * 2) * 3.141592653589793 / (double)nd;
+        out[2 * (size_t)(i - 1)] = (float)std::cos(theta);
+        out[2 * (size_t)(i - 1) + 1] = (float)std::sin(theta);
+    }
+}
+
+// Per heading d and ray i (SR:214-221, SR:404): the fan end points dir ± fov·rot₋₉₀(dir),
+// the LinRange element (Float64 lerp rounded to Float32), its normalisation, and the
+// derived |1/dx|, |1/dy| (cast_ray's delta distances) and dir·ray (SR:404).
+// Layout [nd][5][N]: see RCW_TABLE_ROWS.
+void build_ray_table(const rcw_config& c, const std::vector<float>& dirs, std::vector<float>& out)
+{
+    const int N = c.num_rays, nd = c.num_directions;
+    const float fov = c.semi_field_of_view_wu;
+    out.assign((size_t)nd * RCW_TABLE_ROWS * N, 0.0f);
+    const int lendiv = N - 1 > 1 ? N - 1 : 1;   // LinRange lendiv = max(len - 1, 1)
+    for (int d = 0; d < nd; ++d) {
+        const float d1 = dirs[2 * (size_t)d], d2 = dirs[2 * (size_t)d + 1];
+        const float cam1 = d2, cam2 = -d1;                    // rotate_minus_90 SR:193
+        const float fc1 = fov * cam1, fc2 = fov * cam2;
+        const float first1 = d1 + fc1, first2 = d2 + fc2;     // SR:216
+        const float last1 = d1 - fc1, last2 = d2 - fc2;       // SR:217
+        float* row = out.data() + (size_t)d * RCW_TABLE_ROWS * N;
+        for (int i = 0; i < N; ++i) {
+            const double t = (double)i / (double)lendiv;      // lerpi: t = j/d in Float64
+            const double omt = 1.0 - t;
+            const double a1 = omt * (double)first1, b1 = t * (double)last1;
+            const double a2 = omt * (double)first2, b2 = t * (double)last2;
+            const float u1 = (float)(a1 + b1);
+            const float u2 = (float)(a2 + b2);
+            const float s1 = u1 * u1, s2 = u2 * u2;
+            const float nrm = std::sqrt(s1 + s2);             // norm(SVector) = sqrt(sum abs2)
+            float r1, r2;
+            if (c.normalize_mode == RCW_NORMALIZE_DIVIDE) {
+                r1 = u1 / nrm; r2 = u2 / nrm;
+            } else {
+                const float inv = 1.0f / nrm;                 // inv(norm(a)) * a
+                r1 = inv * u1; r2 = inv * u2;
+            }
+            const float m1 = d1 * r1, m2 = d2 * r2;           // sum(dir .* ray) SR:404
+            row[i] = r1;
+            row[(size_t)N + i] = r2;
+            row[2 * (size_t)N + i] = std::fabs(1.0f / r1);
+            row[3 * (size_t)N + i] = std::fabs(1.0f / r2);
+            row[4 * (size_t)N + i] = m1 + m2;
+        }
+    }
+}
+
+int upload_tables(rcw_handle* h)
+{
+    RCW_HIP(hipMemcpyAsync(h->d_dir_table, h->dir_table.data(), h->dir_table.size() * sizeof(float),
+                           hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipMemcpyAsync(h->d_ray_table, h->ray_table.data(), h->ray_table.size() * sizeof(float),
+                           hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    return RCW_OK;
+}
+
+int validate_config(const rcw_config* c, int32_t batch)
+{
+    if (c->abi_version != RCW_ABI_VERSION)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "rcw_config.abi_version %d != %d", c->abi_version, RCW_ABI_VERSION);
+    if (batch < 1) return fail(RCW_ERR_INVALID_ARGUMENT, "batch must be >= 1 (got %d)", batch);
+    if (c->height_tile_map_tu < 3 || c->width_tile_map_tu < 3)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "tile map must be at least 3x3 (got %dx%d)",
+                    c->height_tile_map_tu, c->width_tile_map_tu);
+    if ((long long)c->height_tile_map_tu * c->width_tile_map_tu > 65536)
+        return fail(RCW_ERR_UNSUPPORTED, "tile map larger than 65536 tiles does not fit the LDS staging");
+    if (c->num_directions < 1 || c->num_rays < 1 || c->height_camera_view_pu < 1)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "num_directions, num_rays, height_camera_view_pu must be >= 1");
+    if (c->num_rays > 8192) return fail(RCW_ERR_UNSUPPORTED, "num_rays > 8192 does not fit the LDS column buffer");
+    if (c->num_rays > (1 << 24)) return fail(RCW_ERR_INVALID_ARGUMENT, "num_rays not exactly representable in Float32");
+    if (!(c->player_radius_wu > 0.0f && c->player_radius_wu < 0.5f))   // "should be less than 0.5" SR:47
+        return fail(RCW_ERR_INVALID_ARGUMENT, "player_radius_wu must be in (0, 0.5)");
+    if (!(c->position_increment_wu > 0.0f) || !std::isfinite(c->position_increment_wu))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "position_increment_wu must be positive and finite");
+    if (!(c->semi_field_of_view_wu > 0.0f) || !std::isfinite(c->semi_field_of_view_wu))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "semi_field_of_view_wu must be positive and finite");
+    if (!(c->camera_height_tile_wu > 0.0f) || !std::isfinite(c->camera_height_tile_wu))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "camera_height_tile_wu must be positive and finite");
+    if (c->dda_tie_break < 0 || c->dda_tie_break > 1 || c->dda_distance < 0 || c->dda_distance > 1 ||
+        c->normalize_mode < 0 || c->normalize_mode > 1)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "dda_tie_break / dda_distance / normalize_mode out of range");
+    return RCW_OK;
+}
+
+// Wait for the stream, then surface the sticky device error word.
+int sync_and_check(rcw_handle* h)
+{
+    RCW_HIP(hipMemcpyAsync(h->h_err, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    const int32_t e = *h->h_err;
+    if (e == RCW_ERR_INVALID_ACTION) return fail(e, "invalid action (must be in 1..%d); no agent was stepped", RCW_NUM_ACTIONS);
+    if (e == RCW_ERR_OUT_OF_BOUNDS) return fail(e, "a tile index left the tile map (BoundsError in the reference)");
+    if (e != 0) return fail(e, "device error %d", e);
+    return RCW_OK;
+}
+
+int check_handle(rcw_handle* h)
+{
+    if (!h) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL handle");
+    RCW_HIP(hipSetDevice(h->device));
+    return RCW_OK;
+}
+
+int upload_mask(rcw_handle* h, const uint8_t* mask_host, const uint8_t** mask_dev)
+{
+    *mask_dev = nullptr;
+    if (!mask_host) return RCW_OK;
+    RCW_HIP(hipMemcpyAsync(h->d_mask, mask_host, (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    // the host buffer may be pageable and reused by the caller right away
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    *mask_dev = (const uint8_t*)h->d_mask;
+    return RCW_OK;
+}
+
+template <typename T>
+int copy_out(rcw_handle* h, T* out_host, const void* dev, size_t count)
+{
+    if (!out_host) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL output pointer");
+    int rc = sync_and_check(h);
+    RCW_HIP(hipMemcpy(out_host, dev, count * sizeof(T), hipMemcpyDeviceToHost));
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcw_abi_version(void) { return RCW_ABI_VERSION; }
+const char* rcw_last_error(void) { return g_err; }
+
+int rcw_config_default(rcw_config* c)
+{
+    if (!c) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL config");
+    std::memset(c, 0, sizeof *c);
+    c->abi_version = RCW_ABI_VERSION;
+    c->height_tile_map_tu = 8;          // SR:260
+    c->width_tile_map_tu = 16;          // SR:261
+    c->num_directions = 128;            // SR:262
+    c->num_rays = 512;                  // SR:268
+    c->height_camera_view_pu = 256;     // SR:271
+    c->pu_per_tu = 32;                  // SR:269
+    c->player_radius_wu = (float)(1.0 / 8.0);        // convert(T, 1/8) SR:263
+    c->position_increment_wu = (float)(1.0 / 8.0);   // SR:264
+    c->semi_field_of_view_wu = (float)(2.0 / 3.0);   // convert(T, 2/3) SR:267
+    c->camera_height_tile_wu = 1.0f;    // SR:270
+    c->goal_reward = 1.0f;              // one(R) SR:86
+    c->floor_color = 0x00404040u;       // SR:291
+    c->ceiling_color = 0x00FFFFFFu;     // SR:292
+    c->wall_dim_1_color = 0x00808080u;  // SR:293
+    c->wall_dim_2_color = 0x00c0c0c0u;  // SR:294
+    c->goal_dim_1_color = 0x00800000u;  // SR:295
+    c->goal_dim_2_color = 0x00c00000u;  // SR:296
+    c->dda_tie_break = RCW_DDA_TIE_X_FIRST_ON_LT;
+    c->dda_distance = RCW_DDA_DIST_SIDE_MINUS_DELTA;
+    c->normalize_mode = RCW_NORMALIZE_INV_NORM_TIMES;
+    c->auto_reset = 0;
+    c->agent_id_offset = 0;
+    c->write_columns = 1;
+    return RCW_OK;
+}
+
+int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t seed, rcw_handle** out)
+{
+    if (!cfg || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    int rc = validate_config(cfg, batch);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(RCW_ERR_NO_DEVICE, "no HIP device visible: librcw_hip has no CPU fallback");
+    if (device < 0 || device >= ndev)
+        return fail(RCW_ERR_NO_DEVICE, "device %d not in 0..%d", device, ndev - 1);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(RCW_ERR_NO_DEVICE, "hipGetDeviceProperties(%d) failed", device);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RCW_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    RCW_HIP(hipSetDevice(device));
+
+    rcw_handle* h = new (std::nothrow) rcw_handle();
+    if (!h) return fail(RCW_ERR_OUT_OF_MEMORY, "host allocation failed");
+    h->cfg = *cfg;
+    h->B = batch;
+    h->device = device;
+    const int H = cfg->height_tile_map_tu, W = cfg->width_tile_map_tu, N = cfg->num_rays;
+    const int nd = cfg->num_directions, Hc = cfg->height_camera_view_pu;
+    h->nchunks = (2 * H * W + 63) / 64;   // BitArray chunks: cld(2HW, 64)
+    const size_t B = (size_t)batch;
+
+#define RCW_TRY(expr)                                       \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            free_all(h);                                    \
+            delete h;                                       \
+            return fail(e_ == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, \
+                        "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                   \
+    } while (0)
+
+    RCW_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    RCW_TRY(hipEventCreate(&h->ev_start));
+    RCW_TRY(hipEventCreate(&h->ev_stop));
+    RCW_TRY(hipMalloc(&h->d_pos, B * sizeof(float2)));
+    RCW_TRY(hipMalloc(&h->d_dir, B * sizeof(int32_t)));
+    RCW_TRY(hipMalloc(&h->d_goal, B * sizeof(int2)));
+    RCW_TRY(hipMalloc(&h->d_reward, B * sizeof(float)));
+    RCW_TRY(hipMalloc(&h->d_done, B));
+    RCW_TRY(hipMalloc(&h->d_episode, B * sizeof(uint32_t)));
+    RCW_TRY(hipMalloc(&h->d_tile_map, B * (size_t)h->nchunks * sizeof(uint64_t)));
+    RCW_TRY(hipMalloc(&h->d_dir_table, (size_t)nd * sizeof(float2)));
+    RCW_TRY(hipMalloc(&h->d_ray_table, (size_t)nd * RCW_TABLE_ROWS * N * sizeof(float)));
+    RCW_TRY(hipMalloc(&h->d_obs, B * (size_t)N * Hc * sizeof(uint32_t)));
+    if (cfg->write_columns) {
+        RCW_TRY(hipMalloc(&h->d_col_h, B * (size_t)N * sizeof(int32_t)));
+        RCW_TRY(hipMalloc(&h->d_col_c, B * (size_t)N));
+    }
+    RCW_TRY(hipMalloc(&h->d_err, sizeof(int32_t)));
+    RCW_TRY(hipMalloc(&h->d_actions, B));
+    RCW_TRY(hipMalloc(&h->d_mask, B));
+    RCW_TRY(hipMalloc(&h->d_in_goal, B * sizeof(int2)));
+    RCW_TRY(hipMalloc(&h->d_in_pos, B * sizeof(float2)));
+    RCW_TRY(hipMalloc(&h->d_in_dir, B * sizeof(int32_t)));
+    RCW_TRY(hipHostMalloc((void**)&h->h_err, sizeof(int32_t), hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) {
+        RCW_TRY(hipHostMalloc((void**)&h->h_actions[k], B, hipHostMallocDefault));
+        RCW_TRY(hipEventCreateWithFlags(&h->ev_actions[k], hipEventDisableTiming));
+    }
+    RCW_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+#undef RCW_TRY
+
+    RcwDev& d = h->dev;
+    d.B = batch; d.H = H; d.W = W; d.N = N; d.nd = nd; d.Hc = Hc;
+    d.nwords = h->nchunks * 2;
+    d.radius = cfg->player_radius_wu;
+    d.radius_sq = cfg->player_radius_wu * cfg->player_radius_wu;        // radius * radius CD:18
+    d.inc = cfg->position_increment_wu;
+    d.goal_reward = cfg->goal_reward;
+    d.num = cfg->camera_height_tile_wu * (float)N;                      // SR:406 numerator
+    d.two_fov = 2.0f * cfg->semi_field_of_view_wu;                      // 2 * fov
+    d.floor_color = cfg->floor_color; d.ceiling_color = cfg->ceiling_color;
+    d.colour[RCW_COLOUR_WALL_DIM_1] = cfg->wall_dim_1_color;
+    d.colour[RCW_COLOUR_WALL_DIM_2] = cfg->wall_dim_2_color;
+    d.colour[RCW_COLOUR_GOAL_DIM_1] = cfg->goal_dim_1_color;
+    d.colour[RCW_COLOUR_GOAL_DIM_2] = cfg->goal_dim_2_color;
+    d.tie_le = cfg->dda_tie_break == RCW_DDA_TIE_X_FIRST_ON_LE;
+    d.dist_pre = cfg->dda_distance == RCW_DDA_DIST_PRE_INCREMENT;
+    d.auto_reset = cfg->auto_reset ? 1 : 0;
+    d.agent_id_offset = cfg->agent_id_offset;
+    d.seed = seed;
+    d.pos = (float2*)h->d_pos; d.dir = (int32_t*)h->d_dir; d.goal = (int2*)h->d_goal;
+    d.reward = (float*)h->d_reward; d.done = (uint8_t*)h->d_done; d.episode = (uint32_t*)h->d_episode;
+    d.tile_map = (uint32_t*)h->d_tile_map;
+    d.dir_table = (const float2*)h->d_dir_table; d.ray_table = (const float*)h->d_ray_table;
+    d.obs = (uint32_t*)h->d_obs; d.col_h = (int32_t*)h->d_col_h; d.col_c = (uint8_t*)h->d_col_c;
+    d.err = (int32_t*)h->d_err;
+
+    if (rcw_step_lds_bytes(d) > 64 * 1024) {
+        free_all(h); delete h;
+        return fail(RCW_ERR_UNSUPPORTED, "tile map + column buffer need %zu B of LDS (> 64 KiB)", rcw_step_lds_bytes(d));
+    }
+
+    build_direction_table(nd, h->dir_table);
+    build_ray_table(h->cfg, h->dir_table, h->ray_table);
+    rc = upload_tables(h);
+    if (rc == RCW_OK) {
+        hipError_t e = rcw_launch_init_tile_map(d, h->stream);
+        if (e != hipSuccess) rc = fail(RCW_ERR_HIP, "init_tile_map launch: %s", hipGetErrorString(e));
+    }
+    if (rc == RCW_OK) rc = rcw_reset(h, nullptr, seed);
+    if (rc == RCW_OK) rc = sync_and_check(h);
+    if (rc != RCW_OK) { free_all(h); delete h; return rc; }
+    *out = h;
+    return RCW_OK;
+}
+
+int rcw_destroy(rcw_handle* h)
+{
+    if (!h) return RCW_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return RCW_OK;
+}
+
+int rcw_set_direction_table(rcw_handle* h, const float* directions_wu)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!directions_wu) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL direction table");
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    h->dir_table.assign(directions_wu, directions_wu + (size_t)2 * h->cfg.num_directions);
+    build_ray_table(h->cfg, h->dir_table, h->ray_table);
+    rc = upload_tables(h); if (rc) return rc;
+    RCW_HIP(rcw_launch_step(h->dev, nullptr, nullptr, h->stream));   // re-render
+    return RCW_OK;
+}
+
+int rcw_set_stream(rcw_handle* h, void* hip_stream)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return RCW_OK;
+}
+
+int rcw_bind_obs(rcw_handle* h, void* device_ptr)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    if (device_ptr && ((uintptr_t)device_ptr & 15u))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "observation buffer must be 16-byte aligned");
+    h->dev.obs = device_ptr ? (uint32_t*)device_ptr : (uint32_t*)h->d_obs;
+    return RCW_OK;
+}
+
+int rcw_reset(rcw_handle* h, const uint8_t* mask_host, uint64_t seed)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    const uint8_t* mask_dev = nullptr;
+    rc = upload_mask(h, mask_host, &mask_dev); if (rc) return rc;
+    h->dev.seed = seed;
+    RCW_HIP(rcw_launch_reset(h->dev, mask_dev, h->stream));            // SR:110-132
+    RCW_HIP(rcw_launch_step(h->dev, nullptr, mask_dev, h->stream));    // SR:134, SR:329
+    return RCW_OK;
+}
+
+int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_wu,
+                  const int32_t* direction_au, const uint8_t* mask_host)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!goal_ij || !position_wu || !direction_au) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL state array");
+    const int H = h->cfg.height_tile_map_tu, W = h->cfg.width_tile_map_tu;
+    for (int32_t a = 0; a < h->B; ++a) {
+        if (mask_host && !mask_host[a]) continue;
+        const int gi = goal_ij[2 * a], gj = goal_ij[2 * a + 1];
+        if (gi < 2 || gi > H - 1 || gj < 2 || gj > W - 1)   // rand(2:H-1), rand(2:W-1) SR:120
+            return fail(RCW_ERR_INVALID_ARGUMENT, "agent %d: goal (%d,%d) not an interior tile", a, gi, gj);
+        if (direction_au[a] < 0 || direction_au[a] >= h->cfg.num_directions)
+            return fail(RCW_ERR_INVALID_ARGUMENT, "agent %d: direction %d not in 0..%d", a, direction_au[a], h->cfg.num_directions - 1);
+        const float x = position_wu[2 * a], y = position_wu[2 * a + 1];
+        if (!(std::isfinite(x) && std::isfinite(y) && x >= 1.0f && x < (float)(H - 1) && y >= 1.0f && y < (float)(W - 1)))
+            return fail(RCW_ERR_INVALID_ARGUMENT, "agent %d: position (%g,%g) not inside the room", a, (double)x, (double)y);
+    }
+    const uint8_t* mask_dev = nullptr;
+    rc = upload_mask(h, mask_host, &mask_dev); if (rc) return rc;
+    const size_t B = (size_t)h->B;
+    RCW_HIP(hipMemcpyAsync(h->d_in_goal, goal_ij, B * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipMemcpyAsync(h->d_in_pos, position_wu, B * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipMemcpyAsync(h->d_in_dir, direction_au, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    RCW_HIP(rcw_launch_set_state(h->dev, (const int2*)h->d_in_goal, (const float2*)h->d_in_pos,
+                                 (const int32_t*)h->d_in_dir, mask_dev, h->stream));
+    RCW_HIP(rcw_launch_step(h->dev, nullptr, mask_dev, h->stream));
+    return RCW_OK;
+}
+
+int rcw_step(rcw_handle* h, const uint8_t* actions_host)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!actions_host) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL actions");
+    for (int32_t a = 0; a < h->B; ++a)   // @assert action in Base.OneTo(NUM_ACTIONS) SR:140
+        if (actions_host[a] < 1 || actions_host[a] > RCW_NUM_ACTIONS)
+            return fail(RCW_ERR_INVALID_ACTION, "Invalid action: %d (agent %d)", (int)actions_host[a], a);
+    // Stage through a pinned ring so the caller may reuse its buffer at once and the host
+    // can run one step ahead of the GPU; the copy is ordered on the stream behind the
+    // previous step, which is still reading d_actions.
+    const int slot = h->action_slot;
+    h->action_slot ^= 1;
+    RCW_HIP(hipEventSynchronize(h->ev_actions[slot]));
+    std::memcpy(h->h_actions[slot], actions_host, (size_t)h->B);
+    RCW_HIP(hipMemcpyAsync(h->d_actions, h->h_actions[slot], (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipEventRecord(h->ev_actions[slot], h->stream));
+    RCW_HIP(rcw_launch_step(h->dev, (const uint8_t*)h->d_actions, nullptr, h->stream));
+    return RCW_OK;
+}
+
+int rcw_step_device(rcw_handle* h, const uint8_t* actions_device)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!actions_device) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL actions");
+    RCW_HIP(rcw_launch_validate(h->dev, actions_device, h->stream));
+    RCW_HIP(rcw_launch_step(h->dev, actions_device, nullptr, h->stream));
+    return RCW_OK;
+}
+
+int rcw_sync(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    return sync_and_check(h);
+}
+
+int rcw_clear_error(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    return RCW_OK;
+}
+
+int rcw_obs_device_ptr(rcw_handle* h, void** device_ptr)
+{
+    if (!h || !device_ptr) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *device_ptr = h->dev.obs;
+    return RCW_OK;
+}
+
+int rcw_obs_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!out_host || first < 0 || count < 0 || first + (int64_t)count > h->B)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
+    rc = sync_and_check(h);
+    const size_t frame = (size_t)h->cfg.num_rays * h->cfg.height_camera_view_pu;
+    RCW_HIP(hipMemcpy(out_host, h->dev.obs + (size_t)first * frame, (size_t)count * frame * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int rcw_reward(rcw_handle* h, float* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_reward, (size_t)h->B); }
+int rcw_done(rcw_handle* h, uint8_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_done, (size_t)h->B); }
+int rcw_position(rcw_handle* h, float* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_pos, (size_t)2 * h->B); }
+int rcw_direction(rcw_handle* h, int32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_dir, (size_t)h->B); }
+int rcw_goal(rcw_handle* h, int32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_goal, (size_t)2 * h->B); }
+int rcw_episode(rcw_handle* h, uint32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_episode, (size_t)h->B); }
+
+int rcw_reward_device_ptr(rcw_handle* h, void** p)
+{
+    if (!h || !p) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *p = h->d_reward; return RCW_OK;
+}
+int rcw_done_device_ptr(rcw_handle* h, void** p)
+{
+    if (!h || !p) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *p = h->d_done; return RCW_OK;
+}
+
+int rcw_tile_map_num_chunks(rcw_handle* h, int32_t* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = h->nchunks; return RCW_OK;
+}
+int rcw_tile_map_chunks(rcw_handle* h, uint64_t* out)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    return copy_out(h, out, h->d_tile_map, (size_t)h->nchunks * h->B);
+}
+
+int rcw_rays(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int64_t* hit_dimension,
+             float* distance_wu, float* directions_wu)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (first < 0 || count < 1 || first + (int64_t)count > h->B)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
+    const size_t n = (size_t)count * h->cfg.num_rays;
+    RcwRayOut out{};
+    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto cleanup = [&]() { for (void* b : bufs) if (b) (void)hipFree(b); };
+#define RCW_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(RCW_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    if (stop_ij) { RCW_TRY(hipMalloc(&bufs[0], 2 * n * sizeof(int64_t))); out.stop_ij = (int64_t*)bufs[0]; }
+    if (hit_dimension) { RCW_TRY(hipMalloc(&bufs[1], n * sizeof(int64_t))); out.hit_dim = (int64_t*)bufs[1]; }
+    if (distance_wu) { RCW_TRY(hipMalloc(&bufs[2], n * sizeof(float))); out.dist = (float*)bufs[2]; }
+    if (directions_wu) { RCW_TRY(hipMalloc(&bufs[3], 2 * n * sizeof(float))); out.dirs = (float*)bufs[3]; }
+    RCW_TRY(rcw_launch_rays(h->dev, first, count, out, h->stream));
+    RCW_TRY(hipStreamSynchronize(h->stream));
+    if (stop_ij) RCW_TRY(hipMemcpy(stop_ij, bufs[0], 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (hit_dimension) RCW_TRY(hipMemcpy(hit_dimension, bufs[1], n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (distance_wu) RCW_TRY(hipMemcpy(distance_wu, bufs[2], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (directions_wu) RCW_TRY(hipMemcpy(directions_wu, bufs[3], 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+#undef RCW_TRY
+    cleanup();
+    return RCW_OK;
+}
+
+int rcw_columns(rcw_handle* h, int32_t first, int32_t count, int32_t* height_line_pu, uint8_t* colour_id)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!h->d_col_h) return fail(RCW_ERR_UNSUPPORTED, "handle was created with write_columns = 0");
+    if (first < 0 || count < 0 || first + (int64_t)count > h->B)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
+    rc = sync_and_check(h);
+    const size_t N = (size_t)h->cfg.num_rays;
+    if (height_line_pu)
+        RCW_HIP(hipMemcpy(height_line_pu, (int32_t*)h->d_col_h + (size_t)first * N, (size_t)count * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (colour_id)
+        RCW_HIP(hipMemcpy(colour_id, (uint8_t*)h->d_col_c + (size_t)first * N, (size_t)count * N, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** colour_id)
+{
+    if (!h) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (!h->d_col_h) return fail(RCW_ERR_UNSUPPORTED, "handle was created with write_columns = 0");
+    if (height_line_pu) *height_line_pu = h->d_col_h;
+    if (colour_id) *colour_id = h->d_col_c;
+    return RCW_OK;
+}
+
+int rcw_expand_columns(rcw_handle* h, const int32_t* height_line_pu_device, const uint8_t* colour_id_device,
+                       int32_t count, void* frames_device)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!height_line_pu_device || !colour_id_device || !frames_device || count < 1)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "bad argument");
+    if ((uintptr_t)frames_device & 15u) return fail(RCW_ERR_INVALID_ARGUMENT, "frames must be 16-byte aligned");
+    RCW_HIP(rcw_launch_expand(h->dev, height_line_pu_device, colour_id_device, count, (uint32_t*)frames_device, h->stream));
+    return RCW_OK;
+}
+
+int rcw_ray_table(rcw_handle* h, float* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memcpy(out, h->ray_table.data(), h->ray_table.size() * sizeof(float));
+    return RCW_OK;
+}
+int rcw_direction_table(rcw_handle* h, float* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memcpy(out, h->dir_table.data(), h->dir_table.size() * sizeof(float));
+    return RCW_OK;
+}
+
+int rcw_timer_start(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(hipEventRecord(h->ev_start, h->stream));
+    return RCW_OK;
+}
+int rcw_timer_stop(rcw_handle* h, float* elapsed_ms)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!elapsed_ms) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    RCW_HIP(hipEventRecord(h->ev_stop, h->stream));
+    RCW_HIP(hipEventSynchronize(h->ev_stop));
+    RCW_HIP(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+    return RCW_OK;
+}
+
+int rcw_batch(rcw_handle* h, int32_t* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = h->B; return RCW_OK;
+}
+int rcw_get_config(rcw_handle* h, rcw_config* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = h->cfg; return RCW_OK;
+}
+int rcw_device_name(rcw_handle* h, char* buf, int32_t buflen)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!buf || buflen < 1) return fail(RCW_ERR_INVALID_ARGUMENT, "bad buffer");
+    hipDeviceProp_t prop;
+    RCW_HIP(hipGetDeviceProperties(&prop, h->device));
+    std::snprintf(buf, (size_t)buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return RCW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Device-side view of one batch of SingleRoom agents and the kernel launchers.
+// State is structure-of-arrays in HBM, resident for the handle's lifetime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Per-direction ray table: for heading d the slice is 5 rows of N floats
+//   [dx | dy | |1/dx| | |1/dy| | dir . ray]
+// so lane i of the cast phase reads five coalesced floats (SR:214-221, SR:404).
+#define RCW_TABLE_ROWS 5
+
+struct RcwDev {
+    // geometry / config (all wave-uniform, live in SGPRs)
+    int32_t B, H, W, N, nd, Hc;
+    int32_t nwords;          // 32-bit words of one agent's tile_map (2 per UInt64 chunk)
+    float radius, radius_sq; // player_radius_wu, fl(r*r)            (CD:18)
+    float inc;               // position_increment_wu                (UT:16-17)
+    float goal_reward;       // SR:86
+    float num;               // fl(camera_height_tile_wu * N)        (SR:406)
+    float two_fov;           // fl(2 * semi_field_of_view_wu)        (SR:406)
+    uint32_t floor_color, ceiling_color;
+    uint32_t colour[4];      // indexed by RCW_COLOUR_*              (SR:293-296)
+    int32_t tie_le;          // RCW_DDA_TIE_X_FIRST_ON_LE
+    int32_t dist_pre;        // RCW_DDA_DIST_PRE_INCREMENT
+    int32_t auto_reset;
+    int64_t agent_id_offset;
+    uint64_t seed;
+    // state (SR:21-40), one entry per agent
+    float2* pos;             // player_position_wu
+    int32_t* dir;            // player_direction_au
+    int2* goal;              // goal_position (1-based i, j)
+    float* reward;
+    uint8_t* done;
+    uint32_t* episode;       // resets seen (keys the generator)
+    uint32_t* tile_map;      // BitArray{3}(2,H,W).chunks viewed as 32-bit words, [B][nwords]
+    // constants
+    const float2* dir_table; // directions_wu [nd]
+    const float* ray_table;  // [nd][RCW_TABLE_ROWS][N]
+    // outputs
+    uint32_t* obs;           // camera_view UInt32 (Hc, N, B)
+    int32_t* col_h;          // optional (N, B) height_line_pu by image column
+    uint8_t* col_c;          // optional (N, B) colour id by image column
+    int32_t* err;            // sticky error word (0 = ok)
+};
+
+struct RcwRayOut {           // rcw_rays(): SR:29-31,39 for agents [first, first+count)
+    int64_t* stop_ij;        // (2, N, count)
+    int64_t* hit_dim;        // (N, count)
+    float* dist;             // (N, count)
+    float* dirs;             // (2, N, count)
+};
+
+size_t rcw_step_lds_bytes(const RcwDev& p);
+
+// act!(env, a): dynamics + cast + project + fill, one workgroup per agent.
+// actions == nullptr: render only (used after reset / set_state); mask == nullptr: all.
+hipError_t rcw_launch_step(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
+                           hipStream_t s);
+hipError_t rcw_launch_validate(const RcwDev& p, const uint8_t* actions_dev, hipStream_t s);
+hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
+hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const float2* pos,
+                                const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);
+hipError_t rcw_launch_init_tile_map(const RcwDev& p, hipStream_t s);
+hipError_t rcw_launch_rays(const RcwDev& p, int32_t first, int32_t count, RcwRayOut out,
+                           hipStream_t s);
+hipError_t rcw_launch_expand(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c,
+                             int32_t count, uint32_t* frames, hipStream_t s);

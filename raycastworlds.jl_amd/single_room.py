@@ -1,0 +1,432 @@
+"""Host-side mirror of RayCastWorlds.jl's SingleRoomModule for a BATCH of agents.
+
+The reference is Julia (src/single_room.jl, "SR" below); no Julia toolchain exists in this
+pipeline, so this Python layer plays the role of the Julia host code above the C ABI
+(include/rcw.h) with the reference's names and argument meanings:
+
+    reference (Julia)                       here (Python)
+    SingleRoom(; kwargs...)      SR:258     SingleRoom(batch, **same kwargs)
+    RCW.reset!(env)              SR:326     reset_(env)
+    RCW.act!(env, action)        SR:333     act_(env, actions)        # one action per agent
+    RCW.get_action_names(env)    SR:486     get_action_names(env)
+    RCW.RLBaseEnv(env)           rlbase.jl  RLBaseEnv(env)            # see rlbase.py
+    env.world.reward / .done ... SR:21-40   env.world.reward / .done ...
+
+All compute happens in librcw_hip.so on the GPU; nothing here falls back to the CPU.
+Arrays come back batch-first in numpy C order, which is byte-identical to the Julia
+column-major layout with a trailing batch axis: camera_view (B, N, H_cam) == Julia
+UInt32 (H_cam, N, B).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+
+NUM_OBJECTS = 2   # SR:16
+WALL = 1          # SR:17
+GOAL = 2          # SR:18
+NUM_ACTIONS = 4   # SR:19
+
+NUM_VIEWS = 2     # SR:237
+CAMERA_VIEW = 1   # SR:238
+TOP_VIEW = 2      # SR:239
+
+
+class DeviceArray:
+    """A typed view of library-owned device memory (no copy).
+
+    Exposes `__cuda_array_interface__` (v3), so `torch.as_tensor(x, device="cuda")` and
+    friends alias it exactly as `RLBase.state(env)` aliases `camera_view` (SR:576).
+    """
+
+    def __init__(self, ptr: int, shape: Sequence[int], dtype, owner, sync):
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._owner = owner   # keeps the handle alive
+        self._sync = sync
+
+    @property
+    def nbytes(self) -> int:
+        return int(np.prod(self.shape)) * self.dtype.itemsize
+
+    @property
+    def __cuda_array_interface__(self):
+        self._sync()
+        return {
+            "shape": self.shape,
+            "typestr": self.dtype.str,
+            "data": (self.ptr, False),
+            "version": 3,
+            "strides": None,
+        }
+
+    def torch(self):
+        """Zero-copy torch tensor on the handle's device (int32 view for uint32 data)."""
+        import torch
+
+        t = torch.as_tensor(self, device=f"cuda:{self._owner.device}")
+        return t
+
+    def numpy(self) -> np.ndarray:
+        """Copy to host."""
+        return self._owner._copy_device_array(self)
+
+    def __repr__(self):
+        return f"DeviceArray(ptr=0x{self.ptr:x}, shape={self.shape}, dtype={self.dtype})"
+
+
+def _as_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SingleRoomWorld:
+    """Accessors for the batched `SingleRoomWorld` state (SR:21-40). Each property copies
+    the current device state to host."""
+
+    def __init__(self, env: "SingleRoom"):
+        self._env = env
+
+    def _get(self, fn, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        _capi.check(fn(self._env._h, _as_ptr(out)))
+        return out
+
+    @property
+    def num_directions(self) -> int:
+        return self._env.cfg.num_directions
+
+    @property
+    def num_rays(self) -> int:
+        return self._env.cfg.num_rays
+
+    @property
+    def player_radius_wu(self) -> float:
+        return self._env.cfg.player_radius_wu
+
+    @property
+    def position_increment_wu(self) -> float:
+        return self._env.cfg.position_increment_wu
+
+    @property
+    def semi_field_of_view_wu(self) -> float:
+        return self._env.cfg.semi_field_of_view_wu
+
+    @property
+    def goal_reward(self) -> np.float32:
+        return np.float32(self._env.cfg.goal_reward)
+
+    @property
+    def reward(self) -> np.ndarray:                    # SR:33
+        return self._get(self._env._lib.rcw_reward, np.float32, (self._env.batch,))
+
+    @property
+    def done(self) -> np.ndarray:                      # SR:35
+        return self._get(self._env._lib.rcw_done, np.uint8, (self._env.batch,)).astype(bool)
+
+    @property
+    def player_position_wu(self) -> np.ndarray:        # SR:24, (B, 2)
+        return self._get(self._env._lib.rcw_position, np.float32, (self._env.batch, 2))
+
+    @property
+    def player_direction_au(self) -> np.ndarray:       # SR:25
+        return self._get(self._env._lib.rcw_direction, np.int32, (self._env.batch,))
+
+    @property
+    def goal_position(self) -> np.ndarray:             # SR:32, (B, 2) 1-based (i, j)
+        return self._get(self._env._lib.rcw_goal, np.int32, (self._env.batch, 2))
+
+    @property
+    def episode(self) -> np.ndarray:
+        return self._get(self._env._lib.rcw_episode, np.uint32, (self._env.batch,))
+
+    @property
+    def directions_wu(self) -> np.ndarray:             # SR:28, (nd, 2)
+        out = np.empty((self.num_directions, 2), dtype=np.float32)
+        _capi.check(self._env._lib.rcw_direction_table(self._env._h, _as_ptr(out)))
+        return out
+
+    @property
+    def tile_map_chunks(self) -> np.ndarray:
+        """BitArray{3}(2, H, W).chunks per agent: uint64 (B, nchunks)  SR:22."""
+        n = C.c_int32()
+        _capi.check(self._env._lib.rcw_tile_map_num_chunks(self._env._h, C.byref(n)))
+        return self._get(self._env._lib.rcw_tile_map_chunks, np.uint64, (self._env.batch, n.value))
+
+    @property
+    def tile_map(self) -> np.ndarray:
+        """bool (B, 2, H, W): tile_map[b, o-1, i-1, j-1] == Julia tile_map[o, i, j] of agent b."""
+        env = self._env
+        H, W = env.cfg.height_tile_map_tu, env.cfg.width_tile_map_tu
+        chunks = self.tile_map_chunks
+        bits = np.unpackbits(chunks.view(np.uint8), axis=1, bitorder="little")[:, : 2 * H * W]
+        # linear bit index = (o-1) + 2(i-1) + 2H(j-1)  ->  C-order axes (j, i, o)
+        return bits.reshape(env.batch, W, H, 2).transpose(0, 3, 2, 1).astype(bool)
+
+    def rays(self, first: int = 0, count: Optional[int] = None):
+        """(ray_stop_position_tu (n, N, 2) int64, ray_hit_dimension (n, N) int64,
+        ray_distance_wu (n, N) float32, ray_directions_wu (n, N, 2) float32)  SR:29-31,39."""
+        env = self._env
+        n = env.batch - first if count is None else count
+        N = env.cfg.num_rays
+        stop = np.empty((n, N, 2), dtype=np.int64)
+        dim = np.empty((n, N), dtype=np.int64)
+        dist = np.empty((n, N), dtype=np.float32)
+        dirs = np.empty((n, N, 2), dtype=np.float32)
+        _capi.check(env._lib.rcw_rays(env._h, first, n, _as_ptr(stop), _as_ptr(dim), _as_ptr(dist), _as_ptr(dirs)))
+        return stop, dim, dist, dirs
+
+
+class SingleRoom:
+    """`SingleRoom(; kwargs...)` (SR:258-324) for `batch` independent agents on one MI355X.
+
+    Keyword arguments and defaults are the reference's (SR:258-272). `T`/`R` other than
+    Float32 and a caller-supplied Julia `rng` are not supported; `seed`
+    keys the device generator instead. `device` is the HIP device index.
+    """
+
+    def __init__(
+        self,
+        batch: int = 1,
+        *,
+        T="Float32",
+        height_tile_map_tu: int = 8,
+        width_tile_map_tu: int = 16,
+        num_directions: int = 128,
+        player_radius_wu: float = 1 / 8,
+        position_increment_wu: float = 1 / 8,
+        seed: int = 0,
+        R="Float32",
+        semi_field_of_view_wu: float = 2 / 3,
+        num_rays: int = 512,
+        pu_per_tu: int = 32,
+        camera_height_tile_wu: float = 1.0,
+        height_camera_view_pu: int = 256,
+        device: int = 0,
+        auto_reset: bool = False,
+        agent_id_offset: int = 0,
+        write_columns: bool = True,
+        dda_tie_break: int = 0,
+        dda_distance: int = 0,
+        normalize_mode: int = 0,
+    ):
+        if str(T) not in ("Float32", "float32", "<class 'numpy.float32'>") or str(R) not in (
+            "Float32", "float32", "<class 'numpy.float32'>"):
+            raise NotImplementedError("only T = R = Float32 is built (SURVEY.md §8f row 2)")
+        self._lib = _capi.load()
+        cfg = _capi.default_config()
+        cfg.height_tile_map_tu = height_tile_map_tu
+        cfg.width_tile_map_tu = width_tile_map_tu
+        cfg.num_directions = num_directions
+        cfg.player_radius_wu = np.float32(player_radius_wu)          # convert(T, .) SR:263
+        cfg.position_increment_wu = np.float32(position_increment_wu)
+        cfg.semi_field_of_view_wu = np.float32(semi_field_of_view_wu)
+        cfg.num_rays = num_rays
+        cfg.pu_per_tu = pu_per_tu
+        cfg.camera_height_tile_wu = np.float32(camera_height_tile_wu)
+        cfg.height_camera_view_pu = height_camera_view_pu
+        cfg.auto_reset = 1 if auto_reset else 0
+        cfg.agent_id_offset = agent_id_offset
+        cfg.write_columns = 1 if write_columns else 0
+        cfg.dda_tie_break = dda_tie_break
+        cfg.dda_distance = dda_distance
+        cfg.normalize_mode = normalize_mode
+        self.cfg = cfg
+        self.batch = int(batch)
+        self.device = int(device)
+        self.seed = int(seed)
+        self._h = C.c_void_p()
+        _capi.check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
+        self.world = SingleRoomWorld(self)
+        # colour fields of the reference struct SR:241-256
+        self.floor_color = cfg.floor_color
+        self.ceiling_color = cfg.ceiling_color
+        self.wall_dim_1_color = cfg.wall_dim_1_color
+        self.wall_dim_2_color = cfg.wall_dim_2_color
+        self.goal_dim_1_color = cfg.goal_dim_1_color
+        self.goal_dim_2_color = cfg.goal_dim_2_color
+        self.camera_height_tile_wu = cfg.camera_height_tile_wu
+        self.height_camera_view_pu = cfg.height_camera_view_pu
+
+    # ---- lifetime -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rcw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- device views ---------------------------------------------------------------
+    def _sync(self):
+        _capi.check(self._lib.rcw_sync(self._h))
+
+    def sync(self):
+        self._sync()
+
+    def _copy_device_array(self, arr: DeviceArray) -> np.ndarray:
+        if arr.ptr == self._obs_ptr():
+            out = np.empty(arr.shape, dtype=arr.dtype)
+            _capi.check(self._lib.rcw_obs_copy(self._h, _as_ptr(out), 0, self.batch))
+            return out
+        import torch
+
+        return torch.as_tensor(arr, device=f"cuda:{self.device}").cpu().numpy()
+
+    def _obs_ptr(self) -> int:
+        p = C.c_void_p()
+        _capi.check(self._lib.rcw_obs_device_ptr(self._h, C.byref(p)))
+        return int(p.value)
+
+    @property
+    def camera_view(self) -> DeviceArray:
+        """The observation batch, aliased (SR:300, SR:576): uint32 (B, N, H_cam) in C order."""
+        return DeviceArray(self._obs_ptr(), (self.batch, self.cfg.num_rays, self.cfg.height_camera_view_pu),
+                           np.uint32, self, self._sync)
+
+    def camera_view_host(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        n = self.batch - first if count is None else count
+        out = np.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=np.uint32)
+        _capi.check(self._lib.rcw_obs_copy(self._h, _as_ptr(out), first, n))
+        return out
+
+    def columns(self, first: int = 0, count: Optional[int] = None):
+        """Compact per-column descriptors (height_line_pu int32 (n, N), colour id uint8 (n, N))."""
+        n = self.batch - first if count is None else count
+        h = np.empty((n, self.cfg.num_rays), dtype=np.int32)
+        c = np.empty((n, self.cfg.num_rays), dtype=np.uint8)
+        _capi.check(self._lib.rcw_columns(self._h, first, n, _as_ptr(h), _as_ptr(c)))
+        return h, c
+
+    def columns_device(self):
+        hp, cp = C.c_void_p(), C.c_void_p()
+        _capi.check(self._lib.rcw_columns_device_ptr(self._h, C.byref(hp), C.byref(cp)))
+        shape = (self.batch, self.cfg.num_rays)
+        return (DeviceArray(hp.value, shape, np.int32, self, self._sync),
+                DeviceArray(cp.value, shape, np.uint8, self, self._sync))
+
+    def reward_device(self) -> DeviceArray:
+        p = C.c_void_p()
+        _capi.check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
+        return DeviceArray(p.value, (self.batch,), np.float32, self, self._sync)
+
+    def done_device(self) -> DeviceArray:
+        p = C.c_void_p()
+        _capi.check(self._lib.rcw_done_device_ptr(self._h, C.byref(p)))
+        return DeviceArray(p.value, (self.batch,), np.uint8, self, self._sync)
+
+    def ray_table(self) -> np.ndarray:
+        """(nd, 5, N) float32: per heading [dx | dy | |1/dx| | |1/dy| | dir·ray]."""
+        out = np.empty((self.cfg.num_directions, 5, self.cfg.num_rays), dtype=np.float32)
+        _capi.check(self._lib.rcw_ray_table(self._h, _as_ptr(out)))
+        return out
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _capi.check(self._lib.rcw_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    # ---- state injection (how "identical seeds" is realised) ---------
+    def set_state(self, goal_position, player_position_wu, player_direction_au, mask=None):
+        g = np.ascontiguousarray(goal_position, dtype=np.int32).reshape(self.batch, 2)
+        p = np.ascontiguousarray(player_position_wu, dtype=np.float32).reshape(self.batch, 2)
+        d = np.ascontiguousarray(player_direction_au, dtype=np.int32).reshape(self.batch)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.batch)
+        _capi.check(self._lib.rcw_set_state(self._h, _as_ptr(g), _as_ptr(p), _as_ptr(d), _as_ptr(m)))
+
+    def set_direction_table(self, directions_wu):
+        d = np.ascontiguousarray(directions_wu, dtype=np.float32).reshape(self.cfg.num_directions, 2)
+        _capi.check(self._lib.rcw_set_direction_table(self._h, _as_ptr(d)))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        _capi.check(self._lib.rcw_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def bind_obs(self, device_ptr: Optional[int]):
+        _capi.check(self._lib.rcw_bind_obs(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def clear_error(self):
+        _capi.check(self._lib.rcw_clear_error(self._h))
+
+    def timer_start(self):
+        _capi.check(self._lib.rcw_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _capi.check(self._lib.rcw_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+# ---- the generic functions of RayCastWorlds.jl:7-14 that are on the path ------------------
+def reset_(env: SingleRoom, mask=None, seed: Optional[int] = None) -> None:
+    """`RCW.reset!(env)` SR:326-331 — all agents, or those with a non-zero `mask` byte."""
+    if seed is not None:
+        env.seed = int(seed)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(env.batch)
+    _capi.check(env._lib.rcw_reset(env._h, _as_ptr(m), env.seed))
+    return None
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "is_cuda") and hasattr(x, "data_ptr")
+
+
+def act_(env: SingleRoom, action) -> None:
+    """`RCW.act!(env, action)` SR:333-340 (without the top view) for every agent.
+
+    `action`: one int in 1..4 applied to all agents, a length-B sequence / numpy array, or
+    a CUDA uint8 torch tensor of length B (stays on the device).  Anything outside 1..4
+    raises AssertionError and steps no agent (`@assert` SR:140).
+    """
+    if _is_device_tensor(action):
+        if not action.is_cuda:
+            action = action.numpy()
+        else:
+            import torch
+
+            if action.dtype != torch.uint8 or action.numel() != env.batch or not action.is_contiguous():
+                raise ValueError("device actions must be a contiguous uint8 tensor of length batch")
+            _capi.check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
+            return None
+    if np.isscalar(action):
+        a = np.full(env.batch, action)
+    else:
+        a = np.asarray(action).reshape(-1)
+        if a.size != env.batch:
+            raise ValueError(f"expected {env.batch} actions, got {a.size}")
+    if a.dtype != np.uint8:
+        if not np.all((a >= 1) & (a <= NUM_ACTIONS)) or not np.all(a == np.floor(a)):
+            bad = a[~((a >= 1) & (a <= NUM_ACTIONS))]
+            raise AssertionError(f"Invalid action: {bad[0] if bad.size else a[0]}")
+        a = a.astype(np.uint8)
+    a = np.ascontiguousarray(a)
+    _capi.check(env._lib.rcw_step(env._h, _as_ptr(a)))
+    return None
+
+
+def cast_rays_(env: SingleRoom, first: int = 0, count: Optional[int] = None):
+    """`RCW.cast_rays!(world)` SR:195-231: returns the ray buffers for agents [first, first+count)."""
+    return env.world.rays(first, count)
+
+
+def update_camera_view_(env: SingleRoom) -> None:
+    """`RCW.update_camera_view!(env)` SR:374-444.  The engine renders as part of every
+    reset/act/set_state, so the view is always current; this only waits for the GPU."""
+    env.sync()
+
+
+def get_action_names(env: SingleRoom):
+    """`RCW.get_action_names(env)` SR:486."""
+    return ("MOVE_FORWARD", "MOVE_BACKWARD", "TURN_LEFT", "TURN_RIGHT")

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def rcw():
+    """The product package (host mirror + ctypes binding of librcw_hip.so)."""
+    import raycastworlds_jl_amd as RCW
+
+    return RCW
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle — test infrastructure only."""
+    from oracle import oracle as O
+
+    O.build()
+    return O

@@ -1,0 +1,163 @@
+"""GPU parity: librcw_hip (through the C ABI) vs the CPU oracle on identical inputs.
+
+Bit-exact for every integer output (tile_map, camera_view, ray stop tiles, hit dimension,
+height_line_pu, colour id, direction, done); player_position_wu within 1e-6 as
+BASELINE.json's north_star states (and in fact bit-exact).
+"""
+import numpy as np
+import pytest
+
+from helpers import CFG1, CFG2, CFG3, CFG4, CFG5, REFERENCE_DEFAULT, assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(rcw, oracle, batch, seed=0, **kw):
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=seed, **kw)
+    okw = {k: v for k, v in kw.items() if k not in ("auto_reset",)}
+    if kw.get("auto_reset"):
+        okw["auto_reset"] = 1
+    orc = oracle.OracleBatch(batch, seed=seed, **okw)
+    return env, orc
+
+
+def _rollout(rcw, env, orc, steps, rng, check_every=1, rays_every=0, frames=True):
+    for s in range(steps):
+        a = rng.integers(1, 5, env.batch).astype(np.uint8)
+        rcw.act_(env, a)
+        assert orc.step(a) == 0
+        if (s + 1) % check_every == 0 or s == steps - 1:
+            assert_state_equal(env, orc, frames=frames, rays=bool(rays_every) and (s % rays_every == 0),
+                               where=f"step {s}")
+
+
+@pytest.mark.parametrize("cfg,batch,steps", [
+    (CFG1, 1, 300),              # configs[0]: the reference's own CPU-runnable case
+    (CFG2, 64, 120),
+    (REFERENCE_DEFAULT, 32, 120),   # 8 x 16, 512 rays (test/runtests.jl:19)
+    (CFG3, 16, 80),
+    (CFG4, 32, 80),
+    (CFG5, 8, 80),               # deep DDA march
+])
+def test_reset_and_rollout_match_oracle(rcw, oracle, cfg, batch, steps):
+    env, orc = _make(rcw, oracle, batch, seed=1234, **cfg)
+    assert_state_equal(env, orc, rays=True, where="after create/reset")
+    rng = np.random.default_rng(7)
+    _rollout(rcw, env, orc, steps, rng, check_every=1 if batch <= 8 else 10, rays_every=20)
+    # masked reset with a new seed
+    mask = (rng.random(batch) < 0.5).astype(np.uint8)
+    mask[0] = 1
+    rcw.reset_(env, mask=mask, seed=99)
+    orc.reset(mask=mask, seed=99)
+    assert_state_equal(env, orc, rays=True, where="after masked reset")
+    _rollout(rcw, env, orc, 20, rng, check_every=5)
+    env.close()
+
+
+def test_set_state_all_headings(rcw, oracle):
+    """Every heading from a fixed off-centre pose: exercises the whole ray table."""
+    nd = 128
+    env, orc = _make(rcw, oracle, nd, **CFG1)
+    goal = np.tile(np.array([[3, 6]], dtype=np.int32), (nd, 1))
+    pos = np.tile(np.array([[4.3125, 2.71875]], dtype=np.float32), (nd, 1))
+    d = np.arange(nd, dtype=np.int32)
+    env.set_state(goal, pos, d)
+    orc.set_state(goal, pos, d)
+    assert_state_equal(env, orc, rays=True, where="all headings")
+    env.close()
+
+
+def test_unpinned_switches_match_oracle(rcw, oracle):
+    """The three UNPINNED choices (include/rcw.h) are switchable and stay in parity."""
+    rng = np.random.default_rng(3)
+    for tie in (0, 1):
+        for dist in (0, 1):
+            for norm in (0, 1):
+                env, orc = _make(rcw, oracle, 16, seed=5, dda_tie_break=tie, dda_distance=dist,
+                                 normalize_mode=norm, **CFG1)
+                _rollout(rcw, env, orc, 40, rng, check_every=10, rays_every=10)
+                env.close()
+
+
+def test_auto_reset_matches_oracle(rcw, oracle):
+    env, orc = _make(rcw, oracle, 256, seed=11, auto_reset=True, **CFG1)
+    rng = np.random.default_rng(5)
+    episodes_before = env.world.episode.copy()
+    _rollout(rcw, env, orc, 400, rng, check_every=50, frames=False)
+    np.testing.assert_array_equal(env.world.episode, orc.episode)
+    assert (env.world.episode > episodes_before).any(), "no agent finished an episode in 400 random steps"
+    env.close()
+
+
+def test_invalid_action_mutates_nothing(rcw, oracle):
+    env, orc = _make(rcw, oracle, 8, seed=2, **CFG1)
+    before = env.camera_view_host().copy()
+    a = np.array([1, 2, 3, 4, 1, 5, 1, 1], dtype=np.uint8)
+    with pytest.raises(AssertionError):
+        rcw.act_(env, a)
+    assert orc.step(a) == -2
+    with pytest.raises(AssertionError):
+        rcw.act_(env, 0)
+    assert_state_equal(env, orc, where="after rejected actions")
+    np.testing.assert_array_equal(env.camera_view_host(), before)
+    env.close()
+
+
+def test_device_actions_and_validation(rcw, oracle):
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 32, seed=4, **CFG2)
+    rng = np.random.default_rng(9)
+    for s in range(30):
+        a = rng.integers(1, 5, env.batch).astype(np.uint8)
+        rcw.act_(env, torch.from_numpy(a).cuda())
+        orc.step(a)
+    assert_state_equal(env, orc, where="device actions")
+    bad = torch.full((env.batch,), 1, dtype=torch.uint8, device="cuda")
+    bad[17] = 9
+    rcw.act_(env, bad)           # asynchronous: surfaces at the next sync / getter
+    with pytest.raises(AssertionError):
+        env.sync()
+    env.clear_error()
+    assert_state_equal(env, orc, where="after rejected device actions")
+    env.close()
+
+
+def test_state_aliases_device_buffer(rcw, oracle):
+    """RLBase.state(env) aliases camera_view (SR:576): same pointer, updated in place."""
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 4, seed=6, **CFG1)
+    rl = rcw.RLBaseEnv(env)
+    s0 = rcw.RLBase.state(rl)
+    t = s0.torch()
+    rl(3)
+    orc.step(np.full(4, 3, dtype=np.uint8))
+    s1 = rcw.RLBase.state(rl)
+    assert s0.ptr == s1.ptr
+    env.sync()
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), orc.camera_view)
+    env.close()
+
+
+def test_expand_columns_reproduces_frames(rcw, oracle):
+    """The compact descriptor + expansion (receiving side of the observation gather)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+
+    env, orc = _make(rcw, oracle, 16, seed=8, **CFG2)
+    h, c = env.columns_device()
+    out = torch.zeros((16, 256, 256), dtype=torch.int32, device="cuda")
+    from raycastworlds_jl_amd import _capi
+    _capi.check(env._lib.rcw_expand_columns(env._h, C.c_void_p(h.ptr), C.c_void_p(c.ptr), 16,
+                                            C.c_void_p(out.data_ptr())))
+    env.sync()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), orc.camera_view)
+    env.close()
+
+
+def test_odd_camera_heights(rcw, oracle):
+    """H_cam not 256 / not a multiple of 4 take the generic store paths."""
+    rng = np.random.default_rng(1)
+    for hc in (64, 250, 37):
+        env, orc = _make(rcw, oracle, 8, seed=3, height_camera_view_pu=hc, **CFG1)
+        _rollout(rcw, env, orc, 20, rng, check_every=5)
+        env.close()
