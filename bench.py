@@ -115,9 +115,21 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def sync_counting_bounds_errors():
+        # The reference raises BoundsError when a forward move lands exactly on x = H-1 or
+        # y = W-1 (include/rcw.h, RCW_OOB_ERROR).  The engine reports it and leaves that agent
+        # untouched for that action; the batch goes on.  Count the agents it happened to.
+        try:
+            env.sync()
+            return 0
+        except IndexError:
+            n = int((env.world.status != 0).sum())
+            env.clear_error()
+            return n
+
     for s in range(args.warmup):
         RCW.act_(env, actions[s])
-    env.sync()
+    sync_counting_bounds_errors()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -125,7 +137,7 @@ def main():
     for s in range(args.warmup, total):
         RCW.act_(env, actions[s])
     kernel_ms = env.timer_stop()   # HIP events on the stream the kernels run on
-    env.sync()
+    bounds_errors = sync_counting_bounds_errors()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -168,6 +180,7 @@ def main():
                 "agents_per_gpu": B,
                 "global_batch": world * B,
                 "auto_reset": not args.no_auto_reset,
+                "agents_that_hit_reference_BoundsError": bounds_errors,
                 "actions": "uniform 1..4 per agent per step, device resident",
                 "sharding": f"agents by rank x{world}, no data-path collective",
             },

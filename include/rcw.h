@@ -81,6 +81,21 @@ extern "C" {
 #define RCW_NORMALIZE_INV_NORM_TIMES 0  /* inv(norm(v)) * v  (StaticArrays 1.2, default)    */
 #define RCW_NORMALIZE_DIVIDE         1  /* v / norm(v)                                      */
 
+/* What a move does when is_player_colliding (collision_detection.jl:30-35) would index a
+ * tile off the map.  The reference raises BoundsError there — and this is reachable at the
+ * defaults: walking along +x (heading 0) or +y (heading nd/4) in exact 1/8 steps reaches
+ * x = H - 1 - 1/8, which does not collide (strict `<`, CD:18); the next forward move tests
+ * x = H - 1, whose tile is H, and reads tile H + 1.
+ *   RCW_OOB_ERROR        the faulting agent is left exactly as it was (as the Julia world is
+ *                        after the exception), its status word and the handle's error word
+ *                        are set to RCW_ERR_OUT_OF_BOUNDS (reported by the next
+ *                        rcw_sync/getter, cleared by rcw_clear_error); other agents and
+ *                        later steps are not affected.
+ *   RCW_OOB_TREAT_EMPTY  tiles off the map count as empty; no error (the move above is then
+ *                        simply blocked by the wall tile). */
+#define RCW_OOB_ERROR       0
+#define RCW_OOB_TREAT_EMPTY 1
+
 /* Mirrors the keyword arguments of SingleRoom(; ...) SR:258-272 and the colour
  * constants SR:288-296.  Fill with rcw_config_default() and then override. */
 typedef struct rcw_config {
@@ -111,9 +126,12 @@ typedef struct rcw_config {
     int64_t  agent_id_offset;         /* global id of local agent 0 (multi-GPU sharding);
                                          keys the reset RNG so results do not depend on
                                          how agents are sharded                            */
-    int32_t  write_columns;           /* 1: also keep the compact per-column descriptor
-                                         (height_line_pu, colour id) in device memory      */
-    int32_t  reserved[7];
+    int32_t  write_columns;           /* ignored since the step became cast + fill: the
+                                         compact per-column descriptor (height_line_pu,
+                                         colour id) is always kept in device memory        */
+    int32_t  out_of_bounds;           /* RCW_OOB_ERROR (default, reference behaviour) |
+                                         RCW_OOB_TREAT_EMPTY                               */
+    int32_t  reserved[6];
 } rcw_config;
 
 typedef struct rcw_handle rcw_handle;   /* opaque */
@@ -162,10 +180,13 @@ RCW_API int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* po
  * actions: UInt8 (B), values 1..4, in HOST memory.  Any value outside 1..4 returns
  * RCW_ERR_INVALID_ACTION and NO agent is mutated (@assert SR:140). */
 RCW_API int rcw_step(rcw_handle* h, const uint8_t* actions_host);
-/* Same with actions already in DEVICE memory (stream-ordered, no host round trip).
- * Validation runs on the device before the step; on an invalid action no agent is
- * mutated and the error is returned by the next rcw_sync()/getter (sticky until
- * rcw_clear_error). */
+/* Same with actions already in DEVICE memory (stream-ordered, no host round trip).  Each
+ * agent's action is checked on the device by the workgroup that steps it: an agent given a
+ * value outside 1..4 is NOT stepped (its state and frame stay as they were), its status
+ * word and the handle's error word are set to RCW_ERR_INVALID_ACTION, and the other agents
+ * step normally — what a loop `for (env, a) in zip(envs, actions) act!(env, a)` over
+ * reference worlds leaves behind, except that agents after the faulting one also run.
+ * The error is returned by the next rcw_sync()/getter and cleared by rcw_clear_error. */
 RCW_API int rcw_step_device(rcw_handle* h, const uint8_t* actions_device);
 
 RCW_API int rcw_sync(rcw_handle* h);
@@ -186,6 +207,10 @@ RCW_API int rcw_position(rcw_handle* h, float* out_host /* (2, B) */);
 RCW_API int rcw_direction(rcw_handle* h, int32_t* out_host /* (B) */);
 RCW_API int rcw_goal(rcw_handle* h, int32_t* out_host /* (2, B), 1-based */);
 RCW_API int rcw_episode(rcw_handle* h, uint32_t* out_host /* (B): resets seen by each agent */);
+/* Per-agent sticky status: 0, RCW_ERR_OUT_OF_BOUNDS (see RCW_OOB_ERROR) or
+ * RCW_ERR_INVALID_ACTION (rcw_step_device).  Does not fail on a set error word, so it can
+ * be used to find the faulting agents. */
+RCW_API int rcw_status(rcw_handle* h, int32_t* out_host /* (B) */);
 /* world.tile_map SR:22 as BitArray{3}(2, H, W).chunks per agent: UInt64 (nchunks, B),
  * nchunks = rcw_tile_map_num_chunks(). Bit (o-1) + 2(i-1) + 2H(j-1), LSB first. */
 RCW_API int rcw_tile_map_num_chunks(rcw_handle* h, int32_t* out);
@@ -199,7 +224,7 @@ RCW_API int rcw_rays(rcw_handle* h, int32_t first, int32_t count,
              float* distance_wu /* (N, count) */, float* directions_wu /* (2, N, count) */);
 /* Compact per-column descriptor of the current frames, indexed by image column k
  * (k = N - i + 1, SR:431): height_line_pu SR:408-411 (Int32, saturated) and colour id.
- * Needs cfg.write_columns = 1. */
+ */
 RCW_API int rcw_columns(rcw_handle* h, int32_t first, int32_t count,
                 int32_t* height_line_pu /* (N, count) */, uint8_t* colour_id /* (N, count) */);
 RCW_API int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** colour_id);

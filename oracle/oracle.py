@@ -45,7 +45,8 @@ class RcwConfig(C.Structure):
         ("auto_reset", C.c_int32),
         ("agent_id_offset", C.c_int64),
         ("write_columns", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("out_of_bounds", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -110,6 +111,9 @@ def lib() -> C.CDLL:
         L.orc_set_state.argtypes = [vp, vp, vp, vp, vp]
         L.orc_set_direction_table.argtypes = [vp, vp]
         L.orc_step.argtypes = [vp, vp]
+        L.orc_step_lenient.argtypes = [vp, vp]
+        L.orc_clear_status.argtypes = [vp]
+        L.orc_clear_status.restype = None
         L.orc_tile_map_chunks.argtypes = [vp, vp]
         L.orc_tile_map_chunks.restype = None
         L.orc_num_chunks.argtypes = [vp]
@@ -121,7 +125,7 @@ def lib() -> C.CDLL:
         L.orc_cast_ray.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.orc_is_player_colliding.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                              C.c_float]
+                                              C.c_float, C.c_int32]
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
         for name in ("camera_view", "reward", "done", "position", "direction", "goal", "episode",
@@ -198,6 +202,14 @@ class OracleBatch:
     def step(self, actions) -> int:
         a = np.ascontiguousarray(actions, dtype=np.uint8).reshape(self.B)
         return lib().orc_step(self._h, _p(a))
+
+    def step_lenient(self, actions) -> int:
+        """rcw_step_device semantics: agents with an invalid action are skipped, not rejected."""
+        a = np.ascontiguousarray(actions, dtype=np.uint8).reshape(self.B)
+        return lib().orc_step_lenient(self._h, _p(a))
+
+    def clear_status(self):
+        lib().orc_clear_status(self._h)
 
     # --- state ---------------------------------------------------------------------
     def _g(self, name, dtype, shape):
@@ -301,10 +313,11 @@ def cast_ray(obstacle_map, x, y, dx, dy, tie_break=0, dist_mode=0):
     return i.value, j.value, dim.value, np.float32(dist.value)
 
 
-def is_player_colliding(layer, px, py, radius) -> bool:
+def is_player_colliding(layer, px, py, radius, oob_empty=False) -> bool:
     lm = np.asfortranarray(np.asarray(layer, dtype=np.uint8))
     H, W = lm.shape
-    rc = lib().orc_is_player_colliding(lm.ctypes.data_as(C.c_void_p), H, W, px, py, radius)
+    rc = lib().orc_is_player_colliding(lm.ctypes.data_as(C.c_void_p), H, W, px, py, radius,
+                                       1 if oob_empty else 0)
     if rc < 0:
         raise IndexError("BoundsError")
     return bool(rc)

@@ -154,7 +154,7 @@ ORC_EXPORT int orc_cast_ray(const uint8_t* obst, int32_t H, int32_t W, float x, 
  * Returns 0/1, or RCW_ERR_OUT_OF_BOUNDS for Julia's BoundsError at CD:35.
  * ---------------------------------------------------------------------------------- */
 ORC_EXPORT int orc_is_player_colliding(const uint8_t* layer, int32_t H, int32_t W,
-                                       float px, float py, float radius)
+                                       float px, float py, float radius, int32_t oob_empty)
 {
     const float half = 0.5f;                           /* StdSquare(0.5) CD:24 */
     const int64_t it = (int64_t)floorf(px) + 1;        /* wu_to_tu CD:27-28, UT:5 */
@@ -163,7 +163,10 @@ ORC_EXPORT int orc_is_player_colliding(const uint8_t* layer, int32_t H, int32_t 
         for (int64_t i = it - 1; i <= it + 1; ++i) {   /* CD:31 */
             const float cx = (float)i - half;          /* CD:33-34 */
             const float cy = (float)j - half;
-            if (i < 1 || i > H || j < 1 || j > W) return RCW_ERR_OUT_OF_BOUNDS;
+            if (i < 1 || i > H || j < 1 || j > W) {
+                if (oob_empty) continue;   /* RCW_OOB_TREAT_EMPTY (not the reference) */
+                return RCW_ERR_OUT_OF_BOUNDS;
+            }
             if (layer[(i - 1) + (int64_t)H * (j - 1)]) {   /* && short-circuit CD:35 */
                 const float qx = px - cx, qy = py - cy;    /* position .- tile CD:35 */
                 /* get_projection: clamp.(q, -h, h) CD:9-12 */
@@ -459,9 +462,11 @@ static void orc_act_agent(orc_batch* b, int32_t a, int action)
         if (action == 1) { nx = b->pos[2 * a] + inc * d1; ny = b->pos[2 * a + 1] + inc * d2; } /* UT:16 */
         else             { nx = b->pos[2 * a] - inc * d1; ny = b->pos[2 * a + 1] - inc * d2; } /* UT:17 */
         const int g = orc_is_player_colliding(b->goalmap + HW * a, H, W, nx, ny,
-                                              b->cfg.player_radius_wu);          /* SR:162 */
+                                              b->cfg.player_radius_wu,
+                                              b->cfg.out_of_bounds == RCW_OOB_TREAT_EMPTY);   /* SR:162 */
         const int w = orc_is_player_colliding(b->wall + HW * a, H, W, nx, ny,
-                                              b->cfg.player_radius_wu);          /* SR:163 */
+                                              b->cfg.player_radius_wu,
+                                              b->cfg.out_of_bounds == RCW_OOB_TREAT_EMPTY);   /* SR:163 */
         if (g < 0 || w < 0) {   /* Julia: BoundsError before any mutation */
             b->status[a] = RCW_ERR_OUT_OF_BOUNDS;
             return;
@@ -498,6 +503,26 @@ ORC_EXPORT int orc_step(orc_batch* b, const uint8_t* actions)
     }
     return RCW_OK;
 }
+
+/* rcw_step_device semantics: an agent given an action outside 1..4 is not stepped (status
+ * RCW_ERR_INVALID_ACTION), the others step. */
+ORC_EXPORT int orc_step_lenient(orc_batch* b, const uint8_t* actions)
+{
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < b->B; ++a) {
+        if (actions[a] < 1 || actions[a] > RCW_NUM_ACTIONS) {
+            b->status[a] = RCW_ERR_INVALID_ACTION;
+            orc_render_agent(b, a);
+            continue;
+        }
+        if (b->cfg.auto_reset && b->done[a]) { orc_reset_agent(b, a, b->seed); continue; }
+        orc_act_agent(b, a, actions[a]);
+        orc_render_agent(b, a);
+    }
+    return RCW_OK;
+}
+
+ORC_EXPORT void orc_clear_status(orc_batch* b) { memset(b->status, 0, sizeof(int32_t) * (size_t)b->B); }
 
 /* ---- getters ----------------------------------------------------------------------- */
 ORC_EXPORT const uint32_t* orc_camera_view(orc_batch* b) { return b->camera_view; }

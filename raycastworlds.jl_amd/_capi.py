@@ -50,7 +50,8 @@ class RcwConfig(C.Structure):
         ("auto_reset", C.c_int32),
         ("agent_id_offset", C.c_int64),
         ("write_columns", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("out_of_bounds", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "rcw_direction": [_vp, _vp],
     "rcw_goal": [_vp, _vp],
     "rcw_episode": [_vp, _vp],
+    "rcw_status": [_vp, _vp],
     "rcw_tile_map_num_chunks": [_vp, C.POINTER(_i32)],
     "rcw_tile_map_chunks": [_vp, _vp],
     "rcw_rays": [_vp, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -110,6 +112,30 @@ _RESTYPE = {"rcw_last_error": C.c_char_p}
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch's ROCm wheel bundles its own libamdhip64.so
+    (soname libamdhip64.so.7, same as /opt/rocm's).  If librcw_hip pulled in the system copy
+    first, a later `import torch` would load a second runtime that finds no GPU.  Loading
+    torch's copy first (without importing torch) makes both resolve to the same one."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load librcw_hip.so; loud failure when it has not been built."""
     global _lib
@@ -120,6 +146,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
             f"(or `make -C raycastworlds.jl_amd/csrc`). There is no CPU fallback."
         )
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -47,7 +48,7 @@ struct rcw_handle {
     void* d_pos = nullptr; void* d_dir = nullptr; void* d_goal = nullptr; void* d_reward = nullptr;
     void* d_done = nullptr; void* d_episode = nullptr; void* d_tile_map = nullptr;
     void* d_dir_table = nullptr; void* d_ray_table = nullptr; void* d_obs = nullptr;
-    void* d_col_h = nullptr; void* d_col_c = nullptr; void* d_err = nullptr;
+    void* d_col_h = nullptr; void* d_col_c = nullptr; void* d_err = nullptr; void* d_status = nullptr;
     void* d_actions = nullptr; void* d_mask = nullptr;
     void* d_in_goal = nullptr; void* d_in_pos = nullptr; void* d_in_dir = nullptr;
     int32_t* h_err = nullptr;   // pinned
@@ -64,7 +65,7 @@ void free_all(rcw_handle* h)
 {
     void** ptrs[] = {&h->d_pos, &h->d_dir, &h->d_goal, &h->d_reward, &h->d_done, &h->d_episode,
                      &h->d_tile_map, &h->d_dir_table, &h->d_ray_table, &h->d_obs, &h->d_col_h,
-                     &h->d_col_c, &h->d_err, &h->d_actions, &h->d_mask, &h->d_in_goal,
+                     &h->d_col_c, &h->d_err, &h->d_status, &h->d_actions, &h->d_mask, &h->d_in_goal,
                      &h->d_in_pos, &h->d_in_dir};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -161,7 +162,6 @@ int validate_config(const rcw_config* c, int32_t batch)
         return fail(RCW_ERR_UNSUPPORTED, "tile map larger than 65536 tiles does not fit the LDS staging");
     if (c->num_directions < 1 || c->num_rays < 1 || c->height_camera_view_pu < 1)
         return fail(RCW_ERR_INVALID_ARGUMENT, "num_directions, num_rays, height_camera_view_pu must be >= 1");
-    if (c->num_rays > 8192) return fail(RCW_ERR_UNSUPPORTED, "num_rays > 8192 does not fit the LDS column buffer");
     if (c->num_rays > (1 << 24)) return fail(RCW_ERR_INVALID_ARGUMENT, "num_rays not exactly representable in Float32");
     if (!(c->player_radius_wu > 0.0f && c->player_radius_wu < 0.5f))   // "should be less than 0.5" SR:47
         return fail(RCW_ERR_INVALID_ARGUMENT, "player_radius_wu must be in (0, 0.5)");
@@ -172,8 +172,8 @@ int validate_config(const rcw_config* c, int32_t batch)
     if (!(c->camera_height_tile_wu > 0.0f) || !std::isfinite(c->camera_height_tile_wu))
         return fail(RCW_ERR_INVALID_ARGUMENT, "camera_height_tile_wu must be positive and finite");
     if (c->dda_tie_break < 0 || c->dda_tie_break > 1 || c->dda_distance < 0 || c->dda_distance > 1 ||
-        c->normalize_mode < 0 || c->normalize_mode > 1)
-        return fail(RCW_ERR_INVALID_ARGUMENT, "dda_tie_break / dda_distance / normalize_mode out of range");
+        c->normalize_mode < 0 || c->normalize_mode > 1 || c->out_of_bounds < 0 || c->out_of_bounds > 1)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "dda_tie_break / dda_distance / normalize_mode / out_of_bounds out of range");
     return RCW_OK;
 }
 
@@ -182,8 +182,8 @@ int sync_and_check(rcw_handle* h)
 {
     RCW_HIP(hipMemcpyAsync(h->h_err, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     RCW_HIP(hipStreamSynchronize(h->stream));
-    const int32_t e = *h->h_err;
-    if (e == RCW_ERR_INVALID_ACTION) return fail(e, "invalid action (must be in 1..%d); no agent was stepped", RCW_NUM_ACTIONS);
+    const int32_t e = h->h_err[0];
+    if (e == RCW_ERR_INVALID_ACTION) return fail(e, "invalid action (must be in 1..%d); the agents it was given to were not stepped (rcw_status)", RCW_NUM_ACTIONS);
     if (e == RCW_ERR_OUT_OF_BOUNDS) return fail(e, "a tile index left the tile map (BoundsError in the reference)");
     if (e != 0) return fail(e, "device error %d", e);
     return RCW_OK;
@@ -251,6 +251,7 @@ int rcw_config_default(rcw_config* c)
     c->auto_reset = 0;
     c->agent_id_offset = 0;
     c->write_columns = 1;
+    c->out_of_bounds = RCW_OOB_ERROR;
     return RCW_OK;
 }
 
@@ -307,11 +308,10 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     RCW_TRY(hipMalloc(&h->d_dir_table, (size_t)nd * sizeof(float2)));
     RCW_TRY(hipMalloc(&h->d_ray_table, (size_t)nd * RCW_TABLE_ROWS * N * sizeof(float)));
     RCW_TRY(hipMalloc(&h->d_obs, B * (size_t)N * Hc * sizeof(uint32_t)));
-    if (cfg->write_columns) {
-        RCW_TRY(hipMalloc(&h->d_col_h, B * (size_t)N * sizeof(int32_t)));
-        RCW_TRY(hipMalloc(&h->d_col_c, B * (size_t)N));
-    }
+    RCW_TRY(hipMalloc(&h->d_col_h, B * (size_t)N * sizeof(int32_t)));
+    RCW_TRY(hipMalloc(&h->d_col_c, B * (size_t)N));
     RCW_TRY(hipMalloc(&h->d_err, sizeof(int32_t)));
+    RCW_TRY(hipMalloc(&h->d_status, B * sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_actions, B));
     RCW_TRY(hipMalloc(&h->d_mask, B));
     RCW_TRY(hipMalloc(&h->d_in_goal, B * sizeof(int2)));
@@ -323,6 +323,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
         RCW_TRY(hipEventCreateWithFlags(&h->ev_actions[k], hipEventDisableTiming));
     }
     RCW_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+    RCW_TRY(hipMemsetAsync(h->d_status, 0, B * sizeof(int32_t), h->stream));
 #undef RCW_TRY
 
     RcwDev& d = h->dev;
@@ -350,6 +351,12 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.dir_table = (const float2*)h->d_dir_table; d.ray_table = (const float*)h->d_ray_table;
     d.obs = (uint32_t*)h->d_obs; d.col_h = (int32_t*)h->d_col_h; d.col_c = (uint8_t*)h->d_col_c;
     d.err = (int32_t*)h->d_err;
+    d.status = (int32_t*)h->d_status;
+    d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;
+    d.fill_grid = 256; d.fill_plain = 0;
+    // tuning knobs for development runs only
+    if (const char* v = std::getenv("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
+    if (const char* v = std::getenv("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
 
     if (rcw_step_lds_bytes(d) > 64 * 1024) {
         free_all(h); delete h;
@@ -475,7 +482,6 @@ int rcw_step_device(rcw_handle* h, const uint8_t* actions_device)
 {
     int rc = check_handle(h); if (rc) return rc;
     if (!actions_device) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL actions");
-    RCW_HIP(rcw_launch_validate(h->dev, actions_device, h->stream));
     RCW_HIP(rcw_launch_step(h->dev, actions_device, nullptr, h->stream));
     return RCW_OK;
 }
@@ -490,6 +496,7 @@ int rcw_clear_error(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
     RCW_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+    RCW_HIP(hipMemsetAsync(h->d_status, 0, (size_t)h->B * sizeof(int32_t), h->stream));
     RCW_HIP(hipStreamSynchronize(h->stream));
     return RCW_OK;
 }
@@ -519,6 +526,15 @@ int rcw_position(rcw_handle* h, float* out) { int rc = check_handle(h); if (rc) 
 int rcw_direction(rcw_handle* h, int32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_dir, (size_t)h->B); }
 int rcw_goal(rcw_handle* h, int32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_goal, (size_t)2 * h->B); }
 int rcw_episode(rcw_handle* h, uint32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_episode, (size_t)h->B); }
+
+int rcw_status(rcw_handle* h, int32_t* out)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL output pointer");
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    RCW_HIP(hipMemcpy(out, h->d_status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RCW_OK;
+}
 
 int rcw_reward_device_ptr(rcw_handle* h, void** p)
 {
@@ -571,7 +587,6 @@ int rcw_rays(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int6
 int rcw_columns(rcw_handle* h, int32_t first, int32_t count, int32_t* height_line_pu, uint8_t* colour_id)
 {
     int rc = check_handle(h); if (rc) return rc;
-    if (!h->d_col_h) return fail(RCW_ERR_UNSUPPORTED, "handle was created with write_columns = 0");
     if (first < 0 || count < 0 || first + (int64_t)count > h->B)
         return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
     rc = sync_and_check(h);
@@ -586,7 +601,6 @@ int rcw_columns(rcw_handle* h, int32_t first, int32_t count, int32_t* height_lin
 int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** colour_id)
 {
     if (!h) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL handle");
-    if (!h->d_col_h) return fail(RCW_ERR_UNSUPPORTED, "handle was created with write_columns = 0");
     if (height_line_pu) *height_line_pu = h->d_col_h;
     if (colour_id) *colour_id = h->d_col_c;
     return RCW_OK;

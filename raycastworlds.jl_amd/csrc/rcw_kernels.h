@@ -23,6 +23,9 @@ struct RcwDev {
     int32_t tie_le;          // RCW_DDA_TIE_X_FIRST_ON_LE
     int32_t dist_pre;        // RCW_DDA_DIST_PRE_INCREMENT
     int32_t auto_reset;
+    int32_t oob_empty;       // RCW_OOB_TREAT_EMPTY
+    int32_t fill_grid;       // workgroups of the fill kernel (the moving window = fill_grid KiB x 4)
+    int32_t fill_plain;      // 1: plain stores, 0: non-temporal
     int64_t agent_id_offset;
     uint64_t seed;
     // state (SR:21-40), one entry per agent
@@ -38,9 +41,10 @@ struct RcwDev {
     const float* ray_table;  // [nd][RCW_TABLE_ROWS][N]
     // outputs
     uint32_t* obs;           // camera_view UInt32 (Hc, N, B)
-    int32_t* col_h;          // optional (N, B) height_line_pu by image column
-    uint8_t* col_c;          // optional (N, B) colour id by image column
-    int32_t* err;            // sticky error word (0 = ok)
+    int32_t* col_h;          // (N, B) height_line_pu by image column
+    uint8_t* col_c;          // (N, B) colour id by image column
+    int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
+    int32_t* status;         // per-agent sticky status
 };
 
 struct RcwRayOut {           // rcw_rays(): SR:29-31,39 for agents [first, first+count)
@@ -52,11 +56,10 @@ struct RcwRayOut {           // rcw_rays(): SR:29-31,39 for agents [first, first
 
 size_t rcw_step_lds_bytes(const RcwDev& p);
 
-// act!(env, a): dynamics + cast + project + fill, one workgroup per agent.
+// act!(env, a): cast kernel (dynamics + rays + projection) then fill kernel (pixels).
 // actions == nullptr: render only (used after reset / set_state); mask == nullptr: all.
 hipError_t rcw_launch_step(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s);
-hipError_t rcw_launch_validate(const RcwDev& p, const uint8_t* actions_dev, hipStream_t s);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const float2* pos,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);

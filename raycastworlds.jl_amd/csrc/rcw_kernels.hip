@@ -1,17 +1,18 @@
 // HIP kernels (gfx950 / CDNA4) for the batched SingleRoom step/render path.
 //
-// One workgroup (256 threads = 4 wavefronts) owns one agent for one step:
-//   phase 0  the agent's tile_map (2·H·W bits) is staged in LDS; lane 0 runs the dynamics
-//            (act!(world, a) SR:139-191, or the opt-in re-sample SR:110-137) and publishes
-//            the new pose through LDS;
-//   phase 1  one lane per view column: table lookup of the ray (SR:214-221), grid DDA
-//            against the LDS tile map (RayCaster.cast_ray, SR:223), perpendicular distance
-//            and column height (SR:404-411), colour (SR:417-429) -> an 8-byte column
-//            descriptor in LDS, mirrored to image column k = N - i + 1 (SR:431);
-//   phase 2  the workgroup re-maps lanes along the image's contiguous axis (rows of one
-//            column, Julia column-major (H_cam, N)) and streams the frame out with
-//            16-byte non-temporal stores — one wavefront store instruction writes one
-//            whole 1 KiB column at H_cam = 256.
+// A step is two launches on the handle's stream:
+//   rcw_cast_kernel   one workgroup (4 wavefronts) per agent.  The agent's tile_map (2·H·W
+//            bits) is staged in LDS; lane 0 runs the dynamics (act!(world, a) SR:139-191, or
+//            the opt-in re-sample SR:110-137) and publishes the new pose through LDS; then
+//            one lane per view column: table lookup of the ray (SR:214-221), grid DDA against
+//            the LDS tile map (RayCaster.cast_ray, SR:223), perpendicular distance and column
+//            height (SR:404-411), colour (SR:417-429) -> a 5-byte column descriptor in HBM,
+//            mirrored to image column k = N - i + 1 (SR:431).
+//   rcw_fill*_kernel  the bandwidth kernel (update_camera_view!'s column fill SR:431-440):
+//            a small fixed grid sweeps one compact window through the (H_cam, N, B) batch,
+//            lanes mapped along the image's contiguous axis (rows of one column, Julia
+//            column-major), one 16-byte store per lane, one whole 1 KiB column per wavefront
+//            store instruction at H_cam = 256.
 // This is an integer/indexing + streaming-store path: no MFMA, the roofline is HBM write
 // bandwidth, and the frame (4·H_cam·N bytes per agent-step) is written exactly once.
 //
@@ -52,7 +53,7 @@ __device__ __forceinline__ void set_goal_bit(uint32_t* tm, int H, int i, int j, 
 // layer: 0 = false, 1 = true, 2 = BoundsError.
 struct Collide { int wall, goal; };
 __device__ __forceinline__ Collide player_colliding(const uint32_t* tm, int H, int W, float px,
-                                                    float py, float radius_sq)
+                                                    float py, float radius_sq, int oob_empty)
 {
     const int it = (int)floorf(px) + 1;   // wu_to_tu UT:5
     const int jt = (int)floorf(py) + 1;
@@ -60,6 +61,7 @@ __device__ __forceinline__ Collide player_colliding(const uint32_t* tm, int H, i
     for (int j = jt - 1; j <= jt + 1; ++j) {
         for (int i = it - 1; i <= it + 1; ++i) {
             if (i < 1 || i > H || j < 1 || j > W) {
+                if (oob_empty) continue;
                 if (wall < 0) wall = 2;
                 if (goal < 0) goal = 2;
                 continue;
@@ -184,22 +186,20 @@ __device__ __forceinline__ uint32_t pixel(int r, int pad, int Hc, uint32_t colou
     return r < pad ? ceil_c : (r < Hc - pad ? colour : floor_c);
 }
 
-// ---- the step kernel --------------------------------------------------------------------
-template <bool HC256>
-__global__ __launch_bounds__(kBlock) void rcw_step_kernel(const RcwDev p,
+// ---- kernel 1 of a step: dynamics + ray cast + projection --------------------------------
+// One workgroup per agent.  Output: the agent's new state and one compact descriptor per
+// image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
+// of pixels the fill kernel then writes for it.
+__global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
                                                           const uint8_t* __restrict__ actions,
                                                           const uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int a = blockIdx.x;
     const int tid = threadIdx.x;
-    if (*p.err != 0) return;                   // sticky error: nothing is mutated
     if (mask != nullptr && mask[a] == 0) return;
 
-    const int nwords_pad = (p.nwords + 3) & ~3;
-    uint32_t* tm = lds;                                     // [nwords]
-    int* s_pad = (int*)(lds + nwords_pad);                  // [N]
-    uint32_t* s_col = lds + nwords_pad + p.N;               // [N]
+    uint32_t* tm = lds;                                     // [nwords] the agent's tile map
     __shared__ float s_pose[4];
 
     uint32_t* tm_hbm = p.tile_map + (size_t)a * p.nwords;
@@ -208,7 +208,12 @@ __global__ __launch_bounds__(kBlock) void rcw_step_kernel(const RcwDev p,
 
     // ---- phase 0: dynamics (lane 0) -------------------------------------------------------
     if (tid == 0) {
-        const int act = actions ? (int)actions[a] : 0;
+        int act = actions ? (int)actions[a] : 0;
+        if (actions && (act < 1 || act > RCW_NUM_ACTIONS)) {                // @assert SR:140
+            p.err[0] = RCW_ERR_INVALID_ACTION;                              // this agent is not stepped
+            p.status[a] = RCW_ERR_INVALID_ACTION;
+            act = 0;
+        }
         float2 pos = p.pos[a];
         int d = p.dir[a];
         if (act != 0 && p.auto_reset && p.done[a]) {
@@ -219,9 +224,10 @@ __global__ __launch_bounds__(kBlock) void rcw_step_kernel(const RcwDev p,
             const float ix = p.inc * dv.x, iy = p.inc * dv.y;
             const float nx = act == 1 ? pos.x + ix : pos.x - ix;            // UT:16-17
             const float ny = act == 1 ? pos.y + iy : pos.y - iy;
-            const Collide c = player_colliding(tm, p.H, p.W, nx, ny, p.radius_sq);   // SR:162-163
+            const Collide c = player_colliding(tm, p.H, p.W, nx, ny, p.radius_sq, p.oob_empty);   // SR:162-163
             if (c.wall == 2 || c.goal == 2) {
-                atomicCAS(p.err, 0, RCW_ERR_OUT_OF_BOUNDS);                 // BoundsError: no mutation
+                p.err[0] = RCW_ERR_OUT_OF_BOUNDS;                           // BoundsError: no mutation
+                p.status[a] = RCW_ERR_OUT_OF_BOUNDS;
             } else if (c.goal) {
                 p.reward[a] = p.goal_reward; p.done[a] = 1;                 // SR:166-168
             } else if (c.wall) {
@@ -248,72 +254,100 @@ __global__ __launch_bounds__(kBlock) void rcw_step_kernel(const RcwDev p,
         const float ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
         const float dot = tab[4 * p.N + i];
         const RayHit r = cast_ray(tm, p.H, p.W, x, y, dx, dy, ddx, ddy, p.tie_le, p.dist_pre);
-        if (r.oob) atomicCAS(p.err, 0, RCW_ERR_OUT_OF_BOUNDS);
+        if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
         const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);
         const int k = p.N - 1 - i;                                          // SR:431 (0-based)
-        s_pad[k] = column_padding(p.Hc, h);
-        s_col[k] = p.colour[cid];
-        if (p.col_h) { p.col_h[(size_t)a * p.N + k] = h; p.col_c[(size_t)a * p.N + k] = (uint8_t)cid; }
+        p.col_h[(size_t)a * p.N + k] = h;
+        p.col_c[(size_t)a * p.N + k] = (uint8_t)cid;
     }
-    __syncthreads();
+}
 
-    // ---- phase 2: stream the frame (Hc, N) column-major --------------------------------------
-    uint32_t* frame = p.obs + (size_t)a * p.N * p.Hc;
+// ---- kernel 2 of a step: column descriptors -> pixels -------------------------------------
+// The bandwidth kernel: B·N·H_cam·4 bytes, written once.  HBM on MI355X takes writes fastest
+// when the whole chip sweeps ONE compact window through memory (measured, tools/fill_bench:
+// 6.6–6.7 TB/s for 128–256 workgroups striding a 0.5–1 MiB window, against 5.9–6.2 TB/s
+// for one workgroup per 256 KiB frame and 4.5 TB/s for 1024 workgroups).  So the grid is
+// small and fixed (p.fill_grid workgroups of 4 wavefronts); wavefront g of G writes the 1 KiB
+// chunks g, g+G, g+2G, ... of the flat (H_cam, N, B) batch.  At H_cam = 256 a chunk is one
+// image column: the wavefront prefetches 64 descriptors (one per lane, for its next 64
+// chunks), then per chunk broadcasts one with v_readlane and lane l writes rows 4l..4l+3
+// with one 16-byte store — 64 lanes x 16 B = the whole column in one instruction.
+template <bool PLAIN>
+__device__ __forceinline__ void store16(u32x4* dst, u32x4 v)
+{
+    if (PLAIN) *dst = v; else __builtin_nontemporal_store(v, dst);
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
+                                                             const int32_t* __restrict__ col_h,
+                                                             const uint8_t* __restrict__ col_c,
+                                                             u32x4* __restrict__ out, long long total_cols,
+                                                             const uint8_t* __restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const long long G = (long long)gridDim.x * (kBlock / 64);
+    const long long g = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
-    if (HC256) {
-        // one wavefront store instruction = one column: lane l writes rows 4l..4l+3
-        const int wave = tid >> 6, lane = tid & 63;
-        const int r0 = lane * 4;
-        u32x4* out = reinterpret_cast<u32x4*>(frame);
+    const int r0 = lane * 4;
+    for (long long base = g; base < total_cols; base += G * 64) {
+        // lane l holds the descriptor of this wavefront's l-th next chunk
+        const long long mine = base + (long long)lane * G;
+        int pad_l = -1;                       // -1: nothing to write (past the end / masked out)
+        uint32_t colour_l = 0u;
+        if (mine < total_cols && (mask == nullptr || mask[mine / p.N] != 0)) {
+            pad_l = column_padding(256, col_h[mine]);
+            colour_l = p.colour[col_c[mine] & 3];
+        }
 #pragma unroll 4
-        for (int k = wave; k < p.N; k += kBlock / 64) {
-            const int pad = s_pad[k];
-            const uint32_t c = s_col[k];
+        for (int l = 0; l < 64; ++l) {
+            const int pad = __builtin_amdgcn_readlane(pad_l, l);
+            if (pad < 0) continue;            // wave-uniform
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)colour_l, l);
             u32x4 v;
             v.x = pixel(r0 + 0, pad, 256, c, ceil_c, floor_c);
             v.y = pixel(r0 + 1, pad, 256, c, ceil_c, floor_c);
             v.z = pixel(r0 + 2, pad, 256, c, ceil_c, floor_c);
             v.w = pixel(r0 + 3, pad, 256, c, ceil_c, floor_c);
-            __builtin_nontemporal_store(v, out + (size_t)k * 64 + lane);
+            store16<PLAIN>(out + (base + (long long)l * G) * 64 + lane, v);
         }
-    } else if ((p.Hc & 3) == 0) {
-        const int vpc = p.Hc >> 2;                       // 16-byte vectors per column
-        const int total = p.N * vpc;
-        u32x4* out = reinterpret_cast<u32x4*>(frame);
-        for (int idx = tid; idx < total; idx += kBlock) {
-            const int k = idx / vpc;
-            const int r0 = (idx - k * vpc) * 4;
-            const int pad = s_pad[k];
-            const uint32_t c = s_col[k];
+    }
+}
+
+// Any H_cam: the same moving window over the flat pixel array; a 1 KiB chunk may straddle
+// columns, so every lane looks its own column up.  VEC: 16-byte stores (H_cam % 4 == 0).
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void rcw_fill_any_kernel(const RcwDev p,
+                                                              const int32_t* __restrict__ col_h,
+                                                              const uint8_t* __restrict__ col_c,
+                                                              uint32_t* __restrict__ out, long long total_cols,
+                                                              const uint8_t* __restrict__ mask)
+{
+    const long long per_col = VEC ? (p.Hc >> 2) : p.Hc;         // store units per column
+    const long long total = total_cols * per_col;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long idx = (long long)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += stride) {
+        const long long c = idx / per_col;
+        if (mask != nullptr && mask[c / p.N] == 0) continue;
+        const int r0 = (int)(idx - c * per_col) * (VEC ? 4 : 1);
+        const int pad = column_padding(p.Hc, col_h[c]);
+        const uint32_t colour = p.colour[col_c[c] & 3];
+        if (VEC) {
             u32x4 v;
-            v.x = pixel(r0 + 0, pad, p.Hc, c, ceil_c, floor_c);
-            v.y = pixel(r0 + 1, pad, p.Hc, c, ceil_c, floor_c);
-            v.z = pixel(r0 + 2, pad, p.Hc, c, ceil_c, floor_c);
-            v.w = pixel(r0 + 3, pad, p.Hc, c, ceil_c, floor_c);
-            __builtin_nontemporal_store(v, out + idx);
-        }
-    } else {
-        const int total = p.N * p.Hc;
-        for (int idx = tid; idx < total; idx += kBlock) {
-            const int k = idx / p.Hc;
-            const int r = idx - k * p.Hc;
-            __builtin_nontemporal_store(pixel(r, s_pad[k], p.Hc, s_col[k], ceil_c, floor_c), frame + idx);
+            v.x = pixel(r0 + 0, pad, p.Hc, colour, p.ceiling_color, p.floor_color);
+            v.y = pixel(r0 + 1, pad, p.Hc, colour, p.ceiling_color, p.floor_color);
+            v.z = pixel(r0 + 2, pad, p.Hc, colour, p.ceiling_color, p.floor_color);
+            v.w = pixel(r0 + 3, pad, p.Hc, colour, p.ceiling_color, p.floor_color);
+            reinterpret_cast<u32x4*>(out)[idx] = v;
+        } else {
+            out[idx] = pixel(r0, pad, p.Hc, colour, p.ceiling_color, p.floor_color);
         }
     }
 }
 
 // ---- small kernels ---------------------------------------------------------------------------
-// @assert action in 1:4  SR:140, for device-resident actions
-__global__ void rcw_validate_kernel(const RcwDev p, const uint8_t* __restrict__ actions)
-{
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= p.B) return;
-    const int act = actions[a];
-    if (act < 1 || act > RCW_NUM_ACTIONS) atomicCAS(p.err, 0, RCW_ERR_INVALID_ACTION);
-}
-
 // wall ring SR:57-60 and a placeholder goal at (2,2) (cleared by the first reset)
 __global__ void rcw_init_tile_map_kernel(const RcwDev p)
 {
@@ -331,6 +365,7 @@ __global__ void rcw_init_tile_map_kernel(const RcwDev p)
     p.episode[a] = 0;
     p.reward[a] = 0.0f;
     p.done[a] = 0;
+    p.status[a] = 0;
 }
 
 __global__ void rcw_reset_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
@@ -387,66 +422,42 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
     }
 }
 
-// receiving side of the compact observation gather: (height_line_pu, colour id) -> frame
-__global__ __launch_bounds__(kBlock) void rcw_expand_kernel(const RcwDev p,
-                                                            const int32_t* __restrict__ col_h,
-                                                            const uint8_t* __restrict__ col_c,
-                                                            uint32_t* __restrict__ frames)
-{
-    const int a = blockIdx.x;
-    const int tid = threadIdx.x;
-    uint32_t* frame = frames + (size_t)a * p.N * p.Hc;
-    const int total = p.N * p.Hc;
-    if ((p.Hc & 3) == 0) {
-        const int vpc = p.Hc >> 2;
-        u32x4* out = reinterpret_cast<u32x4*>(frame);
-        for (int idx = tid; idx < (total >> 2); idx += kBlock) {
-            const int k = idx / vpc;
-            const int r0 = (idx - k * vpc) * 4;
-            const int pad = column_padding(p.Hc, col_h[(size_t)a * p.N + k]);
-            const uint32_t c = p.colour[col_c[(size_t)a * p.N + k] & 3];
-            u32x4 v;
-            v.x = pixel(r0 + 0, pad, p.Hc, c, p.ceiling_color, p.floor_color);
-            v.y = pixel(r0 + 1, pad, p.Hc, c, p.ceiling_color, p.floor_color);
-            v.z = pixel(r0 + 2, pad, p.Hc, c, p.ceiling_color, p.floor_color);
-            v.w = pixel(r0 + 3, pad, p.Hc, c, p.ceiling_color, p.floor_color);
-            __builtin_nontemporal_store(v, out + idx);
-        }
-    } else {
-        for (int idx = tid; idx < total; idx += kBlock) {
-            const int k = idx / p.Hc;
-            const int r = idx - k * p.Hc;
-            const int pad = column_padding(p.Hc, col_h[(size_t)a * p.N + k]);
-            const uint32_t c = p.colour[col_c[(size_t)a * p.N + k] & 3];
-            frame[idx] = pixel(r, pad, p.Hc, c, p.ceiling_color, p.floor_color);
-        }
-    }
-}
-
 }  // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------
 size_t rcw_step_lds_bytes(const RcwDev& p)
 {
-    const size_t nwords_pad = ((size_t)p.nwords + 3) & ~(size_t)3;
-    return (nwords_pad + 2 * (size_t)p.N) * sizeof(uint32_t);
+    return (((size_t)p.nwords + 3) & ~(size_t)3) * sizeof(uint32_t);
+}
+
+hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
+                           long long total_cols, const uint8_t* mask_dev, hipStream_t s)
+{
+    const int grid = p.fill_grid;
+    if (p.Hc == 256) {
+        if (p.fill_plain)
+            hipLaunchKernelGGL(rcw_fill256_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
+                               reinterpret_cast<u32x4*>(frames), total_cols, mask_dev);
+        else
+            hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
+                               reinterpret_cast<u32x4*>(frames), total_cols, mask_dev);
+    } else if ((p.Hc & 3) == 0) {
+        hipLaunchKernelGGL(rcw_fill_any_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames,
+                           total_cols, mask_dev);
+    } else {
+        hipLaunchKernelGGL(rcw_fill_any_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames,
+                           total_cols, mask_dev);
+    }
+    return hipGetLastError();
 }
 
 hipError_t rcw_launch_step(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s)
 {
-    const size_t lds = rcw_step_lds_bytes(p);
-    if (p.Hc == 256)
-        hipLaunchKernelGGL(rcw_step_kernel<true>, dim3(p.B), dim3(kBlock), lds, s, p, actions_dev, mask_dev);
-    else
-        hipLaunchKernelGGL(rcw_step_kernel<false>, dim3(p.B), dim3(kBlock), lds, s, p, actions_dev, mask_dev);
-    return hipGetLastError();
-}
-
-hipError_t rcw_launch_validate(const RcwDev& p, const uint8_t* actions_dev, hipStream_t s)
-{
-    hipLaunchKernelGGL(rcw_validate_kernel, dim3((p.B + kBlock - 1) / kBlock), dim3(kBlock), 0, s, p, actions_dev);
-    return hipGetLastError();
+    hipLaunchKernelGGL(rcw_cast_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), s, p, actions_dev, mask_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return rcw_launch_fill(p, p.col_h, p.col_c, p.obs, (long long)p.B * p.N, mask_dev, s);
 }
 
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
@@ -470,14 +481,12 @@ hipError_t rcw_launch_init_tile_map(const RcwDev& p, hipStream_t s)
 
 hipError_t rcw_launch_rays(const RcwDev& p, int32_t first, int32_t count, RcwRayOut out, hipStream_t s)
 {
-    const size_t lds = (((size_t)p.nwords + 3) & ~(size_t)3) * sizeof(uint32_t);
-    hipLaunchKernelGGL(rcw_rays_kernel, dim3(count), dim3(kBlock), lds, s, p, first, out);
+    hipLaunchKernelGGL(rcw_rays_kernel, dim3(count), dim3(kBlock), rcw_step_lds_bytes(p), s, p, first, out);
     return hipGetLastError();
 }
 
 hipError_t rcw_launch_expand(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c,
                              int32_t count, uint32_t* frames, hipStream_t s)
 {
-    hipLaunchKernelGGL(rcw_expand_kernel, dim3(count), dim3(kBlock), 0, s, p, col_h, col_c, frames);
-    return hipGetLastError();
+    return rcw_launch_fill(p, col_h, col_c, frames, (long long)count * p.N, nullptr, s);
 }

@@ -141,6 +141,11 @@ class SingleRoomWorld:
         return self._get(self._env._lib.rcw_goal, np.int32, (self._env.batch, 2))
 
     @property
+    def status(self) -> np.ndarray:
+        """Per-agent sticky status: 0, or -5 where the reference would have raised BoundsError."""
+        return self._get(self._env._lib.rcw_status, np.int32, (self._env.batch,))
+
+    @property
     def episode(self) -> np.ndarray:
         return self._get(self._env._lib.rcw_episode, np.uint32, (self._env.batch,))
 
@@ -209,10 +214,10 @@ class SingleRoom:
         device: int = 0,
         auto_reset: bool = False,
         agent_id_offset: int = 0,
-        write_columns: bool = True,
         dda_tie_break: int = 0,
         dda_distance: int = 0,
         normalize_mode: int = 0,
+        out_of_bounds: int = 0,
     ):
         if str(T) not in ("Float32", "float32", "<class 'numpy.float32'>") or str(R) not in (
             "Float32", "float32", "<class 'numpy.float32'>"):
@@ -231,10 +236,10 @@ class SingleRoom:
         cfg.height_camera_view_pu = height_camera_view_pu
         cfg.auto_reset = 1 if auto_reset else 0
         cfg.agent_id_offset = agent_id_offset
-        cfg.write_columns = 1 if write_columns else 0
         cfg.dda_tie_break = dda_tie_break
         cfg.dda_distance = dda_distance
         cfg.normalize_mode = normalize_mode
+        cfg.out_of_bounds = out_of_bounds
         self.cfg = cfg
         self.batch = int(batch)
         self.device = int(device)

@@ -112,13 +112,18 @@ def test_device_actions_and_validation(rcw, oracle):
         rcw.act_(env, torch.from_numpy(a).cuda())
         orc.step(a)
     assert_state_equal(env, orc, where="device actions")
-    bad = torch.full((env.batch,), 1, dtype=torch.uint8, device="cuda")
+    bad = rng.integers(1, 5, env.batch).astype(np.uint8)
     bad[17] = 9
-    rcw.act_(env, bad)           # asynchronous: surfaces at the next sync / getter
+    bad[3] = 0
+    rcw.act_(env, torch.from_numpy(bad).cuda())   # asynchronous: surfaces at the next sync / getter
+    orc.step_lenient(bad)
     with pytest.raises(AssertionError):
         env.sync()
+    np.testing.assert_array_equal(env.world.status, orc.status)
+    assert env.world.status[17] == -2 and env.world.status[3] == -2
     env.clear_error()
-    assert_state_equal(env, orc, where="after rejected device actions")
+    orc.clear_status()
+    assert_state_equal(env, orc, where="after device actions with two invalid entries")
     env.close()
 
 
@@ -161,3 +166,45 @@ def test_odd_camera_heights(rcw, oracle):
         env, orc = _make(rcw, oracle, 8, seed=3, height_camera_view_pu=hc, **CFG1)
         _rollout(rcw, env, orc, 20, rng, check_every=5)
         env.close()
+
+
+def test_reference_bounds_error_quirk(rcw, oracle):
+    """Walking +x in exact 1/8 steps reaches x = H-1-1/8 (not colliding: strict `<`, CD:18);
+    the next forward move indexes tile H+1 -> BoundsError in the reference (CD:35).  The
+    engine reports it, leaves that agent as it was and keeps stepping the others."""
+    env, orc = _make(rcw, oracle, 4, seed=0, **CFG1)
+    goal = np.array([[2, 2]] * 4, dtype=np.int32)
+    pos = np.array([[4.5, 4.5], [4.5, 4.5], [4.5, 4.5], [2.5, 5.5]], dtype=np.float32)
+    d = np.array([0, 32, 64, 0], dtype=np.int32)      # +x, +y, -x, +x
+    env.set_state(goal, pos, d)
+    orc.set_state(goal, pos, d)
+    fwd = np.ones(4, dtype=np.uint8)
+    for _ in range(19):                                # 4.5 + 19/8 = 6.875
+        rcw.act_(env, fwd)
+        orc.step(fwd)
+    env.sync()                                         # no error yet
+    assert env.world.player_position_wu[0, 0] == np.float32(6.875)
+    rcw.act_(env, fwd)
+    orc.step(fwd)
+    with pytest.raises(IndexError):
+        env.sync()
+    np.testing.assert_array_equal(env.world.status, orc.status)
+    assert list(env.world.status) == [-5, -5, 0, 0]
+    env.clear_error()
+    assert_state_equal(env, orc, where="after BoundsError")
+    turn = np.full(4, 3, dtype=np.uint8)
+    rcw.act_(env, turn)
+    orc.step(turn)
+    assert_state_equal(env, orc, where="turn after BoundsError")
+    env.close()
+    # RCW_OOB_TREAT_EMPTY: same walk, the move is simply blocked by the wall
+    env, orc = _make(rcw, oracle, 4, seed=0, out_of_bounds=1, **CFG1)
+    env.set_state(goal, pos, d)
+    orc.set_state(goal, pos, d)
+    for _ in range(25):
+        rcw.act_(env, fwd)
+        orc.step(fwd)
+    env.sync()
+    assert_state_equal(env, orc, where="treat-empty policy")
+    assert env.world.player_position_wu[0, 0] == np.float32(6.875)
+    env.close()
