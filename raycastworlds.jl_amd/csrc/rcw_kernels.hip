@@ -2,9 +2,10 @@
 //
 // A step is two launches on the handle's stream:
 //   rcw_cast_kernel   one workgroup (4 wavefronts) per agent.  The agent's tile_map (2·H·W
-//            bits) is staged in LDS; lane 0 runs the dynamics (act!(world, a) SR:139-191, or
-//            the opt-in re-sample SR:110-137) and publishes the new pose through LDS; then
-//            one lane per view column: table lookup of the ray (SR:214-221), grid DDA against
+//            bits) is staged in LDS; every lane runs the (wave-uniform) dynamics
+//            act!(world, a) SR:139-191 redundantly so nothing has to be broadcast — the opt-in
+//            re-sample SR:110-137 runs on lane 0 and goes through LDS; then one lane per
+//            view column: table lookup of the ray (SR:214-221), grid DDA against
 //            the LDS tile map (RayCaster.cast_ray, SR:223), perpendicular distance and column
 //            height (SR:404-411), colour (SR:417-429) -> a 5-byte column descriptor in HBM,
 //            mirrored to image column k = N - i + 1 (SR:431).
@@ -25,6 +26,7 @@
 #include "../../include/rcw.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -52,38 +54,36 @@ __device__ __forceinline__ void set_goal_bit(uint32_t* tm, int H, int i, int j, 
 // (BoundsError if the tile is off the map) and returns at the first hit.  Result per
 // layer: 0 = false, 1 = true, 2 = BoundsError.
 struct Collide { int wall, goal; };
+// Wave-parallel form: lane t < 9 tests tile t of the neighbourhood in the reference's visiting
+// order (t = 3 (j - jt + 1) + (i - it + 1)); three ballots recover "first event in order" per
+// layer.  Every lane of the wave gets the same (wave-uniform) result.  px, py are uniform.
 __device__ __forceinline__ Collide player_colliding(const uint32_t* tm, int H, int W, float px,
                                                     float py, float radius_sq, int oob_empty)
 {
     const int it = (int)floorf(px) + 1;   // wu_to_tu UT:5
     const int jt = (int)floorf(py) + 1;
-    int wall = -1, goal = -1;             // -1 = undecided
-    for (int j = jt - 1; j <= jt + 1; ++j) {
-        for (int i = it - 1; i <= it + 1; ++i) {
-            if (i < 1 || i > H || j < 1 || j > W) {
-                if (oob_empty) continue;
-                if (wall < 0) wall = 2;
-                if (goal < 0) goal = 2;
-                continue;
-            }
-            const uint32_t bits = tile_bits(tm, H, i, j);
-            if (bits == 0u) continue;
-            const float cx = (float)i - 0.5f, cy = (float)j - 0.5f;      // CD:33-34
-            const float qx = px - cx, qy = py - cy;                      // CD:35
-            const float sx = qx < -0.5f ? -0.5f : (qx > 0.5f ? 0.5f : qx);   // CD:11
-            const float sy = qy < -0.5f ? -0.5f : (qy > 0.5f ? 0.5f : qy);
-            const float vx = qx - sx, vy = qy - sy;                      // CD:16
-            const float vx2 = vx * vx, vy2 = vy * vy;
-            const bool hit = (vx2 + vy2) < radius_sq;                    // CD:18
-            if (hit) {
-                if ((bits & 1u) && wall < 0) wall = 1;
-                if ((bits & 2u) && goal < 0) goal = 1;
-            }
-        }
-    }
+    const int t = (int)(threadIdx.x & 63u);
+    const int tq = t / 3;
+    const int i = it - 1 + (t - 3 * tq), j = jt - 1 + tq;
+    const bool valid = t < 9;
+    const bool inb = i >= 1 && i <= H && j >= 1 && j <= W;
+    const uint32_t bits = (valid && inb) ? tile_bits(tm, H, i, j) : 0u;
+    const float cx = (float)i - 0.5f, cy = (float)j - 0.5f;          // CD:33-34
+    const float qx = px - cx, qy = py - cy;                          // CD:35
+    const float sx = qx < -0.5f ? -0.5f : (qx > 0.5f ? 0.5f : qx);   // clamp CD:11
+    const float sy = qy < -0.5f ? -0.5f : (qy > 0.5f ? 0.5f : qy);
+    const float vx = qx - sx, vy = qy - sy;                          // CD:16
+    const float vx2 = vx * vx, vy2 = vy * vy;
+    const bool hit = (vx2 + vy2) < radius_sq;                        // CD:18
+    const unsigned long long m_oob = __ballot(valid && !inb && !oob_empty);
+    const unsigned long long m_wall = __ballot(hit && (bits & 1u));
+    const unsigned long long m_goal = __ballot(hit && (bits & 2u));
+    const int first_oob = m_oob ? __builtin_ctzll(m_oob) : 64;
+    const int first_wall = m_wall ? __builtin_ctzll(m_wall) : 64;
+    const int first_goal = m_goal ? __builtin_ctzll(m_goal) : 64;
     Collide c;
-    c.wall = wall < 0 ? 0 : wall;
-    c.goal = goal < 0 ? 0 : goal;
+    c.wall = first_wall < first_oob ? 1 : (first_oob < 64 ? 2 : 0);
+    c.goal = first_goal < first_oob ? 1 : (first_oob < 64 ? 2 : 0);
     return c;
 }
 
@@ -143,15 +143,17 @@ __device__ __forceinline__ RayHit cast_ray(const uint32_t* tm, int H, int W, flo
     else           { sj = +1; sy = ((float)j - y) * ddy; }
     RayHit r;
     r.dim = 0; r.dist = 0.0f; r.bits = 0u; r.oob = false;
+    int t = (i - 1) + H * (j - 1);          // linear tile index, kept incrementally
+    const int tj = sj * H;
     // Every iteration moves one tile in a fixed direction, so the loop leaves the map (and
     // exits) after at most H + W steps even on a map without a closed wall ring.
     for (;;) {
         if ((unsigned)(i - 1) >= (unsigned)H || (unsigned)(j - 1) >= (unsigned)W) { r.oob = true; break; }
-        r.bits = tile_bits(tm, H, i, j);
+        r.bits = (tm[t >> 4] >> ((t & 15) * 2)) & 3u;
         if (r.bits) break;
         const bool x_first = tie_le ? (sx <= sy) : (sx < sy);
-        if (x_first) { r.dist = sx; sx = sx + ddx; i += si; r.dim = 1; }
-        else         { r.dist = sy; sy = sy + ddy; j += sj; r.dim = 2; }
+        if (x_first) { r.dist = sx; sx = sx + ddx; i += si; t += si; r.dim = 1; }
+        else         { r.dist = sy; sy = sy + ddy; j += sj; t += tj; r.dim = 2; }
     }
     if (!dist_pre) {
         if (r.dim == 1) r.dist = sx - ddx;
@@ -190,6 +192,7 @@ __device__ __forceinline__ uint32_t pixel(int r, int pad, int Hc, uint32_t colou
 // One workgroup per agent.  Output: the agent's new state and one compact descriptor per
 // image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
 // of pixels the fill kernel then writes for it.
+template <int DEV>   // development ablation bits: 1 skip DDA, 2 skip stores, 4 skip dynamics, 8 skip table loads
 __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
                                                           const uint8_t* __restrict__ actions,
                                                           const uint8_t* __restrict__ mask)
@@ -202,65 +205,86 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     uint32_t* tm = lds;                                     // [nwords] the agent's tile map
     __shared__ float s_pose[4];
 
+    // ---- every load of the agent's state is issued up front (all wave-uniform addresses) ----
     uint32_t* tm_hbm = p.tile_map + (size_t)a * p.nwords;
-    for (int w = tid; w < p.nwords; w += kBlock) tm[w] = tm_hbm[w];
+    for (int w = tid; w < p.nwords; w += (int)blockDim.x) tm[w] = tm_hbm[w];
+    int act = actions ? (int)actions[a] : 0;
+    const float2 pos = p.pos[a];
+    const int d = p.dir[a];
+    const int was_done = p.done[a];
+    const float2 dv = p.dir_table[d];                                       // SR:153
+    const bool invalid = actions != nullptr && (act < 1 || act > RCW_NUM_ACTIONS);   // @assert SR:140
+    if (invalid) act = 0;                                                   // this agent is not stepped
+    const bool resample = act != 0 && p.auto_reset != 0 && was_done != 0;
+    // the heading after the action depends on nothing else, so the ray-table row is known now
+    int d_new = d;
+    if (!resample && act == 3) d_new = d + 1 >= p.nd ? 0 : d + 1;          // turn_left  UT:13
+    if (!resample && act == 4) d_new = d - 1 < 0 ? p.nd - 1 : d - 1;       // turn_right UT:14
+    // All four wavefronts must have READ the state before lane 0 overwrites it below: pin the
+    // loaded values in registers ahead of the barrier.
+    asm volatile("" :: "v"(pos.x), "v"(pos.y), "v"(d), "v"(was_done), "v"(act), "v"(dv.x), "v"(dv.y));
     __syncthreads();
 
-    // ---- phase 0: dynamics (lane 0) -------------------------------------------------------
-    if (tid == 0) {
-        int act = actions ? (int)actions[a] : 0;
-        if (actions && (act < 1 || act > RCW_NUM_ACTIONS)) {                // @assert SR:140
-            p.err[0] = RCW_ERR_INVALID_ACTION;                              // this agent is not stepped
-            p.status[a] = RCW_ERR_INVALID_ACTION;
-            act = 0;
-        }
-        float2 pos = p.pos[a];
-        int d = p.dir[a];
-        if (act != 0 && p.auto_reset && p.done[a]) {
+    // ---- phase 0: dynamics, computed redundantly by every lane (no broadcast needed) --------
+    float x = pos.x, y = pos.y;
+    if (resample) {                                                         // wave-uniform, rare
+        if (tid == 0) {
             const Pose np = reset_agent(p, a, tm, tm_hbm);
-            pos = make_float2(np.x, np.y); d = np.d;
-        } else if (act == 1 || act == 2) {                                  // SR:150
-            const float2 dv = p.dir_table[d];                               // SR:153
+            s_pose[0] = np.x; s_pose[1] = np.y; s_pose[2] = __int_as_float(np.d);
+        }
+        __syncthreads();
+        x = s_pose[0]; y = s_pose[1];
+        d_new = __float_as_int(s_pose[2]);
+    } else if (act != 0 && !(DEV & 4)) {
+        float reward = 0.0f;
+        int done = 0;
+        bool oob = false;
+        if (act <= 2) {                                                     // SR:150
             const float ix = p.inc * dv.x, iy = p.inc * dv.y;
             const float nx = act == 1 ? pos.x + ix : pos.x - ix;            // UT:16-17
             const float ny = act == 1 ? pos.y + iy : pos.y - iy;
             const Collide c = player_colliding(tm, p.H, p.W, nx, ny, p.radius_sq, p.oob_empty);   // SR:162-163
-            if (c.wall == 2 || c.goal == 2) {
-                p.err[0] = RCW_ERR_OUT_OF_BOUNDS;                           // BoundsError: no mutation
-                p.status[a] = RCW_ERR_OUT_OF_BOUNDS;
-            } else if (c.goal) {
-                p.reward[a] = p.goal_reward; p.done[a] = 1;                 // SR:166-168
-            } else if (c.wall) {
-                p.reward[a] = 0.0f; p.done[a] = 0;                          // SR:170-171
-            } else {
-                pos = make_float2(nx, ny);
-                p.pos[a] = pos; p.reward[a] = 0.0f; p.done[a] = 0;          // SR:174-176
-            }
-        } else if (act == 3 || act == 4) {
-            d = act == 3 ? d + 1 : d - 1;                                   // UT:13-14
-            d = d >= p.nd ? d - p.nd : (d < 0 ? d + p.nd : d);              // mod(d±1, nd)
-            p.dir[a] = d; p.reward[a] = 0.0f; p.done[a] = 0;                // SR:185-187
+            if (c.wall == 2 || c.goal == 2) oob = true;                     // BoundsError: no mutation
+            else if (c.goal) { reward = p.goal_reward; done = 1; }          // SR:166-168
+            else if (c.wall) { }                                            // SR:170-171
+            else { x = nx; y = ny; }                                        // SR:174
         }
-        s_pose[0] = pos.x; s_pose[1] = pos.y; s_pose[2] = __int_as_float(d);
+        if (tid == 0) {
+            if (oob) {
+                p.err[0] = RCW_ERR_OUT_OF_BOUNDS;
+                p.status[a] = RCW_ERR_OUT_OF_BOUNDS;
+            } else {
+                p.pos[a] = make_float2(x, y);                               // SR:174
+                p.dir[a] = d_new;                                           // SR:185
+                p.reward[a] = reward; p.done[a] = (uint8_t)done;            // SR:175-176, SR:186-187
+            }
+        }
     }
-    __syncthreads();
-    const float x = s_pose[0], y = s_pose[1];
-    const int d = __builtin_amdgcn_readfirstlane(__float_as_int(s_pose[2]));
+    if (invalid && tid == 0) { p.err[0] = RCW_ERR_INVALID_ACTION; p.status[a] = RCW_ERR_INVALID_ACTION; }
+    d_new = __builtin_amdgcn_readfirstlane(d_new);
 
     // ---- phase 1: one lane per view column --------------------------------------------------
-    const float* tab = p.ray_table + (size_t)d * RCW_TABLE_ROWS * p.N;
-    for (int i = tid; i < p.N; i += kBlock) {                               // SR:220, SR:401
-        const float dx = tab[i], dy = tab[p.N + i];
-        const float ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
-        const float dot = tab[4 * p.N + i];
-        const RayHit r = cast_ray(tm, p.H, p.W, x, y, dx, dy, ddx, ddy, p.tie_le, p.dist_pre);
+    const float* tab = p.ray_table + (size_t)d_new * RCW_TABLE_ROWS * p.N;
+    for (int i = tid; i < p.N; i += (int)blockDim.x) {                        // SR:220, SR:401
+        float dx, dy, ddx, ddy, dot;
+        if (DEV & 8) { dx = 0.6f + i * 1e-3f; dy = 0.5f; ddx = 1.0f / dx; ddy = 2.0f; dot = 0.9f; }
+        else {
+        dx = tab[i]; dy = tab[p.N + i];
+        ddx = tab[2 * p.N + i]; ddy = tab[3 * p.N + i];
+        dot = tab[4 * p.N + i];
+        }
+        RayHit r;
+        if (DEV & 1) { r.i = 8; r.j = 3; r.dim = 1; r.dist = 2.0f + dx; r.bits = 1; r.oob = false; }
+        else r = cast_ray(tm, p.H, p.W, x, y, dx, dy, ddx, ddy, p.tie_le, p.dist_pre);
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
         const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);
         const int k = p.N - 1 - i;                                          // SR:431 (0-based)
+        if (!(DEV & 2) || h == 123456789) {
         p.col_h[(size_t)a * p.N + k] = h;
         p.col_c[(size_t)a * p.N + k] = (uint8_t)cid;
+        }
     }
 }
 
@@ -454,9 +478,16 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
 hipError_t rcw_launch_step(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s)
 {
-    hipLaunchKernelGGL(rcw_cast_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), s, p, actions_dev, mask_dev);
+    static const int mode = [] { const char* v = getenv("RCW_STEP_MODE"); return v ? atoi(v) : 0; }();   // dev knob
+    if (mode != 2)
+    {
+        static const int dev = [] { const char* v = getenv("RCW_CAST_DEV"); return v ? atoi(v) : 0; }();
+#define RCW_CAST_CASE(D) case D: hipLaunchKernelGGL(rcw_cast_kernel<D>, dim3(p.B), dim3(p.cast_block), rcw_step_lds_bytes(p), s, p, actions_dev, mask_dev); break;
+        switch (dev) { RCW_CAST_CASE(1) RCW_CAST_CASE(2) RCW_CAST_CASE(3) RCW_CAST_CASE(4) RCW_CAST_CASE(7) RCW_CAST_CASE(8) RCW_CAST_CASE(15) default: RCW_CAST_CASE(0) }
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (mode == 1) return e;
     return rcw_launch_fill(p, p.col_h, p.col_c, p.obs, (long long)p.B * p.N, mask_dev, s);
 }
 
