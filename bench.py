@@ -38,20 +38,37 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(kw, batch_hint, target_seconds=12.0):
-    """Time the CPU oracle (all host cores, OpenMP over agents) on a bounded sample."""
+    """Time the CPU oracle (OpenMP over agents on the usable host cores) on a bounded sample."""
     from oracle import oracle as O
 
-    threads = O.num_threads()
-    agents = min(batch_hint, 512)
-    orc = O.OracleBatch(agents, seed=0, auto_reset=1, **kw)
+    threads = usable_cores()
+    O.set_num_threads(threads)
+    agents = min(batch_hint, 32 * threads)
+    orc = O.OracleBatch(agents, seed=0, auto_reset=1, out_of_bounds=0, **kw)
     rng = np.random.default_rng(0)
     acts = rng.integers(1, 5, (64, agents)).astype(np.uint8)
-    t0 = time.perf_counter()
-    for s in range(4):
+    for s in range(8):                       # warm up threads and pages
         orc.step(acts[s])
-    per_step = (time.perf_counter() - t0) / 4
-    steps = int(max(8, min(20000, target_seconds / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for s in range(16):
+        orc.step(acts[s])
+    per_step = (time.perf_counter() - t0) / 16
+    steps = int(max(16, min(200000, target_seconds / max(per_step, 1e-7))))
     t0 = time.perf_counter()
     for s in range(steps):
         orc.step(acts[s & 63])
@@ -63,7 +80,7 @@ def cpu_baseline(kw, batch_hint, target_seconds=12.0):
         "cores": threads,
         "kind": "port",
         "sample": f"{agents} agents x {steps} steps of the same workload (C restatement of the reference "
-                  f"camera path, OpenMP over agents, {dt:.1f} s)",
+                  f"camera path incl. the frame fill, OpenMP over agents, {dt:.1f} s)",
     }
 
 
@@ -141,16 +158,27 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    # Outside the timed region: the same steps again with HIP events around each kernel, to
+    # read the dominant (fill) kernel's own launch duration for the roofline block.
+    nprof = min(args.steps, 200)
+    env.profile(True)
+    for s in range(args.warmup, args.warmup + nprof):
+        RCW.act_(env, actions[s])
+    cast_ms, fill_ms, nrec = env.profile_read()
+    env.profile(False)
+    sync_counting_bounds_errors()
     if dist is not None:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, kernel_ms, cast_ms, fill_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(t[0]), float(t[1])
+        dt, kernel_ms, cast_ms, fill_ms = (float(v) for v in t)
 
     if rank == 0:
         frame_bytes = 4 * Hc * N                          # bytes per env-step
-        bytes_per_launch = frame_bytes * B                # one launch = B agents
-        launch_s = kernel_ms / 1e3 / args.steps
-        achieved = bytes_per_launch / launch_s / 1e9
+        bytes_per_launch = frame_bytes * B                # one fill launch = B agents
+        fill_s = fill_ms / 1e3                            # dominant kernel, HIP events around it
+        achieved = bytes_per_launch / fill_s / 1e9
+        step_s = kernel_ms / 1e3 / args.steps             # cast + fill, events around the region
+        step_achieved = bytes_per_launch / step_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -158,7 +186,7 @@ def main():
                 with open(tpath) as f:
                     t = json.load(f)
                 if t.get("workload") == args.workload and t.get("batch") == B:
-                    traffic = t.get("write_bytes_per_launch")
+                    traffic = t.get("traffic_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -192,9 +220,17 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "rcw_step_kernel",
+                "kernel": "rcw_fill256_kernel" if Hc == 256 else "rcw_fill_any_kernel",
                 "bytes_per_launch": bytes_per_launch,
-                "launch_ms": launch_s * 1e3,
+                "launch_ms": fill_ms,
+                "launches_timed": nrec,
+                "whole_step": {
+                    "kernels": "rcw_cast_kernel + fill kernel",
+                    "launch_ms": step_s * 1e3,
+                    "cast_ms": cast_ms,
+                    "achieved": step_achieved,
+                    "frac": step_achieved / HBM_PEAK_GBS,
+                },
             },
         }
         if world == 1 and not args.no_cpu_baseline:

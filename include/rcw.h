@@ -243,6 +243,12 @@ RCW_API int rcw_direction_table(rcw_handle* h, float* out_host /* (2, nd) */);
 RCW_API int rcw_timer_start(rcw_handle* h);
 RCW_API int rcw_timer_stop(rcw_handle* h, float* elapsed_ms);
 
+/* Per-kernel timing: while enabled, HIP events bracket the cast kernel and the fill kernel of
+ * each step (at most 256 steps are recorded).  rcw_profile_read returns their mean durations
+ * over the recorded steps. */
+RCW_API int rcw_profile(rcw_handle* h, int32_t enable);
+RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* fill_ms, int32_t* steps);
+
 /* Introspection */
 RCW_API int rcw_batch(rcw_handle* h, int32_t* out);
 RCW_API int rcw_get_config(rcw_handle* h, rcw_config* out);

@@ -18,7 +18,8 @@ at the repository root.
 from . import rlbase as RLBase
 from . import single_room as SingleRoomModule
 from .rlbase import RLBaseEnv
+from .sharded import ShardedSingleRoom, shard_range
 from .single_room import (act_, cast_rays_, get_action_names, reset_, update_camera_view_)
 
-__all__ = ["SingleRoomModule", "RLBase", "RLBaseEnv", "reset_", "act_", "cast_rays_",
+__all__ = ["SingleRoomModule", "RLBase", "RLBaseEnv", "ShardedSingleRoom", "shard_range", "reset_", "act_", "cast_rays_",
            "update_camera_view_", "get_action_names"]

@@ -103,6 +103,8 @@ SIGNATURES = {
     "rcw_direction_table": [_vp, _vp],
     "rcw_timer_start": [_vp],
     "rcw_timer_stop": [_vp, C.POINTER(C.c_float)],
+    "rcw_profile": [_vp, _i32],
+    "rcw_profile_read": [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)],
     "rcw_batch": [_vp, C.POINTER(_i32)],
     "rcw_get_config": [_vp, C.POINTER(RcwConfig)],
     "rcw_device_name": [_vp, C.c_char_p, _i32],

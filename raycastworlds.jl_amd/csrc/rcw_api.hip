@@ -55,11 +55,35 @@ struct rcw_handle {
     uint8_t* h_actions[2] = {nullptr, nullptr};   // pinned staging ring for rcw_step
     hipEvent_t ev_actions[2] = {nullptr, nullptr};
     int action_slot = 0;
+    bool profiling = false;
+    int prof_count = 0;
+    std::vector<hipEvent_t> prof_ev;   // 3 per recorded step
     std::vector<float> dir_table;   // (2, nd)
     std::vector<float> ray_table;   // (N, 5, nd)
 };
 
 namespace {
+
+constexpr int kProfileSlots = 256;
+
+// One step = cast kernel + fill kernel, back to back on the handle's stream.  With profiling on,
+// HIP events bracket each kernel (what bench.py's roofline block reads the fill kernel's
+// duration from).
+hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t* mask_dev)
+{
+    const RcwDev& d = h->dev;
+    const bool prof = h->profiling && h->prof_count < kProfileSlots;
+    hipError_t e;
+    if (prof && (e = hipEventRecord(h->prof_ev[3 * h->prof_count + 0], h->stream)) != hipSuccess) return e;
+    if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
+    if (prof && (e = hipEventRecord(h->prof_ev[3 * h->prof_count + 1], h->stream)) != hipSuccess) return e;
+    if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
+    if (prof) {
+        if ((e = hipEventRecord(h->prof_ev[3 * h->prof_count + 2], h->stream)) != hipSuccess) return e;
+        h->prof_count++;
+    }
+    return hipSuccess;
+}
 
 void free_all(rcw_handle* h)
 {
@@ -79,6 +103,8 @@ void free_all(rcw_handle* h)
         h->h_actions[k] = nullptr;
         h->ev_actions[k] = nullptr;
     }
+    for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
+    h->prof_ev.clear();
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -397,7 +423,7 @@ int rcw_set_direction_table(rcw_handle* h, const float* directions_wu)
     h->dir_table.assign(directions_wu, directions_wu + (size_t)2 * h->cfg.num_directions);
     build_ray_table(h->cfg, h->dir_table, h->ray_table);
     rc = upload_tables(h); if (rc) return rc;
-    RCW_HIP(rcw_launch_step(h->dev, nullptr, nullptr, h->stream));   // re-render
+    RCW_HIP(launch_step(h, nullptr, nullptr));   // re-render
     return RCW_OK;
 }
 
@@ -426,7 +452,7 @@ int rcw_reset(rcw_handle* h, const uint8_t* mask_host, uint64_t seed)
     rc = upload_mask(h, mask_host, &mask_dev); if (rc) return rc;
     h->dev.seed = seed;
     RCW_HIP(rcw_launch_reset(h->dev, mask_dev, h->stream));            // SR:110-132
-    RCW_HIP(rcw_launch_step(h->dev, nullptr, mask_dev, h->stream));    // SR:134, SR:329
+    RCW_HIP(launch_step(h, nullptr, mask_dev));    // SR:134, SR:329
     return RCW_OK;
 }
 
@@ -456,7 +482,7 @@ int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_w
     RCW_HIP(hipStreamSynchronize(h->stream));
     RCW_HIP(rcw_launch_set_state(h->dev, (const int2*)h->d_in_goal, (const float2*)h->d_in_pos,
                                  (const int32_t*)h->d_in_dir, mask_dev, h->stream));
-    RCW_HIP(rcw_launch_step(h->dev, nullptr, mask_dev, h->stream));
+    RCW_HIP(launch_step(h, nullptr, mask_dev));
     return RCW_OK;
 }
 
@@ -476,7 +502,7 @@ int rcw_step(rcw_handle* h, const uint8_t* actions_host)
     std::memcpy(h->h_actions[slot], actions_host, (size_t)h->B);
     RCW_HIP(hipMemcpyAsync(h->d_actions, h->h_actions[slot], (size_t)h->B, hipMemcpyHostToDevice, h->stream));
     RCW_HIP(hipEventRecord(h->ev_actions[slot], h->stream));
-    RCW_HIP(rcw_launch_step(h->dev, (const uint8_t*)h->d_actions, nullptr, h->stream));
+    RCW_HIP(launch_step(h, (const uint8_t*)h->d_actions, nullptr));
     return RCW_OK;
 }
 
@@ -484,7 +510,7 @@ int rcw_step_device(rcw_handle* h, const uint8_t* actions_device)
 {
     int rc = check_handle(h); if (rc) return rc;
     if (!actions_device) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL actions");
-    RCW_HIP(rcw_launch_step(h->dev, actions_device, nullptr, h->stream));
+    RCW_HIP(launch_step(h, actions_device, nullptr));
     return RCW_OK;
 }
 
@@ -645,6 +671,37 @@ int rcw_timer_stop(rcw_handle* h, float* elapsed_ms)
     RCW_HIP(hipEventRecord(h->ev_stop, h->stream));
     RCW_HIP(hipEventSynchronize(h->ev_stop));
     RCW_HIP(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+    return RCW_OK;
+}
+
+int rcw_profile(rcw_handle* h, int32_t enable)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    if (enable && h->prof_ev.empty()) {
+        h->prof_ev.resize(3 * kProfileSlots, nullptr);
+        for (auto& ev : h->prof_ev) RCW_HIP(hipEventCreate(&ev));
+    }
+    h->profiling = enable != 0;
+    h->prof_count = 0;
+    return RCW_OK;
+}
+
+int rcw_profile_read(rcw_handle* h, float* cast_ms, float* fill_ms, int32_t* steps)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!cast_ms || !fill_ms || !steps) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    double c = 0.0, f = 0.0;
+    for (int k = 0; k < h->prof_count; ++k) {
+        float a = 0.0f, b = 0.0f;
+        RCW_HIP(hipEventElapsedTime(&a, h->prof_ev[3 * k], h->prof_ev[3 * k + 1]));
+        RCW_HIP(hipEventElapsedTime(&b, h->prof_ev[3 * k + 1], h->prof_ev[3 * k + 2]));
+        c += a; f += b;
+    }
+    *steps = h->prof_count;
+    *cast_ms = h->prof_count ? (float)(c / h->prof_count) : 0.0f;
+    *fill_ms = h->prof_count ? (float)(f / h->prof_count) : 0.0f;
     return RCW_OK;
 }
 

@@ -57,10 +57,13 @@ struct RcwRayOut {           // rcw_rays(): SR:29-31,39 for agents [first, first
 
 size_t rcw_step_lds_bytes(const RcwDev& p);
 
-// act!(env, a): cast kernel (dynamics + rays + projection) then fill kernel (pixels).
-// actions == nullptr: render only (used after reset / set_state); mask == nullptr: all.
-hipError_t rcw_launch_step(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
+// act!(env, a) = cast kernel (dynamics + rays + projection -> column descriptors) followed by
+// the fill kernel (descriptors -> pixels).  actions == nullptr: render only (after reset /
+// set_state); mask == nullptr: all agents.
+hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s);
+hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
+                           long long total_cols, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const float2* pos,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);

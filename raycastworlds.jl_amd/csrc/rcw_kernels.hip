@@ -129,35 +129,47 @@ __device__ __forceinline__ Pose reset_agent(const RcwDev& p, int a, uint32_t* tm
 // ---- RayCaster.cast_ray  (external; call site SR:223).  UNPINNED choices via p.tie_le /
 // p.dist_pre (include/rcw.h).  Leaves the map -> oob (Julia: BoundsError). ------------------
 struct RayHit { int i, j, dim; float dist; uint32_t bits; bool oob; };
+// The march is written with selects, not branches: lanes of a wavefront disagree on the step
+// axis at almost every iteration, and a divergent if/else costs more in exec-mask bookkeeping
+// than the few extra v_cndmask.  The only divergence left is the trip count (lanes that have
+// hit wait for the longest ray of the wavefront).
+template <bool TIE_LE, bool DIST_PRE>
 __device__ __forceinline__ RayHit cast_ray(const uint32_t* tm, int H, int W, float x, float y,
-                                           float dx, float dy, float ddx, float ddy, int tie_le,
-                                           int dist_pre)
+                                           float dx, float dy, float ddx, float ddy)
 {
-    int i = (int)floorf(x) + 1;
+    int i = (int)floorf(x) + 1;           // wu_to_tu UT:5
     int j = (int)floorf(y) + 1;
-    int si, sj;
-    float sx, sy;
-    if (dx < 0.0f) { si = -1; sx = (x - (float)(i - 1)) * ddx; }
-    else           { si = +1; sx = ((float)i - x) * ddx; }
-    if (dy < 0.0f) { sj = -1; sy = (y - (float)(j - 1)) * ddy; }
-    else           { sj = +1; sy = ((float)j - y) * ddy; }
+    const bool neg_x = dx < 0.0f, neg_y = dy < 0.0f;
+    const int si = neg_x ? -1 : 1, sj = neg_y ? -1 : 1;
+    const float fx = neg_x ? x - (float)(i - 1) : (float)i - x;
+    const float fy = neg_y ? y - (float)(j - 1) : (float)j - y;
+    float sx = fx * ddx, sy = fy * ddy;
+    int t = (i - 1) + H * (j - 1);        // linear tile index, kept incrementally
+    const int tj = sj * H;
     RayHit r;
     r.dim = 0; r.dist = 0.0f; r.bits = 0u; r.oob = false;
-    int t = (i - 1) + H * (j - 1);          // linear tile index, kept incrementally
-    const int tj = sj * H;
     // Every iteration moves one tile in a fixed direction, so the loop leaves the map (and
     // exits) after at most H + W steps even on a map without a closed wall ring.
     for (;;) {
-        if ((unsigned)(i - 1) >= (unsigned)H || (unsigned)(j - 1) >= (unsigned)W) { r.oob = true; break; }
-        r.bits = (tm[t >> 4] >> ((t & 15) * 2)) & 3u;
-        if (r.bits) break;
-        const bool x_first = tie_le ? (sx <= sy) : (sx < sy);
-        if (x_first) { r.dist = sx; sx = sx + ddx; i += si; t += si; r.dim = 1; }
-        else         { r.dist = sy; sy = sy + ddy; j += sj; t += tj; r.dim = 2; }
+        const bool inb = (unsigned)(i - 1) < (unsigned)H && (unsigned)(j - 1) < (unsigned)W;
+        const int ts = inb ? t : 0;
+        r.bits = inb ? (tm[ts >> 4] >> ((ts & 15) * 2)) & 3u : 0u;
+        r.oob = !inb;
+        if (r.bits != 0u || !inb) break;
+        const bool xf = TIE_LE ? (sx <= sy) : (sx < sy);
+        const float side = xf ? sx : sy;
+        const float next = side + (xf ? ddx : ddy);
+        r.dist = side;
+        sx = xf ? next : sx;
+        sy = xf ? sy : next;
+        i += xf ? si : 0;
+        j += xf ? 0 : sj;
+        t += xf ? si : tj;
+        r.dim = xf ? 1 : 2;
     }
-    if (!dist_pre) {
-        if (r.dim == 1) r.dist = sx - ddx;
-        else if (r.dim == 2) r.dist = sy - ddy;
+    if (!DIST_PRE) {
+        const float d1 = sx - ddx, d2 = sy - ddy;
+        r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : 0.0f);
     }
     r.i = i; r.j = j;
     return r;
@@ -169,11 +181,11 @@ __device__ __forceinline__ int height_line_pu(const RcwDev& p, float dist, float
     const float projected = dist * dot;               // SR:404
     const float den = p.two_fov * projected;          // (2 * fov) * projected
     const float height_line = p.num / den;            // SR:406
-    if (!isfinite(height_line)) return p.Hc;          // SR:410
-    const float f = floorf(height_line);              // floor(Int, .) SR:408, saturated
-    if (f >= 2147483648.0f) return INT_MAX;
-    if (f <= -2147483648.0f) return INT_MIN;
-    return (int)f;
+    const float f = floorf(height_line);              // floor(Int, .) SR:408, saturated to Int32
+    const float fc = fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);
+    int h = (int)fc;
+    h = f >= 2147483648.0f ? INT_MAX : h;
+    return isfinite(height_line) ? h : p.Hc;          // SR:407-411
 }
 __device__ __forceinline__ int column_padding(int Hc, int h)
 {
@@ -192,7 +204,8 @@ __device__ __forceinline__ uint32_t pixel(int r, int pad, int Hc, uint32_t colou
 // One workgroup per agent.  Output: the agent's new state and one compact descriptor per
 // image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
 // of pixels the fill kernel then writes for it.
-template <int DEV>   // development ablation bits: 1 skip DDA, 2 skip stores, 4 skip dynamics, 8 skip table loads
+// TIE_LE / DIST_PRE: the UNPINNED cast_ray choices (include/rcw.h), compiled in.
+template <bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
                                                           const uint8_t* __restrict__ actions,
                                                           const uint8_t* __restrict__ mask)
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         __syncthreads();
         x = s_pose[0]; y = s_pose[1];
         d_new = __float_as_int(s_pose[2]);
-    } else if (act != 0 && !(DEV & 4)) {
+    } else if (act != 0) {
         float reward = 0.0f;
         int done = 0;
         bool oob = false;
@@ -266,25 +279,17 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     // ---- phase 1: one lane per view column --------------------------------------------------
     const float* tab = p.ray_table + (size_t)d_new * RCW_TABLE_ROWS * p.N;
     for (int i = tid; i < p.N; i += (int)blockDim.x) {                        // SR:220, SR:401
-        float dx, dy, ddx, ddy, dot;
-        if (DEV & 8) { dx = 0.6f + i * 1e-3f; dy = 0.5f; ddx = 1.0f / dx; ddy = 2.0f; dot = 0.9f; }
-        else {
-        dx = tab[i]; dy = tab[p.N + i];
-        ddx = tab[2 * p.N + i]; ddy = tab[3 * p.N + i];
-        dot = tab[4 * p.N + i];
-        }
-        RayHit r;
-        if (DEV & 1) { r.i = 8; r.j = 3; r.dim = 1; r.dist = 2.0f + dx; r.bits = 1; r.oob = false; }
-        else r = cast_ray(tm, p.H, p.W, x, y, dx, dy, ddx, ddy, p.tie_le, p.dist_pre);
+        const float dx = tab[i], dy = tab[p.N + i];
+        const float ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
+        const float dot = tab[4 * p.N + i];
+        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tm, p.H, p.W, x, y, dx, dy, ddx, ddy);
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
         const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);
         const int k = p.N - 1 - i;                                          // SR:431 (0-based)
-        if (!(DEV & 2) || h == 123456789) {
         p.col_h[(size_t)a * p.N + k] = h;
         p.col_c[(size_t)a * p.N + k] = (uint8_t)cid;
-        }
     }
 }
 
@@ -421,6 +426,7 @@ __global__ void rcw_set_state_kernel(const RcwDev p, const int2* __restrict__ go
 }
 
 // cast_rays!(world) SR:195-231 with the ray buffers materialised (rcw_rays)
+template <bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int first, RcwRayOut out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -436,8 +442,8 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
     const float* tab = p.ray_table + (size_t)d * RCW_TABLE_ROWS * p.N;
     for (int i = tid; i < p.N; i += kBlock) {
         const float dx = tab[i], dy = tab[p.N + i];
-        const RayHit r = cast_ray(tm, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
-                                  tab[3 * p.N + i], p.tie_le, p.dist_pre);
+        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tm, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+                                                    tab[3 * p.N + i]);
         const size_t q = (size_t)local * p.N + i;
         if (out.stop_ij) { out.stop_ij[2 * q] = r.oob ? 1 : r.i; out.stop_ij[2 * q + 1] = r.oob ? 1 : r.j; }
         if (out.hit_dim) out.hit_dim[q] = r.oob ? 0 : r.dim;
@@ -475,20 +481,19 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     return hipGetLastError();
 }
 
-hipError_t rcw_launch_step(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
+hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s)
 {
-    static const int mode = [] { const char* v = getenv("RCW_STEP_MODE"); return v ? atoi(v) : 0; }();   // dev knob
-    if (mode != 2)
-    {
-        static const int dev = [] { const char* v = getenv("RCW_CAST_DEV"); return v ? atoi(v) : 0; }();
-#define RCW_CAST_CASE(D) case D: hipLaunchKernelGGL(rcw_cast_kernel<D>, dim3(p.B), dim3(p.cast_block), rcw_step_lds_bytes(p), s, p, actions_dev, mask_dev); break;
-        switch (dev) { RCW_CAST_CASE(1) RCW_CAST_CASE(2) RCW_CAST_CASE(3) RCW_CAST_CASE(4) RCW_CAST_CASE(7) RCW_CAST_CASE(8) RCW_CAST_CASE(15) default: RCW_CAST_CASE(0) }
+    const dim3 grid(p.B), block(p.cast_block);
+    const size_t lds = rcw_step_lds_bytes(p);
+    if (p.tie_le) {
+        if (p.dist_pre) hipLaunchKernelGGL((rcw_cast_kernel<true, true>), grid, block, lds, s, p, actions_dev, mask_dev);
+        else            hipLaunchKernelGGL((rcw_cast_kernel<true, false>), grid, block, lds, s, p, actions_dev, mask_dev);
+    } else {
+        if (p.dist_pre) hipLaunchKernelGGL((rcw_cast_kernel<false, true>), grid, block, lds, s, p, actions_dev, mask_dev);
+        else            hipLaunchKernelGGL((rcw_cast_kernel<false, false>), grid, block, lds, s, p, actions_dev, mask_dev);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (mode == 1) return e;
-    return rcw_launch_fill(p, p.col_h, p.col_c, p.obs, (long long)p.B * p.N, mask_dev, s);
+    return hipGetLastError();
 }
 
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
@@ -512,7 +517,14 @@ hipError_t rcw_launch_init_tile_map(const RcwDev& p, hipStream_t s)
 
 hipError_t rcw_launch_rays(const RcwDev& p, int32_t first, int32_t count, RcwRayOut out, hipStream_t s)
 {
-    hipLaunchKernelGGL(rcw_rays_kernel, dim3(count), dim3(kBlock), rcw_step_lds_bytes(p), s, p, first, out);
+    const size_t lds = rcw_step_lds_bytes(p);
+    if (p.tie_le) {
+        if (p.dist_pre) hipLaunchKernelGGL((rcw_rays_kernel<true, true>), dim3(count), dim3(kBlock), lds, s, p, first, out);
+        else            hipLaunchKernelGGL((rcw_rays_kernel<true, false>), dim3(count), dim3(kBlock), lds, s, p, first, out);
+    } else {
+        if (p.dist_pre) hipLaunchKernelGGL((rcw_rays_kernel<false, true>), dim3(count), dim3(kBlock), lds, s, p, first, out);
+        else            hipLaunchKernelGGL((rcw_rays_kernel<false, false>), dim3(count), dim3(kBlock), lds, s, p, first, out);
+    }
     return hipGetLastError();
 }
 

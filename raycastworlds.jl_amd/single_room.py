@@ -166,11 +166,7 @@ class SingleRoomWorld:
     def tile_map(self) -> np.ndarray:
         """bool (B, 2, H, W): tile_map[b, o-1, i-1, j-1] == Julia tile_map[o, i, j] of agent b."""
         env = self._env
-        H, W = env.cfg.height_tile_map_tu, env.cfg.width_tile_map_tu
-        chunks = self.tile_map_chunks
-        bits = np.unpackbits(chunks.view(np.uint8), axis=1, bitorder="little")[:, : 2 * H * W]
-        # linear bit index = (o-1) + 2(i-1) + 2H(j-1)  ->  C-order axes (j, i, o)
-        return bits.reshape(env.batch, W, H, 2).transpose(0, 3, 2, 1).astype(bool)
+        return unpack_tile_map(self.tile_map_chunks, env.cfg.height_tile_map_tu, env.cfg.width_tile_map_tu)
 
     def rays(self, first: int = 0, count: Optional[int] = None):
         """(ray_stop_position_tu (n, N, 2) int64, ray_hit_dimension (n, N) int64,
@@ -323,6 +319,26 @@ class SingleRoom:
         return (DeviceArray(hp.value, shape, np.int32, self, self._sync),
                 DeviceArray(cp.value, shape, np.uint8, self, self._sync))
 
+    def expand_columns(self, height_line_pu, colour_id):
+        """Descriptors (CUDA tensors (n, N) int32 / uint8, e.g. gathered from other GPUs) ->
+        frames (n, N, H_cam) as a torch CUDA tensor, with this engine's colours (rcw_expand_columns)."""
+        import torch
+
+        n = int(height_line_pu.shape[0])
+        if tuple(height_line_pu.shape) != (n, self.cfg.num_rays) or tuple(colour_id.shape) != (n, self.cfg.num_rays):
+            raise ValueError("descriptor shape must be (n, num_rays)")
+        if height_line_pu.dtype != torch.int32 or colour_id.dtype != torch.uint8:
+            raise ValueError("descriptors must be int32 / uint8")
+        h = height_line_pu.contiguous()
+        c = colour_id.contiguous()
+        out = torch.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=torch.uint32,
+                          device=f"cuda:{self.device}")
+        torch.cuda.current_stream(self.device).synchronize()   # inputs may come from another stream
+        _capi.check(self._lib.rcw_expand_columns(self._h, C.c_void_p(h.data_ptr()), C.c_void_p(c.data_ptr()), n,
+                                                 C.c_void_p(out.data_ptr())))
+        self._sync()
+        return out
+
     def reward_device(self) -> DeviceArray:
         p = C.c_void_p()
         _capi.check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
@@ -365,6 +381,16 @@ class SingleRoom:
     def clear_error(self):
         _capi.check(self._lib.rcw_clear_error(self._h))
 
+    def profile(self, enable: bool):
+        """Bracket the cast and fill kernels of every step with HIP events (<= 256 steps)."""
+        _capi.check(self._lib.rcw_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(mean cast kernel ms, mean fill kernel ms, steps recorded)."""
+        c, f, n = C.c_float(), C.c_float(), C.c_int32()
+        _capi.check(self._lib.rcw_profile_read(self._h, C.byref(c), C.byref(f), C.byref(n)))
+        return float(c.value), float(f.value), int(n.value)
+
     def timer_start(self):
         _capi.check(self._lib.rcw_timer_start(self._h))
 
@@ -382,6 +408,31 @@ def reset_(env: SingleRoom, mask=None, seed: Optional[int] = None) -> None:
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(env.batch)
     _capi.check(env._lib.rcw_reset(env._h, _as_ptr(m), env.seed))
     return None
+
+
+def host_actions(batch: int, action) -> np.ndarray:
+    """Normalise host-side actions to a contiguous uint8 (batch,) array; anything outside 1..4
+    raises AssertionError like `@assert action in Base.OneTo(NUM_ACTIONS)` (SR:140)."""
+    if np.isscalar(action):
+        a = np.full(batch, action)
+    else:
+        a = np.asarray(action).reshape(-1)
+        if a.size != batch:
+            raise ValueError(f"expected {batch} actions, got {a.size}")
+    ok = (a >= 1) & (a <= NUM_ACTIONS)
+    if a.dtype.kind == "f":
+        ok &= a == np.floor(a)
+    if not np.all(ok):
+        raise AssertionError(f"Invalid action: {a[~ok][0]}")
+    return np.ascontiguousarray(a.astype(np.uint8, copy=False))
+
+
+def unpack_tile_map(chunks: np.ndarray, H: int, W: int) -> np.ndarray:
+    """BitArray{3}(2, H, W).chunks per agent (uint64 (B, nchunks)) -> bool (B, 2, H, W) with
+    tile_map[b, o-1, i-1, j-1] == Julia tile_map[o, i, j]; bit index (o-1) + 2(i-1) + 2H(j-1)."""
+    chunks = np.ascontiguousarray(chunks, dtype=np.uint64)
+    bits = np.unpackbits(chunks.view(np.uint8), axis=1, bitorder="little")[:, : 2 * H * W]
+    return bits.reshape(chunks.shape[0], W, H, 2).transpose(0, 3, 2, 1).astype(bool)
 
 
 def _is_device_tensor(x) -> bool:
@@ -405,18 +456,7 @@ def act_(env: SingleRoom, action) -> None:
                 raise ValueError("device actions must be a contiguous uint8 tensor of length batch")
             _capi.check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
             return None
-    if np.isscalar(action):
-        a = np.full(env.batch, action)
-    else:
-        a = np.asarray(action).reshape(-1)
-        if a.size != env.batch:
-            raise ValueError(f"expected {env.batch} actions, got {a.size}")
-    if a.dtype != np.uint8:
-        if not np.all((a >= 1) & (a <= NUM_ACTIONS)) or not np.all(a == np.floor(a)):
-            bad = a[~((a >= 1) & (a <= NUM_ACTIONS))]
-            raise AssertionError(f"Invalid action: {bad[0] if bad.size else a[0]}")
-        a = a.astype(np.uint8)
-    a = np.ascontiguousarray(a)
+    a = host_actions(env.batch, action)
     _capi.check(env._lib.rcw_step(env._h, _as_ptr(a)))
     return None
 

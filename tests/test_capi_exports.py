@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports every symbol include/rcw.h declares; without a GPU it
+fails loudly instead of falling back to anything.  CPU only — no compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rcw.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"RCW_API\s+[\w\s\*]+?\b(rcw_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = _declared()
+    for must in ("rcw_create", "rcw_destroy", "rcw_reset", "rcw_set_state", "rcw_step", "rcw_step_device",
+                 "rcw_obs_device_ptr", "rcw_reward", "rcw_done", "rcw_tile_map_chunks", "rcw_rays",
+                 "rcw_columns", "rcw_expand_columns", "rcw_last_error"):
+        assert must in names
+    assert len(names) >= 35
+
+
+def test_library_exports_every_declared_symbol(rcw):
+    from raycastworlds_jl_amd import _capi
+
+    lib = C.CDLL(_capi.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(lib, n)]
+    assert not missing, f"declared in rcw.h but not exported: {missing}"
+    # and the Python binding binds exactly that set
+    assert sorted(_capi.SIGNATURES) == _declared()
+
+
+def test_config_struct_matches_header(rcw, oracle):
+    from raycastworlds_jl_amd import _capi
+
+    cfg = _capi.default_config()          # rcw_config_default: host-only, no device touched
+    assert C.sizeof(_capi.RcwConfig) == C.sizeof(oracle.RcwConfig) == 128
+    ref = oracle.default_config()
+    for name, _ in _capi.RcwConfig._fields_:
+        if name == "reserved":
+            continue
+        assert getattr(cfg, name) == getattr(ref, name), name
+    # reference defaults SR:258-272, SR:288-296
+    assert (cfg.height_tile_map_tu, cfg.width_tile_map_tu, cfg.num_directions, cfg.num_rays,
+            cfg.height_camera_view_pu, cfg.pu_per_tu) == (8, 16, 128, 512, 256, 32)
+    assert cfg.player_radius_wu == 0.125 and cfg.position_increment_wu == 0.125
+    assert (cfg.floor_color, cfg.ceiling_color, cfg.wall_dim_1_color, cfg.wall_dim_2_color,
+            cfg.goal_dim_1_color, cfg.goal_dim_2_color) == (0x404040, 0xFFFFFF, 0x808080, 0xC0C0C0, 0x800000, 0xC00000)
+
+
+def test_no_cpu_fallback(rcw):
+    """On a machine without a gfx950 device construction fails loudly (RCW_ERR_NO_DEVICE)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from raycastworlds_jl_amd import _capi
+
+    with pytest.raises(_capi.RcwError) as ei:
+        rcw.SingleRoomModule.SingleRoom(batch=2)
+    assert ei.value.code == _capi.RCW_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    """The product package must not reference oracle/ (it is the checker, not a fallback)."""
+    pkg = os.path.join(ROOT, "raycastworlds.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle" not in text.lower(), (dirpath, fn)

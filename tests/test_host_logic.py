@@ -1,0 +1,83 @@
+"""Host-side logic of the Python mirror that needs no GPU."""
+import numpy as np
+import pytest
+
+
+def test_host_actions_mirror_the_assert(rcw):
+    from raycastworlds_jl_amd.single_room import host_actions
+
+    np.testing.assert_array_equal(host_actions(4, 3), np.full(4, 3, np.uint8))
+    np.testing.assert_array_equal(host_actions(3, [1, 2, 4]), np.array([1, 2, 4], np.uint8))
+    np.testing.assert_array_equal(host_actions(2, np.array([1.0, 4.0])), np.array([1, 4], np.uint8))
+    for bad in (0, 5, -1, [1, 2, 0], np.array([1.5, 2.0]), np.array([1, 9], dtype=np.uint8)):
+        n = 1 if np.isscalar(bad) else len(bad)
+        with pytest.raises(AssertionError, match="Invalid action"):
+            host_actions(n, bad)
+    with pytest.raises(ValueError):
+        host_actions(3, [1, 2])
+
+
+def test_unpack_tile_map_is_julia_bitarray_layout(rcw, oracle):
+    from raycastworlds_jl_amd.single_room import unpack_tile_map
+
+    orc = oracle.OracleBatch(3, seed=5, height_tile_map_tu=8, width_tile_map_tu=16, num_rays=8)
+    tm = unpack_tile_map(orc.tile_map_chunks(), 8, 16)
+    assert tm.shape == (3, 2, 8, 16)
+    for b in range(3):
+        wall, goal = tm[b, 0], tm[b, 1]
+        assert wall[0, :].all() and wall[-1, :].all() and wall[:, 0].all() and wall[:, -1].all()
+        assert wall.sum() == 2 * 8 + 2 * 16 - 4
+        gi, gj = orc.goal[b]
+        assert goal.sum() == 1 and goal[gi - 1, gj - 1]
+        assert 2 <= gi <= 7 and 2 <= gj <= 15
+
+
+def test_action_names_and_spaces(rcw):
+    assert rcw.get_action_names(None) == ("MOVE_FORWARD", "MOVE_BACKWARD", "TURN_LEFT", "TURN_RIGHT")
+    assert list(rcw.RLBase.action_space(None)) == [1, 2, 3, 4]
+    assert rcw.RLBase.state_space(None) is None
+    assert rcw.SingleRoomModule.NUM_ACTIONS == 4 and rcw.SingleRoomModule.WALL == 1 and rcw.SingleRoomModule.GOAL == 2
+
+
+def test_shard_range(rcw):
+    assert rcw.shard_range(65536, 8, 0) == (0, 8192)
+    assert rcw.shard_range(65536, 8, 7) == (57344, 8192)
+    assert rcw.shard_range(8, 1, 0) == (0, 8)
+    covered = []
+    for r in range(4):
+        f, c = rcw.shard_range(4096, 4, r)
+        covered += list(range(f, f + c))
+    assert covered == list(range(4096))
+    with pytest.raises(ValueError):
+        rcw.shard_range(10, 4, 0)
+    with pytest.raises(ValueError):
+        rcw.shard_range(8, 2, 2)
+
+
+def test_reset_generator_is_sharding_invariant(oracle):
+    """The reset stream is keyed by GLOBAL agent id: a batch of 8 equals two shards of 4."""
+    kw = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=16)
+    whole = oracle.OracleBatch(8, seed=42, **kw)
+    lo = oracle.OracleBatch(4, seed=42, agent_id_offset=0, **kw)
+    hi = oracle.OracleBatch(4, seed=42, agent_id_offset=4, **kw)
+    np.testing.assert_array_equal(whole.goal, np.concatenate([lo.goal, hi.goal]))
+    np.testing.assert_array_equal(whole.position, np.concatenate([lo.position, hi.position]))
+    np.testing.assert_array_equal(whole.direction, np.concatenate([lo.direction, hi.direction]))
+    assert len({tuple(g) for g in whole.goal} | {tuple(p) for p in whole.position}) > 4   # not all equal
+
+
+def test_reset_distributions(oracle):
+    """Same distributions as reset!(world) SR:110-137: goal on interior tiles, player at the
+    centre of an empty tile, heading on 0..nd-1."""
+    orc = oracle.OracleBatch(4096, seed=1, render=False, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=4)
+    g, p, d = orc.goal, orc.position, orc.direction
+    assert g.min() >= 2 and g.max() <= 7
+    assert ((p - 0.5) == np.floor(p - 0.5)).all()
+    tile = (p + 0.5).astype(int)
+    assert tile.min() >= 2 and tile.max() <= 7                   # never on the wall ring
+    assert not (tile == g).all(axis=1).any()                     # never on the goal tile
+    assert d.min() >= 0 and d.max() <= 127
+    # roughly uniform: each of the 36 interior goal tiles gets 4096/36 = 114 +- 5 sigma
+    counts = np.bincount((g[:, 0] - 2) * 6 + (g[:, 1] - 2), minlength=36)
+    assert counts.min() > 60 and counts.max() < 170
+    assert len(np.unique(d)) == 128

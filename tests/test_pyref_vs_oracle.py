@@ -1,0 +1,64 @@
+"""Two independent restatements of the reference (C: oracle/rcw_oracle.c, Python:
+oracle/pyref.py) must agree bit for bit.  CPU only, small cases."""
+import numpy as np
+import pytest
+
+from oracle import pyref
+
+
+def _compare(orc, w, where):
+    np.testing.assert_array_equal(orc.position[0], np.array(w.pos, dtype=np.float32), err_msg=where)
+    assert orc.direction[0] == w.dir, where
+    assert orc.reward[0] == w.reward and bool(orc.done[0]) == w.done, where
+    np.testing.assert_array_equal(orc.col_height[0], np.array(w.col_height, dtype=np.int32), err_msg=where)
+    np.testing.assert_array_equal(orc.col_colour[0], np.array(w.col_colour, dtype=np.uint8), err_msg=where)
+    np.testing.assert_array_equal(orc.camera_view[0], w.camera_view, err_msg=where)
+    hits = np.array([(h[0], h[1]) for h in w.ray_hits], dtype=np.int64)
+    np.testing.assert_array_equal(orc.ray_stop[0], hits, err_msg=where)
+    np.testing.assert_array_equal(orc.ray_dim[0], np.array([h[2] for h in w.ray_hits], dtype=np.int64), err_msg=where)
+    dist = np.array([h[3] for h in w.ray_hits], dtype=np.float32)
+    np.testing.assert_array_equal(orc.ray_dist[0].view(np.uint32), dist.view(np.uint32), err_msg=where)
+    dirs = np.array(w.ray_dirs, dtype=np.float32)
+    np.testing.assert_array_equal(orc.ray_dirs[0].view(np.uint32), dirs.view(np.uint32), err_msg=where)
+
+
+@pytest.mark.parametrize("H,W,N,steps,variant", [
+    (8, 8, 64, 60, (0, 0, 0)),
+    (8, 16, 48, 40, (0, 0, 0)),
+    (16, 16, 33, 30, (0, 0, 0)),
+    (8, 8, 32, 30, (1, 0, 0)),
+    (8, 8, 32, 30, (0, 1, 0)),
+    (8, 8, 32, 30, (0, 0, 1)),
+    (8, 8, 1, 10, (0, 0, 0)),       # LinRange of length 1: lendiv = max(len-1, 1)
+])
+def test_rollout_bit_exact(oracle, H, W, N, steps, variant):
+    tie, dist, norm = variant
+    orc = oracle.OracleBatch(1, seed=H * 1000 + N, height_tile_map_tu=H, width_tile_map_tu=W, num_rays=N,
+                             dda_tie_break=tie, dda_distance=dist, normalize_mode=norm, out_of_bounds=0)
+    w = pyref.World(H=H, W=W, num_rays=N, tie_le=bool(tie), dist_pre=bool(dist), normalize_divide=bool(norm))
+    np.testing.assert_array_equal(orc.directions, np.array(w.directions, dtype=np.float32))
+    w.set_state(orc.goal[0], orc.position[0], orc.direction[0])
+    _compare(orc, w, "after set_state")
+    rng = np.random.default_rng(N)
+    for s in range(steps):
+        a = int(rng.integers(1, 5))
+        try:
+            w.step(a)
+        except IndexError:
+            # the reference's BoundsError: the oracle flags the agent and leaves it untouched
+            orc.step([a])
+            assert orc.status[0] == -5
+            orc.clear_status()
+            w.cast_rays(); w.update_camera_view()
+            continue
+        assert orc.step([a]) == 0
+        _compare(orc, w, f"step {s} action {a}")
+
+
+def test_all_headings_ray_fan(oracle):
+    cfg = oracle.default_config(num_rays=17)
+    w = pyref.World(num_rays=17)
+    for d in range(128):
+        w.dir = d
+        fan = oracle.ray_fan(cfg, oracle.direction_table(128)[d])
+        np.testing.assert_array_equal(fan.view(np.uint32), np.array(w.ray_fan(), dtype=np.float32).view(np.uint32))

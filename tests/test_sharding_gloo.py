@@ -1,0 +1,113 @@
+"""N > 1 path on CPU: two ranks over gloo.  The host-side sharding logic
+(raycastworlds.jl_amd/sharded.py) runs for real; the engine underneath is swapped for a test
+double backed by the CPU oracle (injected through `env_factory` — the product default is the
+HIP engine and has no CPU fallback)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+CFG = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=32)
+GLOBAL_B = 12
+STEPS = 25
+
+
+class OracleEngine:
+    """Test double with the slice of the SingleRoom interface ShardedSingleRoom uses."""
+
+    def __init__(self, batch, agent_id_offset, device, seed=0, **kw):
+        from oracle import oracle as O
+
+        self.o = O.OracleBatch(batch, seed=seed, agent_id_offset=agent_id_offset, out_of_bounds=1, **kw)
+        self.batch = batch
+
+    def columns_device(self):
+        return torch.from_numpy(self.o.col_height.copy()), torch.from_numpy(self.o.col_colour.copy())
+
+    @property
+    def camera_view(self):
+        return torch.from_numpy(self.o.camera_view.astype(np.int64))
+
+    def expand_columns(self, h, c):
+        colours = np.array([0x808080, 0xC0C0C0, 0x800000, 0xC00000], dtype=np.int64)
+        h, c = h.numpy().astype(np.int64), c.numpy()
+        Hc = 256
+        pad = np.where(h >= Hc - 1, 0, (Hc - h) // 2)[..., None]
+        rows = np.arange(Hc)[None, None, :]
+        col = colours[c][..., None]
+        return torch.from_numpy(np.where(rows < pad, 0xFFFFFF, np.where(rows < Hc - pad, col, 0x404040)))
+
+    def close(self):
+        self.o.close()
+
+
+def _patch_act():
+    # route the module-level act_/reset_ used by ShardedSingleRoom to the test double
+    from raycastworlds_jl_amd import single_room
+
+    single_room.act_ = lambda env, a: env.o.step(np.asarray(a, dtype=np.uint8))
+    single_room.reset_ = lambda env, mask=None, seed=None: env.o.reset(mask, 0 if seed is None else seed)
+
+
+def _worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import raycastworlds_jl_amd as RCW
+
+        _patch_act()
+        sh = RCW.ShardedSingleRoom(GLOBAL_B, env_factory=OracleEngine, seed=77, **CFG)
+        assert (sh.first, sh.count) == (rank * GLOBAL_B // world, GLOBAL_B // world)
+        rng = np.random.default_rng(5)
+        actions = rng.integers(1, 5, (STEPS, GLOBAL_B)).astype(np.uint8)
+        for s in range(STEPS):
+            sh.act_(sh.local_slice(actions[s]))
+        gh, gc = sh.gather_columns()
+        frames_c = sh.gather_observations("columns")
+        frames_f = sh.gather_observations("frames")
+        sh.reset_(seed=5)
+        gh2, _ = sh.gather_columns()
+        q.put((rank, gh.numpy(), gc.numpy(), frames_c.numpy(), frames_f.numpy(), gh2.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_unsharded_batch(oracle):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the unsharded truth
+    ref = oracle.OracleBatch(GLOBAL_B, seed=77, out_of_bounds=1, **CFG)
+    rng = np.random.default_rng(5)
+    actions = rng.integers(1, 5, (STEPS, GLOBAL_B)).astype(np.uint8)
+    for s in range(STEPS):
+        ref.step(actions[s])
+    for rank, gh, gc, frames_c, frames_f, gh2 in results:
+        np.testing.assert_array_equal(gh, ref.col_height, err_msg=f"rank {rank} gathered heights")
+        np.testing.assert_array_equal(gc, ref.col_colour)
+        np.testing.assert_array_equal(frames_c.astype(np.uint32), ref.camera_view, err_msg="columns-mode gather")
+        np.testing.assert_array_equal(frames_f.astype(np.uint32), ref.camera_view, err_msg="frames-mode gather")
+    ref.reset(seed=5)
+    np.testing.assert_array_equal(results[0][5], ref.col_height, err_msg="after sharded reset")
