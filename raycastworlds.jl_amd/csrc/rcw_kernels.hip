@@ -49,6 +49,13 @@ __device__ __forceinline__ void set_goal_bit(uint32_t* tm, int H, int i, int j, 
     if (v) tm[t >> 4] |= m; else tm[t >> 4] &= ~m;
 }
 
+// In LDS the tile map is staged UNPACKED, one byte per tile (value = the tile's 2 bits), so a
+// lookup in the ray march is a single ds_read_u8 at the linear tile index.
+__device__ __forceinline__ void stage_tile_bytes(uint8_t* tb, const uint32_t* tm_hbm, int HW, int tid, int nthreads)
+{
+    for (int t = tid; t < HW; t += nthreads) tb[t] = (uint8_t)((tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u);
+}
+
 // ---- is_player_colliding for both layers in one sweep  (CD:21-42) ----------------------
 // Per layer the reference walks the 3x3 tiles (j outer, i inner), indexes the map first
 // (BoundsError if the tile is off the map) and returns at the first hit.  Result per
@@ -57,7 +64,7 @@ struct Collide { int wall, goal; };
 // Wave-parallel form: lane t < 9 tests tile t of the neighbourhood in the reference's visiting
 // order (t = 3 (j - jt + 1) + (i - it + 1)); three ballots recover "first event in order" per
 // layer.  Every lane of the wave gets the same (wave-uniform) result.  px, py are uniform.
-__device__ __forceinline__ Collide player_colliding(const uint32_t* tm, int H, int W, float px,
+__device__ __forceinline__ Collide player_colliding(const uint8_t* tb, int H, int W, float px,
                                                     float py, float radius_sq, int oob_empty)
 {
     const int it = (int)floorf(px) + 1;   // wu_to_tu UT:5
@@ -67,7 +74,7 @@ __device__ __forceinline__ Collide player_colliding(const uint32_t* tm, int H, i
     const int i = it - 1 + (t - 3 * tq), j = jt - 1 + tq;
     const bool valid = t < 9;
     const bool inb = i >= 1 && i <= H && j >= 1 && j <= W;
-    const uint32_t bits = (valid && inb) ? tile_bits(tm, H, i, j) : 0u;
+    const uint32_t bits = (valid && inb) ? (uint32_t)tb[(i - 1) + H * (j - 1)] : 0u;
     const float cx = (float)i - 0.5f, cy = (float)j - 0.5f;          // CD:33-34
     const float qx = px - cx, qy = py - cy;                          // CD:35
     const float sx = qx < -0.5f ? -0.5f : (qx > 0.5f ? 0.5f : qx);   // clamp CD:11
@@ -128,50 +135,51 @@ __device__ __forceinline__ Pose reset_agent(const RcwDev& p, int a, uint32_t* tm
 
 // ---- RayCaster.cast_ray  (external; call site SR:223).  UNPINNED choices via p.tie_le /
 // p.dist_pre (include/rcw.h).  Leaves the map -> oob (Julia: BoundsError). ------------------
-struct RayHit { int i, j, dim; float dist; uint32_t bits; bool oob; };
-// The march is written with selects, not branches: lanes of a wavefront disagree on the step
-// axis at almost every iteration, and a divergent if/else costs more in exec-mask bookkeeping
-// than the few extra v_cndmask.  The only divergence left is the trip count (lanes that have
-// hit wait for the longest ray of the wavefront).
+struct RayHit { int t, dim; float dist; uint32_t bits; bool oob; };
+// The march is written with selects, not branches (lanes of a wavefront disagree on the step
+// axis at almost every iteration; a divergent if/else costs more in exec-mask bookkeeping than
+// the few v_cndmask), and it carries only what the result needs: the two side distances, the
+// linear tile index t (the stop tile is t mod H, t div H) and the last axis.  The chip's VALU
+// issue rate bounds this loop (B·N rays x trip count x instructions), so every instruction
+// counts.  A closed wall ring (SR:57-60) stops every ray; `cap` only guards a corrupt map
+// against hanging the wavefront, and is reported as out of bounds.
 template <bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ RayHit cast_ray(const uint32_t* tm, int H, int W, float x, float y,
+__device__ __forceinline__ RayHit cast_ray(const uint8_t* tb, int H, int W, float x, float y,
                                            float dx, float dy, float ddx, float ddy)
 {
-    int i = (int)floorf(x) + 1;           // wu_to_tu UT:5
-    int j = (int)floorf(y) + 1;
+    const int i0 = (int)floorf(x) + 1;    // wu_to_tu UT:5
+    const int j0 = (int)floorf(y) + 1;
     const bool neg_x = dx < 0.0f, neg_y = dy < 0.0f;
-    const int si = neg_x ? -1 : 1, sj = neg_y ? -1 : 1;
-    const float fx = neg_x ? x - (float)(i - 1) : (float)i - x;
-    const float fy = neg_y ? y - (float)(j - 1) : (float)j - y;
+    const int si = neg_x ? -1 : 1;
+    const int tj = neg_y ? -H : H;
+    const float fx = neg_x ? x - (float)(i0 - 1) : (float)i0 - x;
+    const float fy = neg_y ? y - (float)(j0 - 1) : (float)j0 - y;
     float sx = fx * ddx, sy = fy * ddy;
-    int t = (i - 1) + H * (j - 1);        // linear tile index, kept incrementally
-    const int tj = sj * H;
+    int t = (i0 - 1) + H * (j0 - 1);
+    const unsigned last = (unsigned)(H * W - 1);
+    const int cap = H + W;
     RayHit r;
-    r.dim = 0; r.dist = 0.0f; r.bits = 0u; r.oob = false;
-    // Every iteration moves one tile in a fixed direction, so the loop leaves the map (and
-    // exits) after at most H + W steps even on a map without a closed wall ring.
+    r.dim = 0; r.dist = 0.0f;
+    int n = 0;
     for (;;) {
-        const bool inb = (unsigned)(i - 1) < (unsigned)H && (unsigned)(j - 1) < (unsigned)W;
-        const int ts = inb ? t : 0;
-        r.bits = inb ? (tm[ts >> 4] >> ((ts & 15) * 2)) & 3u : 0u;
-        r.oob = !inb;
-        if (r.bits != 0u || !inb) break;
+        const unsigned tc = (unsigned)t < last ? (unsigned)t : last;      // never read outside the map
+        r.bits = tb[tc];
+        if (r.bits != 0u || n >= cap) break;
+        ++n;
         const bool xf = TIE_LE ? (sx <= sy) : (sx < sy);
-        const float side = xf ? sx : sy;
-        const float next = side + (xf ? ddx : ddy);
-        r.dist = side;
-        sx = xf ? next : sx;
-        sy = xf ? sy : next;
-        i += xf ? si : 0;
-        j += xf ? 0 : sj;
+        const float nx = sx + ddx, ny = sy + ddy;
+        if (DIST_PRE) r.dist = xf ? sx : sy;
+        sx = xf ? nx : sx;
+        sy = xf ? sy : ny;
         t += xf ? si : tj;
         r.dim = xf ? 1 : 2;
     }
+    r.oob = r.bits == 0u || (unsigned)t > last;
     if (!DIST_PRE) {
         const float d1 = sx - ddx, d2 = sy - ddy;
         r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : 0.0f);
     }
-    r.i = i; r.j = j;
+    r.t = t;
     return r;
 }
 
@@ -215,12 +223,13 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     const int tid = threadIdx.x;
     if (mask != nullptr && mask[a] == 0) return;
 
-    uint32_t* tm = lds;                                     // [nwords] the agent's tile map
+    uint8_t* tb = reinterpret_cast<uint8_t*>(lds);          // [H*W] the agent's tile map, a byte per tile
     __shared__ float s_pose[4];
+    const int HW = p.H * p.W;
 
     // ---- every load of the agent's state is issued up front (all wave-uniform addresses) ----
     uint32_t* tm_hbm = p.tile_map + (size_t)a * p.nwords;
-    for (int w = tid; w < p.nwords; w += (int)blockDim.x) tm[w] = tm_hbm[w];
+    stage_tile_bytes(tb, tm_hbm, HW, tid, (int)blockDim.x);
     int act = actions ? (int)actions[a] : 0;
     const float2 pos = p.pos[a];
     const int d = p.dir[a];
@@ -242,9 +251,11 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     float x = pos.x, y = pos.y;
     if (resample) {                                                         // wave-uniform, rare
         if (tid == 0) {
-            const Pose np = reset_agent(p, a, tm, tm_hbm);
+            const Pose np = reset_agent(p, a, tm_hbm, nullptr);
             s_pose[0] = np.x; s_pose[1] = np.y; s_pose[2] = __int_as_float(np.d);
         }
+        __syncthreads();
+        stage_tile_bytes(tb, tm_hbm, HW, tid, (int)blockDim.x);             // the goal moved
         __syncthreads();
         x = s_pose[0]; y = s_pose[1];
         d_new = __float_as_int(s_pose[2]);
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
             const float ix = p.inc * dv.x, iy = p.inc * dv.y;
             const float nx = act == 1 ? pos.x + ix : pos.x - ix;            // UT:16-17
             const float ny = act == 1 ? pos.y + iy : pos.y - iy;
-            const Collide c = player_colliding(tm, p.H, p.W, nx, ny, p.radius_sq, p.oob_empty);   // SR:162-163
+            const Collide c = player_colliding(tb, p.H, p.W, nx, ny, p.radius_sq, p.oob_empty);   // SR:162-163
             if (c.wall == 2 || c.goal == 2) oob = true;                     // BoundsError: no mutation
             else if (c.goal) { reward = p.goal_reward; done = 1; }          // SR:166-168
             else if (c.wall) { }                                            // SR:170-171
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         const float dx = tab[i], dy = tab[p.N + i];
         const float ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
         const float dot = tab[4 * p.N + i];
-        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tm, p.H, p.W, x, y, dx, dy, ddx, ddy);
+        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
@@ -433,19 +444,19 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
     const int local = blockIdx.x;
     const int a = first + local;
     const int tid = threadIdx.x;
-    uint32_t* tm = lds;
-    const uint32_t* tm_hbm = p.tile_map + (size_t)a * p.nwords;
-    for (int w = tid; w < p.nwords; w += kBlock) tm[w] = tm_hbm[w];
+    uint8_t* tb = reinterpret_cast<uint8_t*>(lds);
+    stage_tile_bytes(tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kBlock);
     __syncthreads();
     const float2 pos = p.pos[a];
     const int d = p.dir[a];
     const float* tab = p.ray_table + (size_t)d * RCW_TABLE_ROWS * p.N;
     for (int i = tid; i < p.N; i += kBlock) {
         const float dx = tab[i], dy = tab[p.N + i];
-        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tm, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
                                                     tab[3 * p.N + i]);
+        const int hit_j = r.t / p.H, hit_i = r.t - hit_j * p.H;           // 0-based stop tile
         const size_t q = (size_t)local * p.N + i;
-        if (out.stop_ij) { out.stop_ij[2 * q] = r.oob ? 1 : r.i; out.stop_ij[2 * q + 1] = r.oob ? 1 : r.j; }
+        if (out.stop_ij) { out.stop_ij[2 * q] = r.oob ? 1 : hit_i + 1; out.stop_ij[2 * q + 1] = r.oob ? 1 : hit_j + 1; }
         if (out.hit_dim) out.hit_dim[q] = r.oob ? 0 : r.dim;
         if (out.dist) out.dist[q] = r.oob ? 0.0f : r.dist;
         if (out.dirs) { out.dirs[2 * q] = dx; out.dirs[2 * q + 1] = dy; }
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
 // ---- launchers ----------------------------------------------------------------------------------
 size_t rcw_step_lds_bytes(const RcwDev& p)
 {
-    return (((size_t)p.nwords + 3) & ~(size_t)3) * sizeof(uint32_t);
+    return (((size_t)p.H * p.W + 15) & ~(size_t)15);   // one byte per tile
 }
 
 hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
