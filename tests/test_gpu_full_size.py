@@ -1,0 +1,99 @@
+"""Parity at BASELINE.json's FULL sizes (cfg-2 4096 x 256, cfg-3 16384 x 512, cfg-5 8192 x 1024),
+where stepping the rendering oracle would take minutes:
+
+* per-agent state and per-column descriptors (height_line_pu, colour id) of EVERY agent against
+  the oracle run without the pixel fill (cheap: 5 bytes per column);
+* the full observation batch against an independent expansion of those descriptors written
+  with torch ops on the device (size-independent property: a frame is a pure function of its
+  column descriptors, SR:431-440), plus oracle-rendered frames for a sample of agents;
+* sharding invariance: two engines with agent_id_offset reproduce one engine;
+* determinism / idempotence: turn left then right restores the frame bit for bit.
+"""
+import numpy as np
+import pytest
+
+from helpers import CFG2, CFG3, CFG5
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+COLOURS = [0x808080, 0xC0C0C0, 0x800000, 0xC00000]
+
+
+def torch_expand(h, c, Hc=256):
+    """(B, N) int32 / uint8 descriptors -> (B, N, Hc) int64 pixels, straight from SR:431-440."""
+    h = h.to(torch.int64)
+    pad = torch.where(h >= Hc - 1, torch.zeros_like(h), (Hc - h) // 2).unsqueeze(-1)
+    rows = torch.arange(Hc, device=h.device).view(1, 1, Hc)
+    col = torch.tensor(COLOURS, device=h.device, dtype=torch.int64)[c.to(torch.int64)].unsqueeze(-1)
+    return torch.where(rows < pad, 0xFFFFFF, torch.where(rows < Hc - pad, col, 0x404040))
+
+
+def check_frames_against_descriptors(env, chunk=512):
+    obs = env.camera_view.torch()
+    h, c = env.columns_device()
+    h, c = h.torch(), c.torch()
+    for a0 in range(0, env.batch, chunk):
+        want = torch_expand(h[a0:a0 + chunk], c[a0:a0 + chunk]).to(torch.int32)
+        got = obs[a0:a0 + chunk].view(torch.int32)
+        assert torch.equal(got, want), f"frames of agents {a0}..{a0 + chunk} differ from their descriptors"
+
+
+@pytest.mark.parametrize("cfg,batch,steps", [(CFG2, 4096, 24), (CFG3, 16384, 6), (CFG5, 8192, 4)],
+                         ids=["cfg2_4096x256", "cfg3_16384x512", "cfg5_8192x1024"])
+def test_full_size_parity(rcw, oracle, cfg, batch, steps):
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=2024, out_of_bounds=1, **cfg)
+    orc = oracle.OracleBatch(batch, seed=2024, render=False, out_of_bounds=1, **cfg)
+    rng = np.random.default_rng(1)
+    sample = rng.choice(batch, 16, replace=False)
+    for s in range(steps):
+        a = rng.integers(1, 5, batch).astype(np.uint8)
+        rcw.act_(env, a)
+        assert orc.step(a) == 0
+    w = env.world
+    np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
+    np.testing.assert_array_equal(w.player_direction_au, orc.direction)
+    np.testing.assert_array_equal(w.reward, orc.reward)
+    np.testing.assert_array_equal(w.done.astype(np.uint8), orc.done)
+    np.testing.assert_array_equal(w.tile_map_chunks, orc.tile_map_chunks())
+    h, c = env.columns()
+    np.testing.assert_array_equal(h, orc.col_height)
+    np.testing.assert_array_equal(c, orc.col_colour)
+    check_frames_against_descriptors(env)
+    # oracle-rendered frames for a sample of agents (same state injected into a small rendering oracle)
+    small = oracle.OracleBatch(len(sample), seed=0, **cfg)
+    small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
+    got = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
+    np.testing.assert_array_equal(got, small.camera_view)
+    env.close()
+
+
+def test_sharding_invariance_on_device(rcw):
+    kw = dict(seed=9, out_of_bounds=1, **CFG2)
+    whole = rcw.SingleRoomModule.SingleRoom(batch=512, **kw)
+    lo = rcw.SingleRoomModule.SingleRoom(batch=256, agent_id_offset=0, **kw)
+    hi = rcw.SingleRoomModule.SingleRoom(batch=256, agent_id_offset=256, **kw)
+    rng = np.random.default_rng(2)
+    for s in range(40):
+        a = rng.integers(1, 5, 512).astype(np.uint8)
+        rcw.act_(whole, a); rcw.act_(lo, a[:256]); rcw.act_(hi, a[256:])
+    for e in (whole, lo, hi):
+        rcw.reset_(e, seed=31)                      # exercises the on-device generator again
+    np.testing.assert_array_equal(whole.world.goal_position,
+                                  np.concatenate([lo.world.goal_position, hi.world.goal_position]))
+    np.testing.assert_array_equal(whole.camera_view_host(),
+                                  np.concatenate([lo.camera_view_host(), hi.camera_view_host()]))
+    for e in (whole, lo, hi):
+        e.close()
+
+
+def test_turn_left_then_right_restores_the_frame(rcw):
+    env = rcw.SingleRoomModule.SingleRoom(batch=1024, seed=4, **CFG2)
+    before = env.camera_view.torch().clone()
+    rcw.act_(env, 3)
+    middle = env.camera_view.torch().clone()
+    rcw.act_(env, 4)
+    after = env.camera_view.torch()
+    assert torch.equal(before.view(torch.int32), after.view(torch.int32))
+    assert not torch.equal(before.view(torch.int32), middle.view(torch.int32))
+    env.close()
