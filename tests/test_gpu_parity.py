@@ -208,3 +208,51 @@ def test_reference_bounds_error_quirk(rcw, oracle):
     assert_state_equal(env, orc, where="treat-empty policy")
     assert env.world.player_position_wu[0, 0] == np.float32(6.875)
     env.close()
+
+
+def test_non_default_parameters(rcw, oracle):
+    """Odd sizes and non-default kwargs of SingleRoom(; ...) SR:258-272: non-square map, N not a
+    multiple of 64, other num_directions / fov / radius / increment / camera height."""
+    rng = np.random.default_rng(11)
+    cases = [
+        dict(height_tile_map_tu=12, width_tile_map_tu=20, num_rays=100),
+        dict(height_tile_map_tu=5, width_tile_map_tu=9, num_rays=37, num_directions=36),
+        dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=200, semi_field_of_view_wu=1.0,
+             camera_height_tile_wu=0.5),
+        dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, player_radius_wu=0.25,
+             position_increment_wu=0.0625),
+        dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, player_radius_wu=0.1,
+             position_increment_wu=0.3),          # inc > radius: the BoundsError regime (SURVEY §8f.3)
+        dict(height_tile_map_tu=3, width_tile_map_tu=3, num_rays=64),   # smallest room: one free tile
+        dict(height_tile_map_tu=40, width_tile_map_tu=40, num_rays=96),
+    ]
+    for kw in cases:
+        env, orc = _make(rcw, oracle, 24, seed=21, **kw)
+        assert_state_equal(env, orc, rays=True, where=f"create {kw}")
+        for s in range(60):
+            a = rng.integers(1, 5, env.batch).astype(np.uint8)
+            rcw.act_(env, a)
+            assert orc.step(a) == 0
+            try:
+                env.sync()
+            except IndexError:
+                np.testing.assert_array_equal(env.world.status, orc.status)
+                env.clear_error()
+                orc.clear_status()
+        assert_state_equal(env, orc, rays=True, where=f"rollout {kw}")
+        env.close()
+
+
+def test_custom_direction_table(rcw, oracle):
+    """rcw_set_direction_table: a caller-supplied directions_wu (e.g. Julia's own cos/sin) replaces
+    SR:65-69 and the ray table is rebuilt from it."""
+    env, orc = _make(rcw, oracle, 8, seed=3, **CFG1)
+    nd = 128
+    th = (np.arange(nd) * 2 * np.pi / nd) + 0.01
+    dirs = np.stack([np.cos(th), np.sin(th)], axis=1).astype(np.float32)
+    env.set_direction_table(dirs)
+    orc.set_direction_table(dirs)
+    assert_state_equal(env, orc, rays=True, where="custom table")
+    rng = np.random.default_rng(0)
+    _rollout(rcw, env, orc, 30, rng, check_every=10, rays_every=10)
+    env.close()
