@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="agents per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: all ranks share GPU 0 and rendezvous over gloo (checks the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -107,12 +109,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import raycastworlds_jl_amd as RCW
 
@@ -168,7 +175,8 @@ def main():
     env.profile(False)
     sync_counting_bounds_errors()
     if dist is not None:
-        t = torch.tensor([dt, kernel_ms, cast_ms, fill_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, kernel_ms, cast_ms, fill_ms], dtype=torch.float64,
+                         device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms, cast_ms, fill_ms = (float(v) for v in t)
 
