@@ -81,3 +81,19 @@ def test_reset_distributions(oracle):
     counts = np.bincount((g[:, 0] - 2) * 6 + (g[:, 1] - 2), minlength=36)
     assert counts.min() > 60 and counts.max() < 170
     assert len(np.unique(d)) == 128
+
+
+def test_frame_dump_matches_the_reference_blit(rcw, oracle, tmp_path):
+    """frame_to_rgb applies copy_image_to_frame_buffer!'s transpose (utils.jl:64-73)."""
+    orc = oracle.OracleBatch(1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    orc.set_state([[2, 2]], [[4.5, 4.5]], [0])
+    frame = orc.camera_view[0]                       # (N, H_cam)
+    rgb = rcw.frame_to_rgb(frame)
+    assert rgb.shape == (256, 64, 3)
+    assert (rgb[0] == 255).all()                     # ceiling 0x00FFFFFF on top
+    assert (rgb[128] == 0x80).all()                  # wall 0x00808080 in the middle
+    assert (rgb[255] == 0x40).all()                  # floor 0x00404040 at the bottom
+    p = tmp_path / "frame.ppm"
+    rcw.save_ppm(frame, str(p))
+    data = p.read_bytes()
+    assert data.startswith(b"P6\n64 256\n255\n") and len(data) == len(b"P6\n64 256\n255\n") + 64 * 256 * 3
