@@ -1,0 +1,72 @@
+/* Plain-C caller of librcw_hip.so, making the calls julia/BatchedSingleRoom.jl makes through
+ * ccall (same argument types, host buffers in, host buffers out): test/runtests.jl:15-44 for a
+ * batch, then a deterministic rollout whose frame checksum the pytest wrapper compares with the
+ * CPU oracle.  No Python, no torch: only include/rcw.h.
+ *
+ *   gcc -O2 -I include tests/c_abi_harness.c -o harness -L raycastworlds.jl_amd/lib -lrcw_hip
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rcw.h"
+
+#define CHECK(call)                                                              \
+    do {                                                                         \
+        int rc_ = (call);                                                        \
+        if (rc_ != RCW_OK) {                                                     \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, rcw_last_error());     \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+
+static uint64_t lcg(uint64_t* s) { *s = *s * 6364136223846793005ULL + 1442695040888963407ULL; return *s >> 33; }
+
+int main(int argc, char** argv)
+{
+    const int B = 64, STEPS = argc > 1 ? atoi(argv[1]) : 120;
+    rcw_config cfg;
+    CHECK(rcw_config_default(&cfg));
+    cfg.height_tile_map_tu = 8; cfg.width_tile_map_tu = 8; cfg.num_rays = 64;
+    cfg.out_of_bounds = RCW_OOB_TREAT_EMPTY;
+    rcw_handle* h = NULL;
+    CHECK(rcw_create(&cfg, B, 0, 2024, &h));
+
+    float reward[64]; uint8_t done[64], actions[64];
+    CHECK(rcw_reward(h, reward)); CHECK(rcw_done(h, done));
+    for (int a = 0; a < B; ++a)
+        if (reward[a] != 0.0f || done[a]) { fprintf(stderr, "after reset: reward/done not clear\n"); return 1; }
+
+    /* the @assert of single_room.jl:140 */
+    memset(actions, 1, sizeof actions); actions[7] = 5;
+    if (rcw_step(h, actions) != RCW_ERR_INVALID_ACTION) { fprintf(stderr, "invalid action accepted\n"); return 1; }
+
+    uint64_t seed = 99;
+    float ret[64] = {0};
+    int finished = 0;
+    for (int s = 0; s < STEPS; ++s) {
+        for (int a = 0; a < B; ++a) actions[a] = (uint8_t)(1 + lcg(&seed) % 4);
+        CHECK(rcw_step(h, actions));
+        CHECK(rcw_reward(h, reward)); CHECK(rcw_done(h, done));
+        for (int a = 0; a < B; ++a) {
+            if (!done[a] && reward[a] != 0.0f) { fprintf(stderr, "reward on a non-terminal step\n"); return 1; }
+            if (done[a] && reward[a] != 1.0f) { fprintf(stderr, "terminal step without goal_reward\n"); return 1; }
+            ret[a] += reward[a]; finished += done[a];
+        }
+    }
+    const size_t npix = (size_t)B * 64 * 256;
+    uint32_t* frames = (uint32_t*)malloc(npix * sizeof(uint32_t));
+    CHECK(rcw_obs_copy(h, frames, 0, B));
+    uint64_t sum = 1469598103934665603ULL;                 /* FNV-1a over the words */
+    for (size_t k = 0; k < npix; ++k) { sum ^= frames[k]; sum *= 1099511628211ULL; }
+    float pos[128]; int32_t dir[64];
+    CHECK(rcw_position(h, pos)); CHECK(rcw_direction(h, dir));
+    char name[128];
+    CHECK(rcw_device_name(h, name, sizeof name));
+    printf("device=%s steps=%d terminal_events=%d checksum=%016llx pos0=%.9g,%.9g dir0=%d\n", name, STEPS, finished,
+           (unsigned long long)sum, pos[0], pos[1], dir[0]);
+    free(frames);
+    CHECK(rcw_destroy(h));
+    return 0;
+}

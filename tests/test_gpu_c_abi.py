@@ -1,0 +1,48 @@
+"""The C ABI used from plain C (what a Julia `ccall` does), without Python in the call path:
+tests/c_abi_harness.c is compiled with gcc against include/rcw.h, run on the GPU, and its frame
+checksum is compared with the CPU oracle fed the same seed and action stream."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lcg_actions(steps, B, seed=99):
+    out = np.zeros((steps, B), dtype=np.uint8)
+    s = seed
+    for t in range(steps):
+        for a in range(B):
+            s = (s * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            out[t, a] = 1 + (s >> 33) % 4
+    return out
+
+
+def test_plain_c_caller(oracle, tmp_path):
+    exe = str(tmp_path / "harness")
+    lib = os.path.join(ROOT, "raycastworlds.jl_amd", "lib")
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_harness.c"),
+                    "-o", exe, "-L", lib, "-lrcw_hip", f"-Wl,-rpath,{lib}"], check=True)
+    steps = 120
+    res = subprocess.run([exe, str(steps)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    m = re.search(r"terminal_events=(\d+) checksum=([0-9a-f]{16}) pos0=([-\d.e+]+),([-\d.e+]+) dir0=(\d+)", res.stdout)
+    assert m, res.stdout
+    orc = oracle.OracleBatch(64, seed=2024, out_of_bounds=1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    acts = _lcg_actions(steps, 64)
+    terminal = 0
+    for t in range(steps):
+        assert orc.step(acts[t]) == 0
+        terminal += int(orc.done.sum())
+    words = orc.camera_view.reshape(-1).astype(np.uint64)
+    h = 1469598103934665603
+    for wv in words.tolist():                      # FNV-1a over the words, as in the harness
+        h = ((h ^ wv) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(m.group(1)) == terminal
+    assert m.group(2) == f"{h:016x}"
+    assert np.float32(m.group(3)) == orc.position[0, 0] and np.float32(m.group(4)) == orc.position[0, 1]
+    assert int(m.group(5)) == orc.direction[0]
