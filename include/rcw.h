@@ -131,7 +131,11 @@ typedef struct rcw_config {
                                          colour id) is always kept in device memory        */
     int32_t  out_of_bounds;           /* RCW_OOB_ERROR (default, reference behaviour) |
                                          RCW_OOB_TREAT_EMPTY                               */
-    int32_t  reserved[6];
+    int32_t  render_top_view;         /* 1: every reset/step also renders the top view
+                                         (update_top_view! SR:446-483); default 0 — the
+                                         reference always does, but it is a debug view, not the
+                                         observation, and it doubles the bytes per step          */
+    int32_t  reserved[5];
 } rcw_config;
 
 typedef struct rcw_handle rcw_handle;   /* opaque */
@@ -197,6 +201,14 @@ RCW_API int rcw_clear_error(rcw_handle* h);
 RCW_API int rcw_obs_device_ptr(rcw_handle* h, void** device_ptr);
 /* Copy frames of agents [first, first+count) to host: UInt32 (H_cam, N, count). */
 RCW_API int rcw_obs_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count);
+/* env.top_view SR:302 (needs cfg.render_top_view = 1): UInt32 (H*pu, W*pu, B), column-major,
+ * as update_top_view! SR:446-483 leaves it: draw_tile_map! SR:342-372 (tile colours
+ * 0x00FFFFFF wall / 0x00FF0000 goal / 0x00000000 free SR:288, grid 0x00cccccc), one line per
+ * ray to its stop point SR:473-477 (0x00808080) and the player circle SR:480 (0x00c0c0c0).
+ * The line and circle rasterisers belong to SimpleDraw 0.3 (un-vendored): Bresenham / midpoint
+ * circle are ASSUMED — parity unpinned. */
+RCW_API int rcw_top_view_device_ptr(rcw_handle* h, void** device_ptr);
+RCW_API int rcw_top_view_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count);
 /* RLBase.reward SR:583 / RLBase.is_terminated SR:584 */
 RCW_API int rcw_reward(rcw_handle* h, float* out_host /* (B) */);
 RCW_API int rcw_done(rcw_handle* h, uint8_t* out_host /* (B) */);

@@ -56,7 +56,8 @@ Base.@kwdef mutable struct RcwConfig
     agent_id_offset::Int64 = 0
     write_columns::Int32 = 1
     out_of_bounds::Int32 = 0
-    reserved::NTuple{6, Int32} = (0, 0, 0, 0, 0, 0)
+    render_top_view::Int32 = 0
+    reserved::NTuple{5, Int32} = (0, 0, 0, 0, 0)
 end
 
 struct RcwError <: Exception

@@ -46,7 +46,8 @@ class RcwConfig(C.Structure):
         ("agent_id_offset", C.c_int64),
         ("write_columns", C.c_int32),
         ("out_of_bounds", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("render_top_view", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -128,7 +129,7 @@ def lib() -> C.CDLL:
                                               C.c_float, C.c_int32]
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
-        for name in ("camera_view", "reward", "done", "position", "direction", "goal", "episode",
+        for name in ("camera_view", "top_view", "reward", "done", "position", "direction", "goal", "episode",
                      "status", "ray_stop", "ray_dim", "ray_dist", "ray_dirs", "col_height",
                      "col_colour", "directions", "ray_table"):
             f = getattr(L, "orc_" + name)
@@ -219,6 +220,13 @@ class OracleBatch:
     def camera_view(self):
         assert self.render
         return self._g("camera_view", np.uint32, (self.B, self.N, self.Hc))
+
+    @property
+    def top_view(self):
+        """(B, W*pu, H*pu) == Julia (H*pu, W*pu, B); needs render_top_view=1."""
+        assert self.cfg.render_top_view
+        pu = self.cfg.pu_per_tu
+        return self._g("top_view", np.uint32, (self.B, self.W * pu, self.H * pu))
 
     @property
     def reward(self):

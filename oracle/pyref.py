@@ -218,8 +218,64 @@ class World:
                 col[pad:Hc - pad] = colour                           # rows pad+1 : end-pad
                 col[Hc - pad:] = COLOURS["floor"]                    # rows end-pad+1 : end
 
+    # ---- top view (SR:342-372, SR:446-483); SimpleDraw 0.3 rasterisers ASSUMED (unpinned) ----
+    def update_top_view(self, pu=32):
+        H, W = self.H, self.W
+        Ht, Wt = H * pu, W * pu
+        img = np.zeros((Ht + 1, Wt + 1), dtype=np.uint32)        # 1-based [i][j]
+
+        def put(i, j, c):
+            if 1 <= i <= Ht and 1 <= j <= Wt:
+                img[i, j] = c
+
+        pu_per_tu = Ht // H                                       # SR:346
+        colors = (0x00FFFFFF, 0x00FF0000, 0x00000000)             # SR:288
+        for j in range(1, W + 1):                                 # draw_tile_map! SR:348-369
+            for i in range(1, H + 1):
+                i0, j0 = (i - 1) * pu_per_tu + 1, (j - 1) * pu_per_tu + 1
+                obj = 1 if self.tile_map[WALL][i][j] else (2 if self.tile_map[GOAL][i][j] else None)
+                color = colors[-1] if obj is None else colors[obj - 1]
+                img[i0:i0 + pu_per_tu, j0:j0 + pu_per_tu] = color             # FilledRectangle
+                img[i0, j0:j0 + pu_per_tu] = 0x00CCCCCC                        # SR:364
+                img[i0 + pu_per_tu - 1, j0:j0 + pu_per_tu] = 0x00CCCCCC        # SR:365
+                img[i0:i0 + pu_per_tu, j0] = 0x00CCCCCC                        # SR:366
+                img[i0:i0 + pu_per_tu, j0 + pu_per_tu - 1] = 0x00CCCCCC        # SR:367
+
+        def wu_to_pu(x):                                          # UT:6
+            return int(math.floor(float(f32(x) * f32(pu_per_tu)))) + 1
+
+        ip, jp = wu_to_pu(self.pos[0]), wu_to_pu(self.pos[1])     # SR:468
+        rp = wu_to_pu(self.radius)                                # SR:469
+        for r, (_, _, _, dist) in zip(self.ray_dirs, self.ray_hits):          # SR:473-477
+            end = (self.pos[0] + dist * r[0], self.pos[1] + dist * r[1])
+            i1, j1, i2, j2 = ip, jp, wu_to_pu(end[0]), wu_to_pu(end[1])
+            di, dj = abs(i2 - i1), -abs(j2 - j1)                  # Bresenham (assumed SD.Line)
+            si, sj = (1 if i1 < i2 else -1), (1 if j1 < j2 else -1)
+            err = di + dj
+            while True:
+                put(i1, j1, 0x00808080)
+                if i1 == i2 and j1 == j2:
+                    break
+                e2 = 2 * err
+                if e2 >= dj:
+                    err += dj; i1 += si
+                if e2 <= di:
+                    err += di; j1 += sj
+        # SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1): midpoint circle (assumed)  SR:480
+        ci, cj, x, y, d = ip, jp, 0, rp, 1 - rp
+        while x <= y:
+            for a, b in ((x, y), (-x, y), (x, -y), (-x, -y), (y, x), (-y, x), (y, -x), (-y, -x)):
+                put(ci + a, cj + b, 0x00C0C0C0)
+            x += 1
+            if d < 0:
+                d += 2 * x + 1
+            else:
+                y -= 1
+                d += 2 * (x - y) + 1
+        self.top_view = img[1:, 1:].T.copy()                      # [j-1][i-1] == the engine's (Wt, Ht)
+
     def step(self, action):
-        """act!(env, action) SR:333-340 without the top view."""
+        """act!(env, action) SR:333-340 (top view on request only)."""
         self.act(action)
         self.cast_rays()
         self.update_camera_view()

@@ -208,6 +208,8 @@ typedef struct orc_batch {
     int32_t* col_height;    /* (N, B) indexed by image column k */
     uint8_t* col_colour;    /* (N, B) */
     int render;             /* 0: skip the pixel fill (descriptor only) */
+    uint32_t* top_view;     /* (H*pu, W*pu, B) when cfg.render_top_view */
+    int32_t Ht, Wt;
 } orc_batch;
 
 ORC_EXPORT void orc_destroy(orc_batch* b)
@@ -216,7 +218,7 @@ ORC_EXPORT void orc_destroy(orc_batch* b)
     free(b->directions); free(b->ray_table); free(b->wall); free(b->goalmap); free(b->pos);
     free(b->dir); free(b->goal); free(b->reward); free(b->done); free(b->episode);
     free(b->status); free(b->ray_stop); free(b->ray_dim); free(b->ray_dist);
-    free(b->ray_dirs); free(b->camera_view); free(b->col_height); free(b->col_colour);
+    free(b->ray_dirs); free(b->camera_view); free(b->top_view); free(b->col_height); free(b->col_colour);
     free(b);
 }
 
@@ -313,9 +315,88 @@ static void orc_update_camera_view_agent(orc_batch* b, int32_t a)
     }
 }
 
+/* ---- SimpleDraw 0.3 primitives used by the top view (un-vendored: UNPINNED) ------------------
+ * image is column-major (Ht, Wt); (i, j) are 1-based; pixels off the image are skipped. */
+static void sd_put_pixel(uint32_t* img, int64_t Ht, int64_t Wt, int64_t i, int64_t j, uint32_t c)
+{
+    if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) img[(i - 1) + Ht * (j - 1)] = c;
+}
+/* SD.Line: ASSUMED Bresenham, all octants, both end points drawn */
+static void sd_line(uint32_t* img, int64_t Ht, int64_t Wt, int64_t i1, int64_t j1, int64_t i2, int64_t j2, uint32_t c)
+{
+    const int64_t di = llabs(i2 - i1), dj = -llabs(j2 - j1);
+    const int64_t si = i1 < i2 ? 1 : -1, sj = j1 < j2 ? 1 : -1;
+    int64_t err = di + dj;
+    for (;;) {
+        sd_put_pixel(img, Ht, Wt, i1, j1, c);
+        if (i1 == i2 && j1 == j2) break;
+        const int64_t e2 = 2 * err;
+        if (e2 >= dj) { err += dj; i1 += si; }
+        if (e2 <= di) { err += di; j1 += sj; }
+    }
+}
+/* SD.Circle(position, diameter) with an odd diameter: ASSUMED midpoint circle of radius
+ * diameter div 2 around position + radius, 8-way symmetric */
+static void sd_circle(uint32_t* img, int64_t Ht, int64_t Wt, int64_t i_pos, int64_t j_pos, int64_t diameter, uint32_t c)
+{
+    const int64_t r = diameter / 2, ci = i_pos + r, cj = j_pos + r;
+    int64_t x = 0, y = r, d = 1 - r;
+    while (x <= y) {
+        sd_put_pixel(img, Ht, Wt, ci + x, cj + y, c); sd_put_pixel(img, Ht, Wt, ci - x, cj + y, c);
+        sd_put_pixel(img, Ht, Wt, ci + x, cj - y, c); sd_put_pixel(img, Ht, Wt, ci - x, cj - y, c);
+        sd_put_pixel(img, Ht, Wt, ci + y, cj + x, c); sd_put_pixel(img, Ht, Wt, ci - y, cj + x, c);
+        sd_put_pixel(img, Ht, Wt, ci + y, cj - x, c); sd_put_pixel(img, Ht, Wt, ci - y, cj - x, c);
+        x += 1;
+        if (d < 0) d += 2 * x + 1;
+        else { y -= 1; d += 2 * (x - y) + 1; }
+    }
+}
+/* wu_to_pu(x_wu, pu_per_wu) = floor(Int, x_wu * pu_per_wu) + 1  UT:6 (Float32 * Int -> Float32) */
+static int64_t orc_wu_to_pu(float x, int32_t pu) { return (int64_t)floorf(x * (float)pu) + 1; }
+
+/* update_top_view!(env)  SR:446-483 (+ draw_tile_map! SR:342-372) for agent a */
+static void orc_update_top_view_agent(orc_batch* b, int32_t a)
+{
+    const int32_t H = b->H, W = b->W, N = b->N;
+    const int64_t Ht = b->Ht, Wt = b->Wt;
+    const size_t HW = (size_t)H * W;
+    uint32_t* img = b->top_view + (size_t)Ht * Wt * a;
+    const int64_t pu = Ht / H;                                          /* SR:346, SR:466 */
+    const uint32_t colors[3] = {0x00FFFFFFu, 0x00FF0000u, 0x00000000u}; /* tile_map_colors SR:288 */
+    for (int32_t j = 1; j <= W; ++j) {                                  /* SR:348 */
+        for (int32_t i = 1; i <= H; ++i) {
+            const int64_t i0 = (int64_t)(i - 1) * pu + 1, j0 = (int64_t)(j - 1) * pu + 1;   /* SR:350-351 */
+            const size_t t = (size_t)(i - 1) + (size_t)H * (j - 1);
+            /* findfirst over the objects: WALL, then GOAL, else colors[end]  SR:355-360 */
+            const uint32_t c = b->wall[HW * a + t] ? colors[0] : (b->goalmap[HW * a + t] ? colors[1] : colors[2]);
+            for (int64_t jj = j0; jj < j0 + pu; ++jj)                   /* SD.FilledRectangle SR:353,362 */
+                for (int64_t ii = i0; ii < i0 + pu; ++ii) sd_put_pixel(img, Ht, Wt, ii, jj, c);
+            for (int64_t jj = j0; jj < j0 + pu; ++jj) {                 /* SR:364-365 */
+                sd_put_pixel(img, Ht, Wt, i0, jj, 0x00ccccccu);
+                sd_put_pixel(img, Ht, Wt, i0 + pu - 1, jj, 0x00ccccccu);
+            }
+            for (int64_t ii = i0; ii < i0 + pu; ++ii) {                 /* SR:366-367 */
+                sd_put_pixel(img, Ht, Wt, ii, j0, 0x00ccccccu);
+                sd_put_pixel(img, Ht, Wt, ii, j0 + pu - 1, 0x00ccccccu);
+            }
+        }
+    }
+    const float px = b->pos[2 * a], py = b->pos[2 * a + 1];
+    const int64_t ip = orc_wu_to_pu(px, (int32_t)pu), jp = orc_wu_to_pu(py, (int32_t)pu);     /* SR:468 */
+    const int64_t rp = orc_wu_to_pu(b->cfg.player_radius_wu, (int32_t)pu);                    /* SR:469 */
+    for (int32_t i = 0; i < N; ++i) {                                   /* SR:473-477 */
+        const size_t r = (size_t)N * a + i;
+        const float ex = px + b->ray_dist[r] * b->ray_dirs[2 * r];
+        const float ey = py + b->ray_dist[r] * b->ray_dirs[2 * r + 1];
+        sd_line(img, Ht, Wt, ip, jp, orc_wu_to_pu(ex, (int32_t)pu), orc_wu_to_pu(ey, (int32_t)pu), 0x00808080u);
+    }
+    sd_circle(img, Ht, Wt, ip - rp, jp - rp, 2 * rp + 1, 0x00c0c0c0u);  /* SR:480 */
+}
+
 static void orc_render_agent(orc_batch* b, int32_t a)
 {
     orc_cast_rays_agent(b, a);            /* SR:336 / SR:134 */
+    if (b->top_view) orc_update_top_view_agent(b, a);   /* SR:337 / SR:328 */
     orc_update_camera_view_agent(b, a);   /* SR:338 / SR:329 */
 }
 
@@ -382,6 +463,12 @@ ORC_EXPORT int orc_create(const rcw_config* cfg, int32_t batch, uint64_t seed, i
     b->ray_dist = (float*)calloc(N * B, sizeof(float));
     b->ray_dirs = (float*)calloc(2 * N * B, sizeof(float));
     b->camera_view = (uint32_t*)calloc(render ? (size_t)b->Hc * N * B : 1, sizeof(uint32_t));
+    b->Ht = H * cfg->pu_per_tu; b->Wt = W * cfg->pu_per_tu;
+    if (cfg->render_top_view) {
+        if (cfg->pu_per_tu < 1) { orc_destroy(b); return RCW_ERR_INVALID_ARGUMENT; }
+        b->top_view = (uint32_t*)calloc((size_t)b->Ht * b->Wt * B, sizeof(uint32_t));
+        if (!b->top_view) { orc_destroy(b); return RCW_ERR_OUT_OF_MEMORY; }
+    }
     b->col_height = (int32_t*)calloc(N * B, sizeof(int32_t));
     b->col_colour = (uint8_t*)calloc(N * B, 1);
     if (!b->directions || !b->ray_table || !b->wall || !b->goalmap || !b->pos || !b->dir ||
@@ -526,6 +613,7 @@ ORC_EXPORT void orc_clear_status(orc_batch* b) { memset(b->status, 0, sizeof(int
 
 /* ---- getters ----------------------------------------------------------------------- */
 ORC_EXPORT const uint32_t* orc_camera_view(orc_batch* b) { return b->camera_view; }
+ORC_EXPORT const uint32_t* orc_top_view(orc_batch* b) { return b->top_view; }
 ORC_EXPORT const float* orc_reward(orc_batch* b) { return b->reward; }
 ORC_EXPORT const uint8_t* orc_done(orc_batch* b) { return b->done; }
 ORC_EXPORT const float* orc_position(orc_batch* b) { return b->pos; }

@@ -20,7 +20,7 @@ from . import single_room as SingleRoomModule
 from .rlbase import RLBaseEnv
 from .sharded import ShardedSingleRoom, shard_range
 from .viewer import frame_to_rgb, save_agent_ppm, save_ppm
-from .single_room import (act_, cast_rays_, get_action_names, reset_, update_camera_view_)
+from .single_room import (act_, cast_rays_, get_action_names, reset_, update_camera_view_, update_top_view_)
 
 __all__ = ["SingleRoomModule", "RLBase", "RLBaseEnv", "ShardedSingleRoom", "shard_range", "frame_to_rgb", "save_ppm", "save_agent_ppm", "reset_", "act_", "cast_rays_",
-           "update_camera_view_", "get_action_names"]
+           "update_camera_view_", "update_top_view_", "get_action_names"]

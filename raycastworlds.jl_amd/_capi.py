@@ -51,7 +51,8 @@ class RcwConfig(C.Structure):
         ("agent_id_offset", C.c_int64),
         ("write_columns", C.c_int32),
         ("out_of_bounds", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("render_top_view", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -84,6 +85,8 @@ SIGNATURES = {
     "rcw_clear_error": [_vp],
     "rcw_obs_device_ptr": [_vp, C.POINTER(_vp)],
     "rcw_obs_copy": [_vp, _vp, _i32, _i32],
+    "rcw_top_view_device_ptr": [_vp, C.POINTER(_vp)],
+    "rcw_top_view_copy": [_vp, _vp, _i32, _i32],
     "rcw_reward": [_vp, _vp],
     "rcw_done": [_vp, _vp],
     "rcw_reward_device_ptr": [_vp, C.POINTER(_vp)],

@@ -49,6 +49,7 @@ struct rcw_handle {
     void* d_done = nullptr; void* d_episode = nullptr; void* d_tile_map = nullptr;
     void* d_dir_table = nullptr; void* d_ray_table = nullptr; void* d_obs = nullptr;
     void* d_col_h = nullptr; void* d_col_c = nullptr; void* d_err = nullptr; void* d_status = nullptr;
+    void* d_top_view = nullptr;
     void* d_actions = nullptr; void* d_mask = nullptr;
     void* d_in_goal = nullptr; void* d_in_pos = nullptr; void* d_in_dir = nullptr;
     int32_t* h_err = nullptr;   // pinned
@@ -76,6 +77,7 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
     hipError_t e;
     if (prof && (e = hipEventRecord(h->prof_ev[3 * h->prof_count + 0], h->stream)) != hipSuccess) return e;
     if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
+    if (d.top_view && (e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;   // SR:337
     if (prof && (e = hipEventRecord(h->prof_ev[3 * h->prof_count + 1], h->stream)) != hipSuccess) return e;
     if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
     if (prof) {
@@ -89,7 +91,7 @@ void free_all(rcw_handle* h)
 {
     void** ptrs[] = {&h->d_pos, &h->d_dir, &h->d_goal, &h->d_reward, &h->d_done, &h->d_episode,
                      &h->d_tile_map, &h->d_dir_table, &h->d_ray_table, &h->d_obs, &h->d_col_h,
-                     &h->d_col_c, &h->d_err, &h->d_status, &h->d_actions, &h->d_mask, &h->d_in_goal,
+                     &h->d_col_c, &h->d_err, &h->d_status, &h->d_top_view, &h->d_actions, &h->d_mask, &h->d_in_goal,
                      &h->d_in_pos, &h->d_in_dir};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -195,6 +197,8 @@ int validate_config(const rcw_config* c, int32_t batch)
         return fail(RCW_ERR_INVALID_ARGUMENT, "position_increment_wu must be positive and finite");
     if (!(c->semi_field_of_view_wu > 0.0f) || !std::isfinite(c->semi_field_of_view_wu))
         return fail(RCW_ERR_INVALID_ARGUMENT, "semi_field_of_view_wu must be positive and finite");
+    if (c->render_top_view && (c->pu_per_tu < 1 || c->pu_per_tu > 4096))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "pu_per_tu must be in 1..4096 for the top view");
     if (!(c->camera_height_tile_wu > 0.0f) || !std::isfinite(c->camera_height_tile_wu))
         return fail(RCW_ERR_INVALID_ARGUMENT, "camera_height_tile_wu must be positive and finite");
     if (c->dda_tie_break < 0 || c->dda_tie_break > 1 || c->dda_distance < 0 || c->dda_distance > 1 ||
@@ -336,6 +340,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     RCW_TRY(hipMalloc(&h->d_obs, B * (size_t)N * Hc * sizeof(uint32_t)));
     RCW_TRY(hipMalloc(&h->d_col_h, B * (size_t)N * sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_col_c, B * (size_t)N));
+    if (cfg->render_top_view)
+        RCW_TRY(hipMalloc(&h->d_top_view, B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)));
     RCW_TRY(hipMalloc(&h->d_err, sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_status, B * sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_actions, B));
@@ -377,6 +383,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.dir_table = (const float2*)h->d_dir_table; d.ray_table = (const float*)h->d_ray_table;
     d.obs = (uint32_t*)h->d_obs; d.col_h = (int32_t*)h->d_col_h; d.col_c = (uint8_t*)h->d_col_c;
     d.err = (int32_t*)h->d_err;
+    d.top_view = (uint32_t*)h->d_top_view; d.pu = cfg->pu_per_tu;
     d.status = (int32_t*)h->d_status;
     d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;
     d.fill_grid = 256; d.fill_plain = 0;
@@ -545,6 +552,27 @@ int rcw_obs_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count
     rc = sync_and_check(h);
     const size_t frame = (size_t)h->cfg.num_rays * h->cfg.height_camera_view_pu;
     RCW_HIP(hipMemcpy(out_host, h->dev.obs + (size_t)first * frame, (size_t)count * frame * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int rcw_top_view_device_ptr(rcw_handle* h, void** device_ptr)
+{
+    if (!h || !device_ptr) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
+    *device_ptr = h->d_top_view;
+    return RCW_OK;
+}
+
+int rcw_top_view_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
+    if (!out_host || first < 0 || count < 0 || first + (int64_t)count > h->B)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
+    rc = sync_and_check(h);
+    const size_t frame = (size_t)h->cfg.height_tile_map_tu * h->cfg.width_tile_map_tu * h->cfg.pu_per_tu * h->cfg.pu_per_tu;
+    RCW_HIP(hipMemcpy(out_host, (uint32_t*)h->d_top_view + (size_t)first * frame, (size_t)count * frame * sizeof(uint32_t),
                       hipMemcpyDeviceToHost));
     return rc;
 }

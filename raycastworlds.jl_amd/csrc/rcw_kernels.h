@@ -44,6 +44,8 @@ struct RcwDev {
     uint32_t* obs;           // camera_view UInt32 (Hc, N, B)
     int32_t* col_h;          // (N, B) height_line_pu by image column
     uint8_t* col_c;          // (N, B) colour id by image column
+    uint32_t* top_view;      // optional env.top_view UInt32 (H*pu, W*pu, B)  SR:302
+    int32_t pu;              // pu_per_tu
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
     int32_t* status;         // per-agent sticky status
 };
@@ -64,6 +66,8 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
                            hipStream_t s);
 hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
                            long long total_cols, const uint8_t* mask_dev, hipStream_t s);
+// update_top_view!(env) SR:446-483 for every (unmasked) agent; needs p.top_view
+hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const float2* pos,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);

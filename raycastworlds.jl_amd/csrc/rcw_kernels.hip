@@ -463,6 +463,106 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
     }
 }
 
+// ---- update_top_view!(env)  SR:446-483 (+ draw_tile_map! SR:342-372) ----------------------------
+// The reference's debug view: tile squares with a grid, one line per ray, the player circle.  Not
+// an observation and off by default (cfg.render_top_view).  One workgroup per agent, three phases
+// separated by barriers (a later phase overwrites pixels of an earlier one, as in the reference).
+// The line and circle rasterisers are SimpleDraw 0.3's (un-vendored): Bresenham and the midpoint
+// circle are ASSUMED — parity unpinned.
+__device__ __forceinline__ void put_pixel(uint32_t* img, int Ht, int Wt, int i, int j, uint32_t c)
+{
+    if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) img[(size_t)(i - 1) + (size_t)Ht * (j - 1)] = c;
+}
+__device__ __forceinline__ int wu_to_pu(float x, int pu) { return (int)floorf(x * (float)pu) + 1; }   // UT:6
+
+__device__ __forceinline__ uint32_t top_view_tile_pixel(const uint8_t* tb, int H, int pu, int ip0, int jp0)
+{
+    const int i = ip0 / pu, j = jp0 / pu;                   // 0-based tile
+    const int ri = ip0 - i * pu, rj = jp0 - j * pu;
+    if (ri == 0 || ri == pu - 1 || rj == 0 || rj == pu - 1) return 0x00ccccccu;   // SR:364-367
+    const uint32_t bits = tb[i + H * j];
+    return (bits & 1u) ? 0x00FFFFFFu : ((bits & 2u) ? 0x00FF0000u : 0x00000000u); // findfirst SR:355-360, colours SR:288
+}
+
+template <bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int a = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (mask != nullptr && mask[a] == 0) return;
+    uint8_t* tb = reinterpret_cast<uint8_t*>(lds);
+    stage_tile_bytes(tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kBlock);
+    __syncthreads();
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu;
+    uint32_t* img = p.top_view + (size_t)a * Ht * Wt;
+
+    // ---- draw_tile_map!: each tile's square and its one-pixel frame.  Tiles do not overlap, so the
+    // reference's tile-by-tile order does not matter; rows of a column are contiguous (column-major).
+    if ((Ht & 3) == 0) {
+        const int vpc = Ht >> 2;
+        u32x4* out = reinterpret_cast<u32x4*>(img);
+        for (int idx = tid; idx < vpc * Wt; idx += kBlock) {
+            const int jp0 = idx / vpc, ip0 = (idx - jp0 * vpc) * 4;
+            u32x4 v;
+            v.x = top_view_tile_pixel(tb, p.H, pu, ip0 + 0, jp0);
+            v.y = top_view_tile_pixel(tb, p.H, pu, ip0 + 1, jp0);
+            v.z = top_view_tile_pixel(tb, p.H, pu, ip0 + 2, jp0);
+            v.w = top_view_tile_pixel(tb, p.H, pu, ip0 + 3, jp0);
+            out[idx] = v;
+        }
+    } else {
+        for (int idx = tid; idx < Ht * Wt; idx += kBlock) {
+            const int jp0 = idx / Ht;
+            img[idx] = top_view_tile_pixel(tb, p.H, pu, idx - jp0 * Ht, jp0);
+        }
+    }
+    __syncthreads();   // (waits for the stores above: the lines below overwrite some of those pixels)
+
+    // ---- one line per ray from the player to the ray's stop point  SR:473-477 ----
+    const float2 pos = p.pos[a];
+    const int d = p.dir[a];
+    const int ip = wu_to_pu(pos.x, pu), jp = wu_to_pu(pos.y, pu);            // SR:468
+    const float* tab = p.ray_table + (size_t)d * RCW_TABLE_ROWS * p.N;
+    for (int i = tid; i < p.N; i += kBlock) {
+        const float dx = tab[i], dy = tab[p.N + i];
+        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+                                                    tab[3 * p.N + i]);
+        const float dist = r.oob ? 0.0f : r.dist;
+        const float ox = dist * dx, oy = dist * dy;                          // ray_distance_wu * ray_direction_wu
+        const float ex = pos.x + ox, ey = pos.y + oy;
+        int i1 = ip, j1 = jp;
+        const int i2 = wu_to_pu(ex, pu), j2 = wu_to_pu(ey, pu);
+        // SD.Line: Bresenham, all octants, both end points (assumed)
+        const int di = abs(i2 - i1), dj = -abs(j2 - j1);
+        const int si = i1 < i2 ? 1 : -1, sj = j1 < j2 ? 1 : -1;
+        int err = di + dj;
+        for (int guard = 0; guard <= Ht + Wt + 4 * pu; ++guard) {           // a line has at most di - dj + 1 pixels
+            put_pixel(img, Ht, Wt, i1, j1, 0x00808080u);                     // ray_color SR:289
+            if (i1 == i2 && j1 == j2) break;
+            const int e2 = 2 * err;
+            if (e2 >= dj) { err += dj; i1 += si; }
+            if (e2 <= di) { err += di; j1 += sj; }
+        }
+    }
+    __syncthreads();
+
+    // ---- the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed) ----
+    if (tid == 0) {
+        const int rp = wu_to_pu(p.radius, pu);                               // SR:469
+        int x = 0, y = rp, dd = 1 - rp;
+        while (x <= y) {
+            put_pixel(img, Ht, Wt, ip + x, jp + y, 0x00c0c0c0u); put_pixel(img, Ht, Wt, ip - x, jp + y, 0x00c0c0c0u);
+            put_pixel(img, Ht, Wt, ip + x, jp - y, 0x00c0c0c0u); put_pixel(img, Ht, Wt, ip - x, jp - y, 0x00c0c0c0u);
+            put_pixel(img, Ht, Wt, ip + y, jp + x, 0x00c0c0c0u); put_pixel(img, Ht, Wt, ip - y, jp + x, 0x00c0c0c0u);
+            put_pixel(img, Ht, Wt, ip + y, jp - x, 0x00c0c0c0u); put_pixel(img, Ht, Wt, ip - y, jp - x, 0x00c0c0c0u);
+            x += 1;
+            if (dd < 0) dd += 2 * x + 1;
+            else { y -= 1; dd += 2 * (x - y) + 1; }
+        }
+    }
+}
+
 }  // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -503,6 +603,19 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
     } else {
         if (p.dist_pre) hipLaunchKernelGGL((rcw_cast_kernel<false, true>), grid, block, lds, s, p, actions_dev, mask_dev);
         else            hipLaunchKernelGGL((rcw_cast_kernel<false, false>), grid, block, lds, s, p, actions_dev, mask_dev);
+    }
+    return hipGetLastError();
+}
+
+hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
+{
+    const size_t lds = rcw_step_lds_bytes(p);
+    if (p.tie_le) {
+        if (p.dist_pre) hipLaunchKernelGGL((rcw_top_view_kernel<true, true>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
+        else            hipLaunchKernelGGL((rcw_top_view_kernel<true, false>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
+    } else {
+        if (p.dist_pre) hipLaunchKernelGGL((rcw_top_view_kernel<false, true>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
+        else            hipLaunchKernelGGL((rcw_top_view_kernel<false, false>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
     }
     return hipGetLastError();
 }

@@ -214,6 +214,7 @@ class SingleRoom:
         dda_distance: int = 0,
         normalize_mode: int = 0,
         out_of_bounds: int = 0,
+        render_top_view: bool = False,
     ):
         if str(T) not in ("Float32", "float32", "<class 'numpy.float32'>") or str(R) not in (
             "Float32", "float32", "<class 'numpy.float32'>"):
@@ -236,6 +237,7 @@ class SingleRoom:
         cfg.dda_distance = dda_distance
         cfg.normalize_mode = normalize_mode
         cfg.out_of_bounds = out_of_bounds
+        cfg.render_top_view = 1 if render_top_view else 0
         self.cfg = cfg
         self.batch = int(batch)
         self.device = int(device)
@@ -297,6 +299,23 @@ class SingleRoom:
         """The observation batch, aliased (SR:300, SR:576): uint32 (B, N, H_cam) in C order."""
         return DeviceArray(self._obs_ptr(), (self.batch, self.cfg.num_rays, self.cfg.height_camera_view_pu),
                            np.uint32, self, self._sync)
+
+    @property
+    def top_view(self) -> DeviceArray:
+        """`env.top_view` (SR:302, needs render_top_view=True): uint32 (B, W*pu, H*pu) in C order ==
+        Julia (H*pu, W*pu, B)."""
+        p = C.c_void_p()
+        _capi.check(self._lib.rcw_top_view_device_ptr(self._h, C.byref(p)))
+        pu = self.cfg.pu_per_tu
+        return DeviceArray(p.value, (self.batch, self.cfg.width_tile_map_tu * pu, self.cfg.height_tile_map_tu * pu),
+                           np.uint32, self, self._sync)
+
+    def top_view_host(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        n = self.batch - first if count is None else count
+        pu = self.cfg.pu_per_tu
+        out = np.empty((n, self.cfg.width_tile_map_tu * pu, self.cfg.height_tile_map_tu * pu), dtype=np.uint32)
+        _capi.check(self._lib.rcw_top_view_copy(self._h, _as_ptr(out), first, n))
+        return out
 
     def camera_view_host(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         n = self.batch - first if count is None else count
@@ -469,6 +488,12 @@ def cast_rays_(env: SingleRoom, first: int = 0, count: Optional[int] = None):
 def update_camera_view_(env: SingleRoom) -> None:
     """`RCW.update_camera_view!(env)` SR:374-444.  The engine renders as part of every
     reset/act/set_state, so the view is always current; this only waits for the GPU."""
+    env.sync()
+
+
+def update_top_view_(env: SingleRoom) -> None:
+    """`RCW.update_top_view!(env)` SR:446-483: rendered with every reset/act/set_state when the env
+    was built with render_top_view=True; this only waits for the GPU."""
     env.sync()
 
 

@@ -256,3 +256,28 @@ def test_custom_direction_table(rcw, oracle):
     rng = np.random.default_rng(0)
     _rollout(rcw, env, orc, 30, rng, check_every=10, rays_every=10)
     env.close()
+
+
+def test_top_view_matches_oracle(rcw, oracle):
+    """update_top_view! SR:446-483 (opt-in): tiles + grid, one line per ray, the player circle."""
+    rng = np.random.default_rng(13)
+    for kw in (dict(pu_per_tu=32, **CFG1), dict(pu_per_tu=32), dict(pu_per_tu=10, **CFG2),
+               dict(pu_per_tu=7, height_tile_map_tu=9, width_tile_map_tu=12, num_rays=100)):
+        env, orc = _make(rcw, oracle, 12, seed=17, render_top_view=1, **kw)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
+        for s in range(40):
+            a = rng.integers(1, 5, env.batch).astype(np.uint8)
+            rcw.act_(env, a)
+            assert orc.step(a) == 0
+            try:
+                env.sync()
+            except IndexError:
+                env.clear_error(); orc.clear_status()
+            if s % 8 == 7:
+                np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"step {s} {kw}")
+        mask = (rng.random(env.batch) < 0.5).astype(np.uint8)
+        rcw.reset_(env, mask=mask, seed=5)
+        orc.reset(mask=mask, seed=5)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after masked reset {kw}")
+        assert_state_equal(env, orc, where=f"camera path unaffected {kw}")
+        env.close()

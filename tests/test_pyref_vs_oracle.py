@@ -62,3 +62,45 @@ def test_all_headings_ray_fan(oracle):
         w.dir = d
         fan = oracle.ray_fan(cfg, oracle.direction_table(128)[d])
         np.testing.assert_array_equal(fan.view(np.uint32), np.array(w.ray_fan(), dtype=np.float32).view(np.uint32))
+
+
+def test_top_view_two_restatements_agree(oracle):
+    """update_top_view! SR:446-483 restated twice (C and Python) — same pixels."""
+    for H, W, N, pu in ((8, 8, 64, 32), (8, 16, 40, 16), (6, 7, 33, 9)):
+        orc = oracle.OracleBatch(1, seed=H + N, height_tile_map_tu=H, width_tile_map_tu=W, num_rays=N,
+                                 render_top_view=1, pu_per_tu=pu, out_of_bounds=1)
+        w = pyref.World(H=H, W=W, num_rays=N)
+        w.set_state(orc.goal[0], orc.position[0], orc.direction[0])
+        rng = np.random.default_rng(pu)
+        for s in range(25):
+            a = int(rng.integers(1, 5))
+            orc.step([a])
+            try:
+                w.step(a)
+            except IndexError:          # reference BoundsError: with out_of_bounds=1 the oracle blocks the move
+                w.cast_rays(); w.update_camera_view()
+        w.update_top_view(pu)
+        np.testing.assert_array_equal(w.top_view, orc.top_view[0])
+
+
+def test_top_view_certain_parts_by_hand(oracle):
+    """The parts of the top view that do not depend on SimpleDraw's rasterisers, derived by hand from
+    SR:342-372: tile (i, j) occupies pixels (i-1)pu+1..i pu in both axes, its outermost pixel ring is
+    0x00cccccc, the inside is white for walls, red for the goal, black for free tiles; the player's own
+    pixel wu_to_pu.(position) lies on the first pixel of every ray line (0x00808080 unless the circle,
+    radius floor(r pu)+1 = 5 at pu 32, covers it — it does not cover the centre)."""
+    pu = 32
+    orc = oracle.OracleBatch(1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, render_top_view=1, pu_per_tu=pu)
+    orc.set_state([[7, 2]], [[4.5, 4.5]], [0])
+    tv = orc.top_view[0]                      # [jp-1][ip-1]
+    px = lambda ip, jp: int(tv[jp - 1, ip - 1])
+    assert px(1, 1) == 0xCCCCCC and px(32, 32) == 0xCCCCCC and px(33, 1) == 0xCCCCCC      # frames
+    assert px(2, 2) == 0xFFFFFF and px(16, 16) == 0xFFFFFF                                # wall tile (1,1) inside
+    assert px(6 * pu + 2, 1 * pu + 2) == 0xFF0000 and px(7 * pu - 1, 2 * pu - 1) == 0xFF0000   # goal tile (7,2) inside
+    assert px(6 * pu + 1, 1 * pu + 1) == 0xCCCCCC                                          # goal tile frame
+    assert px(2 * pu + 2, 2 * pu + 2) == 0x000000                                          # free tile (3,3), away from the fan
+    ip = jp = int(np.floor(4.5 * pu)) + 1                                                  # 145
+    assert px(ip, jp) == 0x808080                                                          # start of every ray line
+    assert px(ip + 5, jp) == 0xC0C0C0 and px(ip, jp + 5) == 0xC0C0C0 and px(ip - 5, jp) == 0xC0C0C0   # circle's axis points
+    # facing +x: the central ray runs straight down the i axis to the wall face x = 7 -> pixel 7*32+1 = 225
+    assert px(200, jp) == 0x808080 and px(225, jp) == 0x808080 and px(226, jp) != 0x808080
