@@ -262,7 +262,8 @@ def test_top_view_matches_oracle(rcw, oracle):
     """update_top_view! SR:446-483 (opt-in): tiles + grid, one line per ray, the player circle."""
     rng = np.random.default_rng(13)
     for kw in (dict(pu_per_tu=32, **CFG1), dict(pu_per_tu=32), dict(pu_per_tu=10, **CFG2),
-               dict(pu_per_tu=7, height_tile_map_tu=9, width_tile_map_tu=12, num_rays=100)):
+               dict(pu_per_tu=7, height_tile_map_tu=9, width_tile_map_tu=12, num_rays=100),
+               dict(pu_per_tu=32, **CFG3)):      # 512 x 512 px: too big for the LDS bit planes -> in-place path
         env, orc = _make(rcw, oracle, 12, seed=17, render_top_view=1, **kw)
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
         for s in range(40):
