@@ -12,7 +12,7 @@ where stepping the rendering oracle would take minutes:
 import numpy as np
 import pytest
 
-from helpers import CFG2, CFG3, CFG5
+from helpers import CFG1, CFG2, CFG3, CFG5
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -96,4 +96,46 @@ def test_turn_left_then_right_restores_the_frame(rcw):
     after = env.camera_view.torch()
     assert torch.equal(before.view(torch.int32), after.view(torch.int32))
     assert not torch.equal(before.view(torch.int32), middle.view(torch.int32))
+    env.close()
+
+
+def test_sharded_wrapper_world_of_one(rcw, oracle):
+    """ShardedSingleRoom on one rank: stepping is local, and the compact gather + on-device expansion
+    (rcw_expand_columns) reproduces the engine's own frames."""
+    sh = rcw.ShardedSingleRoom(256, rank=0, world=1, device=0, seed=6, out_of_bounds=1, **CFG2)
+    orc = oracle.OracleBatch(256, seed=6, out_of_bounds=1, **CFG2)
+    rng = np.random.default_rng(8)
+    for s in range(30):
+        a = rng.integers(1, 5, 256).astype(np.uint8)
+        sh.act_(sh.local_slice(a))
+        orc.step(a)
+    frames_c = sh.gather_observations("columns")
+    frames_f = sh.gather_observations("frames")
+    assert torch.equal(frames_c.view(torch.int32), frames_f.view(torch.int32))
+    np.testing.assert_array_equal(frames_c.cpu().numpy().view(np.uint32), orc.camera_view)
+    sh.close()
+
+
+def test_long_rollout_with_auto_reset_stays_in_parity(rcw, oracle):
+    """5000 steps x 512 agents with auto-reset: thousands of episodes end and restart on the device;
+    state, episode counters and descriptors are compared with the oracle every 500 steps."""
+    kw = dict(seed=12, auto_reset=True, out_of_bounds=1, **CFG1)
+    env = rcw.SingleRoomModule.SingleRoom(batch=512, **kw)
+    orc = oracle.OracleBatch(512, seed=12, render=False, auto_reset=1, out_of_bounds=1, **CFG1)
+    rng = np.random.default_rng(3)
+    for s in range(5000):
+        a = rng.integers(1, 5, 512).astype(np.uint8)
+        rcw.act_(env, a)
+        orc.step(a)
+        if s % 500 == 499:
+            w = env.world
+            np.testing.assert_array_equal(w.episode, orc.episode, err_msg=f"episodes at step {s}")
+            np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
+            np.testing.assert_array_equal(w.player_direction_au, orc.direction)
+            np.testing.assert_array_equal(w.goal_position, orc.goal)
+            h, c = env.columns()
+            np.testing.assert_array_equal(h, orc.col_height)
+            np.testing.assert_array_equal(c, orc.col_colour)
+    assert int(env.world.episode.sum()) > 512 + 100, "expected hundreds of episode restarts"
+    check_frames_against_descriptors(env)
     env.close()
