@@ -159,7 +159,8 @@ RCW_API int rcw_set_direction_table(rcw_handle* h, const float* directions_wu);
  * handle's own stream.  The caller keeps the stream alive. */
 RCW_API int rcw_set_stream(rcw_handle* h, void* hip_stream);
 /* Render into a caller-owned DEVICE buffer of B*N*H_cam UInt32 instead of the
- * library's (NULL restores it).  Takes effect at the next render. */
+ * library's (NULL restores it).  Takes effect at the next render; does not synchronise, so a
+ * caller can alternate two buffers while the previous frame batch is still being consumed. */
 RCW_API int rcw_bind_obs(rcw_handle* h, void* device_ptr);
 
 /* RCW.reset!(env) SR:326-331 -> SR:110-137 for the agents whose mask byte is non-zero

@@ -446,9 +446,10 @@ int rcw_set_stream(rcw_handle* h, void* hip_stream)
 int rcw_bind_obs(rcw_handle* h, void* device_ptr)
 {
     int rc = check_handle(h); if (rc) return rc;
-    RCW_HIP(hipStreamSynchronize(h->stream));
     if (device_ptr && ((uintptr_t)device_ptr & 15u))
         return fail(RCW_ERR_INVALID_ARGUMENT, "observation buffer must be 16-byte aligned");
+    // No synchronisation: the pointer travels in the kernel arguments of the launches that follow,
+    // work already enqueued keeps the buffer it was launched with (double-buffered observations).
     h->dev.obs = device_ptr ? (uint32_t*)device_ptr : (uint32_t*)h->d_obs;
     return RCW_OK;
 }

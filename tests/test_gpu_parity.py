@@ -282,3 +282,32 @@ def test_top_view_matches_oracle(rcw, oracle):
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after masked reset {kw}")
         assert_state_equal(env, orc, where=f"camera path unaffected {kw}")
         env.close()
+
+
+def test_caller_stream_and_caller_buffer(rcw, oracle):
+    """rcw_set_stream + rcw_bind_obs: the engine runs on torch's stream and renders straight into a
+    torch tensor, so torch ops on that stream see the frames without any host synchronisation."""
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 64, seed=19, **CFG2)
+    stream = torch.cuda.Stream()
+    frames = torch.zeros((2, 64, 256, 256), dtype=torch.int32, device="cuda")     # two observation slots
+    torch.cuda.synchronize()
+    env.set_stream(stream.cuda_stream)
+    rng = np.random.default_rng(4)
+    sums = []
+    with torch.cuda.stream(stream):
+        for s in range(20):
+            env.bind_obs(frames[s & 1].data_ptr())                                  # double-buffered observations
+            a = rng.integers(1, 5, 64).astype(np.uint8)
+            rcw.act_(env, torch.from_numpy(a).to("cuda", non_blocking=False))
+            orc.step(a)
+            sums.append((frames[s & 1].to(torch.int64).sum(), int(orc.camera_view.astype(np.int64).sum())))
+    stream.synchronize()
+    for got, want in sums:
+        assert int(got) == want
+    np.testing.assert_array_equal(frames[1].cpu().numpy().view(np.uint32), orc.camera_view)   # step 19 -> slot 1
+    env.set_stream(None)
+    env.bind_obs(None)
+    rcw.act_(env, 3); orc.step(np.full(64, 3, np.uint8))
+    assert_state_equal(env, orc, where="back on the handle's own stream and buffer")
+    env.close()
