@@ -311,3 +311,39 @@ def test_caller_stream_and_caller_buffer(rcw, oracle):
     rcw.act_(env, 3); orc.step(np.full(64, 3, np.uint8))
     assert_state_equal(env, orc, where="back on the handle's own stream and buffer")
     env.close()
+
+
+def test_error_paths_fail_loudly(rcw):
+    """Bad configs / arguments come back as errors (never a silent fallback), with a message."""
+    SR = rcw.SingleRoomModule.SingleRoom
+    from raycastworlds_jl_amd import _capi
+
+    for bad in (dict(height_tile_map_tu=2), dict(num_rays=0), dict(player_radius_wu=0.5), dict(player_radius_wu=0.0),
+                dict(position_increment_wu=-1.0), dict(semi_field_of_view_wu=float("nan")), dict(num_directions=0),
+                dict(height_camera_view_pu=0), dict(dda_tie_break=7), dict(out_of_bounds=3)):
+        with pytest.raises(ValueError):
+            SR(batch=4, **bad)
+    with pytest.raises(ValueError):
+        SR(batch=0)
+    with pytest.raises(_capi.RcwError) as ei:
+        SR(batch=4, device=99)
+    assert ei.value.code == _capi.RCW_ERR_NO_DEVICE
+    with pytest.raises(NotImplementedError):
+        SR(batch=4, T="Float64")
+    env = SR(batch=4, **CFG1)
+    with pytest.raises(ValueError):
+        env.set_state([[1, 2]] * 4, [[4.5, 4.5]] * 4, [0] * 4)            # goal on the wall ring
+    with pytest.raises(ValueError):
+        env.set_state([[2, 2]] * 4, [[0.5, 4.5]] * 4, [0] * 4)            # player outside the room
+    with pytest.raises(ValueError):
+        env.set_state([[2, 2]] * 4, [[4.5, 4.5]] * 4, [128] * 4)          # heading out of range
+    with pytest.raises(ValueError):
+        env.camera_view_host(2, 5)                                         # agent range past the batch
+    with pytest.raises(ValueError):
+        rcw.act_(env, [1, 2, 3])                                           # wrong number of actions
+    with pytest.raises(_capi.RcwError):
+        env.top_view_host()                                                # not built with render_top_view
+    env.sync()                                                             # the handle is still healthy
+    rcw.act_(env, 1)
+    env.sync()
+    env.close()
