@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RCW_ABI_VERSION 1
+#define RCW_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define RCW_API __attribute__((visibility("default")))
@@ -135,7 +135,18 @@ typedef struct rcw_config {
                                          (update_top_view! SR:446-483); default 0 — the
                                          reference always does, but it is a debug view, not the
                                          observation, and it doubles the bytes per step          */
-    int32_t  reserved[5];
+    int32_t  world_unit_bits;         /* T of SingleRoom(; T = ...) SR:259: 32 (Float32, default) or 64
+                                         (Float64).  With 64 the four world-unit parameters are
+                                         taken from the *_f64 fields below (convert(T, 2/3) is
+                                         not the Float32 value widened), positions / rays / tables
+                                         cross the boundary as double (the *64 entry points), and
+                                         every Float32 operation of the path becomes the same
+                                         Float64 operation.  R (reward) stays Float32.            */
+    double   player_radius_wu_f64;    /* SR:263 convert(Float64, 1/8)                           */
+    double   position_increment_wu_f64;
+    double   semi_field_of_view_wu_f64;
+    double   camera_height_tile_wu_f64;
+    int32_t  reserved[4];
 } rcw_config;
 
 typedef struct rcw_handle rcw_handle;   /* opaque */
@@ -179,6 +190,17 @@ RCW_API int rcw_reset(rcw_handle* h, const uint8_t* mask_host, uint64_t seed);
  * goal bit, sets the new one, zeroes reward/done, casts and renders. */
 RCW_API int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_wu,
                   const int32_t* direction_au, const uint8_t* mask_host);
+
+/* Float64 worlds (cfg.world_unit_bits = 64): the same calls with double arrays.  The Float32
+ * forms return RCW_ERR_UNSUPPORTED on a Float64 handle and vice versa. */
+RCW_API int rcw_set_state64(rcw_handle* h, const int32_t* goal_ij, const double* position_wu,
+                            const int32_t* direction_au, const uint8_t* mask_host);
+RCW_API int rcw_position64(rcw_handle* h, double* out_host /* (2, B) */);
+RCW_API int rcw_rays64(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int64_t* hit_dimension,
+                       double* distance_wu, double* directions_wu);
+RCW_API int rcw_set_direction_table64(rcw_handle* h, const double* directions_wu);
+RCW_API int rcw_ray_table64(rcw_handle* h, double* out_host);
+RCW_API int rcw_direction_table64(rcw_handle* h, double* out_host);
 
 /* RCW.act!(env, action) SR:333-340 (minus update_top_view!) for every agent:
  * dynamics SR:139-191 -> cast_rays! SR:195-231 -> update_camera_view! SR:374-444.

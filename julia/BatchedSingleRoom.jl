@@ -29,9 +29,9 @@ const librcw = get(ENV, "LIBRCW_HIP", "librcw_hip.so")
 
 const NUM_ACTIONS = 4   # src/single_room.jl:19
 
-# struct rcw_config (include/rcw.h) — field order and types must match exactly (128 bytes)
+# struct rcw_config (include/rcw.h) — field order and types must match exactly (160 bytes)
 Base.@kwdef mutable struct RcwConfig
-    abi_version::Int32 = 1
+    abi_version::Int32 = 2
     height_tile_map_tu::Int32 = 8
     width_tile_map_tu::Int32 = 16
     num_directions::Int32 = 128
@@ -57,7 +57,12 @@ Base.@kwdef mutable struct RcwConfig
     write_columns::Int32 = 1
     out_of_bounds::Int32 = 0
     render_top_view::Int32 = 0
-    reserved::NTuple{5, Int32} = (0, 0, 0, 0, 0)
+    world_unit_bits::Int32 = 32
+    player_radius_wu_f64::Float64 = 1 / 8
+    position_increment_wu_f64::Float64 = 1 / 8
+    semi_field_of_view_wu_f64::Float64 = 2 / 3
+    camera_height_tile_wu_f64::Float64 = 1
+    reserved::NTuple{4, Int32} = (0, 0, 0, 0)
 end
 
 struct RcwError <: Exception

@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "librcw_oracle.so")
+_LIB64_PATH = os.path.join(_HERE, "_build", "librcw_oracle64.so")   # the same source with T = Float64
 
 
 class RcwConfig(C.Structure):
@@ -47,14 +48,19 @@ class RcwConfig(C.Structure):
         ("write_columns", C.c_int32),
         ("out_of_bounds", C.c_int32),
         ("render_top_view", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("world_unit_bits", C.c_int32),
+        ("player_radius_wu_f64", C.c_double),
+        ("position_increment_wu_f64", C.c_double),
+        ("semi_field_of_view_wu_f64", C.c_double),
+        ("camera_height_tile_wu_f64", C.c_double),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
 def default_config(**overrides) -> RcwConfig:
     """Reference defaults SR:258-272, SR:288-296 (restated, not read from the product)."""
     cfg = RcwConfig()
-    cfg.abi_version = 1
+    cfg.abi_version = 2
     cfg.height_tile_map_tu = 8
     cfg.width_tile_map_tu = 16
     cfg.num_directions = 128
@@ -73,6 +79,11 @@ def default_config(**overrides) -> RcwConfig:
     cfg.goal_dim_1_color = 0x00800000
     cfg.goal_dim_2_color = 0x00C00000
     cfg.write_columns = 1
+    cfg.world_unit_bits = 32
+    cfg.player_radius_wu_f64 = 1 / 8
+    cfg.position_increment_wu_f64 = 1 / 8
+    cfg.semi_field_of_view_wu_f64 = 2 / 3
+    cfg.camera_height_tile_wu_f64 = 1.0
     for k, v in overrides.items():
         if not hasattr(cfg, k):
             raise TypeError(f"unknown config field {k!r}")
@@ -84,25 +95,23 @@ def build(force: bool = False) -> str:
     """Compile the C restatement (gcc, strict IEEE).  Building the checker is not using it."""
     src = os.path.join(_HERE, "rcw_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "rcw.h")
-    stale = (
-        force
-        or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
-    )
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+    stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in (_LIB_PATH, _LIB64_PATH))
     if stale:
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
                        stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib() -> C.CDLL:
-    global _lib
-    if _lib is None:
+def lib(bits: int = 32) -> C.CDLL:
+    """The oracle for world-unit type Float32 (bits=32) or Float64 (bits=64)."""
+    if bits not in _libs:
         build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_LIB_PATH if bits == 32 else _LIB64_PATH)
+        real = C.c_float if bits == 32 else C.c_double
         vp = C.c_void_p
         L.orc_create.argtypes = [C.POINTER(RcwConfig), C.c_int32, C.c_uint64, C.c_int, C.POINTER(vp)]
         L.orc_create.restype = C.c_int
@@ -123,10 +132,9 @@ def lib() -> C.CDLL:
         L.orc_direction_table.restype = None
         L.orc_ray_fan.argtypes = [C.POINTER(RcwConfig), vp, vp]
         L.orc_ray_fan.restype = None
-        L.orc_cast_ray.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
-                                   C.c_float, C.c_int32, C.c_int32, vp, vp, vp, vp]
-        L.orc_is_player_colliding.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                              C.c_float, C.c_int32]
+        L.orc_cast_ray.argtypes = [vp, C.c_int32, C.c_int32, real, real, real, real, C.c_int32, C.c_int32,
+                                   vp, vp, vp, vp]
+        L.orc_is_player_colliding.argtypes = [vp, C.c_int32, C.c_int32, real, real, real, C.c_int32]
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
         for name in ("camera_view", "top_view", "reward", "done", "position", "direction", "goal", "episode",
@@ -135,8 +143,8 @@ def lib() -> C.CDLL:
             f = getattr(L, "orc_" + name)
             f.argtypes = [vp]
             f.restype = vp
-        _lib = L
-    return _lib
+        _libs[bits] = L
+    return _libs[bits]
 
 
 def _view(ptr, dtype, shape):
@@ -158,8 +166,10 @@ class OracleBatch:
                  **overrides):
         self.cfg = config if config is not None else default_config(**overrides)
         self.B = int(batch)
+        self.bits = 64 if self.cfg.world_unit_bits == 64 else 32
+        self.real = np.float64 if self.bits == 64 else np.float32   # the reference's T
         self._h = C.c_void_p()
-        rc = lib().orc_create(C.byref(self.cfg), self.B, seed, 1 if render else 0, C.byref(self._h))
+        rc = lib(self.bits).orc_create(C.byref(self.cfg), self.B, seed, 1 if render else 0, C.byref(self._h))
         if rc != 0:
             raise ValueError(f"orc_create failed: {rc}")
         self.render = render
@@ -171,7 +181,7 @@ class OracleBatch:
 
     def close(self):
         if self._h:
-            lib().orc_destroy(self._h)
+            lib(self.bits).orc_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -183,38 +193,38 @@ class OracleBatch:
     # --- RCW.reset! / act! ---------------------------------------------------------
     def reset(self, mask=None, seed: int = 0):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        rc = lib().orc_reset(self._h, _p(m), seed)
+        rc = lib(self.bits).orc_reset(self._h, _p(m), seed)
         if rc:
             raise ValueError(rc)
 
     def set_state(self, goal_ij, position_wu, direction_au, mask=None):
         g = np.ascontiguousarray(goal_ij, dtype=np.int32).reshape(self.B, 2)
-        p = np.ascontiguousarray(position_wu, dtype=np.float32).reshape(self.B, 2)
+        p = np.ascontiguousarray(position_wu, dtype=self.real).reshape(self.B, 2)
         d = np.ascontiguousarray(direction_au, dtype=np.int32).reshape(self.B)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        rc = lib().orc_set_state(self._h, _p(g), _p(p), _p(d), _p(m))
+        rc = lib(self.bits).orc_set_state(self._h, _p(g), _p(p), _p(d), _p(m))
         if rc:
             raise ValueError(f"orc_set_state: {rc}")
 
     def set_direction_table(self, dirs):
-        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(self.nd, 2)
-        lib().orc_set_direction_table(self._h, _p(d))
+        d = np.ascontiguousarray(dirs, dtype=self.real).reshape(self.nd, 2)
+        lib(self.bits).orc_set_direction_table(self._h, _p(d))
 
     def step(self, actions) -> int:
         a = np.ascontiguousarray(actions, dtype=np.uint8).reshape(self.B)
-        return lib().orc_step(self._h, _p(a))
+        return lib(self.bits).orc_step(self._h, _p(a))
 
     def step_lenient(self, actions) -> int:
         """rcw_step_device semantics: agents with an invalid action are skipped, not rejected."""
         a = np.ascontiguousarray(actions, dtype=np.uint8).reshape(self.B)
-        return lib().orc_step_lenient(self._h, _p(a))
+        return lib(self.bits).orc_step_lenient(self._h, _p(a))
 
     def clear_status(self):
-        lib().orc_clear_status(self._h)
+        lib(self.bits).orc_clear_status(self._h)
 
     # --- state ---------------------------------------------------------------------
     def _g(self, name, dtype, shape):
-        return _view(getattr(lib(), "orc_" + name)(self._h), dtype, shape)
+        return _view(getattr(lib(self.bits), "orc_" + name)(self._h), dtype, shape)
 
     @property
     def camera_view(self):
@@ -238,7 +248,7 @@ class OracleBatch:
 
     @property
     def position(self):
-        return self._g("position", np.float32, (self.B, 2))
+        return self._g("position", self.real, (self.B, 2))
 
     @property
     def direction(self):
@@ -266,11 +276,11 @@ class OracleBatch:
 
     @property
     def ray_dist(self):
-        return self._g("ray_dist", np.float32, (self.B, self.N))
+        return self._g("ray_dist", self.real, (self.B, self.N))
 
     @property
     def ray_dirs(self):
-        return self._g("ray_dirs", np.float32, (self.B, self.N, 2))
+        return self._g("ray_dirs", self.real, (self.B, self.N, 2))
 
     @property
     def col_height(self):
@@ -282,49 +292,50 @@ class OracleBatch:
 
     @property
     def directions(self):
-        return self._g("directions", np.float32, (self.nd, 2))
+        return self._g("directions", self.real, (self.nd, 2))
 
     @property
     def ray_table(self):
         """(nd, N, 2) normalized ray directions per heading."""
-        return self._g("ray_table", np.float32, (self.nd, self.N, 2))
+        return self._g("ray_table", self.real, (self.nd, self.N, 2))
 
     def tile_map_chunks(self):
-        n = lib().orc_num_chunks(self._h)
+        n = lib(self.bits).orc_num_chunks(self._h)
         out = np.zeros((self.B, n), dtype=np.uint64)
-        lib().orc_tile_map_chunks(self._h, _p(out))
+        lib(self.bits).orc_tile_map_chunks(self._h, _p(out))
         return out
 
 
-def direction_table(nd: int) -> np.ndarray:
-    out = np.zeros((nd, 2), dtype=np.float32)
-    lib().orc_direction_table(nd, _p(out))
+def direction_table(nd: int, bits: int = 32) -> np.ndarray:
+    out = np.zeros((nd, 2), dtype=np.float64 if bits == 64 else np.float32)
+    lib(bits).orc_direction_table(nd, _p(out))
     return out
 
 
-def ray_fan(cfg: RcwConfig, direction) -> np.ndarray:
-    d = np.ascontiguousarray(direction, dtype=np.float32)
-    out = np.zeros((cfg.num_rays, 2), dtype=np.float32)
-    lib().orc_ray_fan(C.byref(cfg), _p(d), _p(out))
+def ray_fan(cfg: RcwConfig, direction, bits: int = 32) -> np.ndarray:
+    real = np.float64 if bits == 64 else np.float32
+    d = np.ascontiguousarray(direction, dtype=real)
+    out = np.zeros((cfg.num_rays, 2), dtype=real)
+    lib(bits).orc_ray_fan(C.byref(cfg), _p(d), _p(out))
     return out
 
 
-def cast_ray(obstacle_map, x, y, dx, dy, tie_break=0, dist_mode=0):
+def cast_ray(obstacle_map, x, y, dx, dy, tie_break=0, dist_mode=0, bits: int = 32):
     """obstacle_map: bool array indexed [i-1, j-1] (shape (H, W))."""
     om = np.asfortranarray(np.asarray(obstacle_map, dtype=np.uint8))
     H, W = om.shape
-    i = C.c_int64(); j = C.c_int64(); dim = C.c_int64(); dist = C.c_float()
-    rc = lib().orc_cast_ray(om.ctypes.data_as(C.c_void_p), H, W, x, y, dx, dy, tie_break, dist_mode,
+    i = C.c_int64(); j = C.c_int64(); dim = C.c_int64(); dist = C.c_double() if bits == 64 else C.c_float()
+    rc = lib(bits).orc_cast_ray(om.ctypes.data_as(C.c_void_p), H, W, x, y, dx, dy, tie_break, dist_mode,
                             C.addressof(i), C.addressof(j), C.addressof(dim), C.addressof(dist))
     if rc:
         raise IndexError("BoundsError")
-    return i.value, j.value, dim.value, np.float32(dist.value)
+    return i.value, j.value, dim.value, (np.float64 if bits == 64 else np.float32)(dist.value)
 
 
-def is_player_colliding(layer, px, py, radius, oob_empty=False) -> bool:
+def is_player_colliding(layer, px, py, radius, oob_empty=False, bits: int = 32) -> bool:
     lm = np.asfortranarray(np.asarray(layer, dtype=np.uint8))
     H, W = lm.shape
-    rc = lib().orc_is_player_colliding(lm.ctypes.data_as(C.c_void_p), H, W, px, py, radius,
+    rc = lib(bits).orc_is_player_colliding(lm.ctypes.data_as(C.c_void_p), H, W, px, py, radius,
                                        1 if oob_empty else 0)
     if rc < 0:
         raise IndexError("BoundsError")

@@ -15,7 +15,15 @@ import math
 
 import numpy as np
 
-f32 = np.float32
+f32 = np.float32          # rebound per World to the world-unit type T (Float32 or Float64)
+
+
+
+def set_world_unit_type(T):
+    """Select the reference's T (np.float32 or np.float64) for everything below."""
+    global f32
+    f32 = T
+
 
 WALL, GOAL = 1, 2           # SR:17-18
 NUM_ACTIONS = 4             # SR:19
@@ -93,7 +101,9 @@ class World:
     """SingleRoomWorld + the camera half of SingleRoom, one agent (SR:21-40, SR:241-256)."""
 
     def __init__(self, H=8, W=16, nd=128, radius=1 / 8, inc=1 / 8, fov=2 / 3, num_rays=512,
-                 camera_height=1.0, Hc=256, tie_le=False, dist_pre=False, normalize_divide=False):
+                 camera_height=1.0, Hc=256, tie_le=False, dist_pre=False, normalize_divide=False, T=np.float32):
+        set_world_unit_type(T)
+        self.T = T
         self.H, self.W, self.nd, self.N, self.Hc = H, W, nd, num_rays, Hc
         self.radius, self.inc, self.fov = f32(radius), f32(inc), f32(fov)
         self.camh = f32(camera_height)

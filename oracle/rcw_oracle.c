@@ -37,6 +37,31 @@
 
 #define ORC_EXPORT __attribute__((visibility("default")))
 
+/* World-unit type T of the reference (SR:259).  This file is compiled twice: as is (Float32,
+ * librcw_oracle.so) and with -DORC_REAL64 (Float64, librcw_oracle64.so); every arithmetic
+ * operation of the path is the same operation in T.  R (reward) is Float32 in both. */
+#ifdef ORC_REAL64
+typedef double real;
+#define RC(x) x
+#define R_FLOOR floor
+#define R_FABS fabs
+#define R_SQRT sqrt
+#define CFG_RADIUS(c) ((c)->player_radius_wu_f64)
+#define CFG_INC(c) ((c)->position_increment_wu_f64)
+#define CFG_FOV(c) ((c)->semi_field_of_view_wu_f64)
+#define CFG_CAMH(c) ((c)->camera_height_tile_wu_f64)
+#else
+typedef float real;
+#define RC(x) x##f
+#define R_FLOOR floorf
+#define R_FABS fabsf
+#define R_SQRT sqrtf
+#define CFG_RADIUS(c) ((c)->player_radius_wu)
+#define CFG_INC(c) ((c)->position_increment_wu)
+#define CFG_FOV(c) ((c)->semi_field_of_view_wu)
+#define CFG_CAMH(c) ((c)->camera_height_tile_wu)
+#endif
+
 /* ------------------------------------------------------------------------------------
  * Counter-based generator used by reset (the build's own; Julia's streams are not
  * reproducible).  Restated independently in csrc/rcw_rng.h — the spec is
@@ -67,45 +92,45 @@ static uint64_t orc_below(uint64_t u, uint64_t range)
 /* ------------------------------------------------------------------------------------
  * A.1 direction table  (SR:65-69)
  * ---------------------------------------------------------------------------------- */
-ORC_EXPORT void orc_direction_table(int32_t nd, float* out /* (2, nd) */)
+ORC_EXPORT void orc_direction_table(int32_t nd, real* out /* (2, nd) */)
 {
     for (int32_t i = 1; i <= nd; ++i) {
         /* theta_wu = (i - 1) * 2 * pi / num_directions, left to right, Float64 (SR:67) */
         double theta = (double)((int64_t)(i - 1) * 2) * 3.141592653589793 / (double)nd;
-        out[2 * (i - 1) + 0] = (float)cos(theta);   /* convert(T, cos(theta)) SR:68 */
-        out[2 * (i - 1) + 1] = (float)sin(theta);
+        out[2 * (i - 1) + 0] = (real)cos(theta);   /* convert(T, cos(theta)) SR:68 */
+        out[2 * (i - 1) + 1] = (real)sin(theta);
     }
 }
 
 /* ------------------------------------------------------------------------------------
  * A.3 ray fan for one heading  (SR:193, SR:214-221)
  * ---------------------------------------------------------------------------------- */
-ORC_EXPORT void orc_ray_fan(const rcw_config* cfg, const float* dir /* (2) */,
-                            float* rays /* (2, N) */)
+ORC_EXPORT void orc_ray_fan(const rcw_config* cfg, const real* dir /* (2) */,
+                            real* rays /* (2, N) */)
 {
     const int32_t N = cfg->num_rays;
-    const float fov = cfg->semi_field_of_view_wu;
-    const float d1 = dir[0], d2 = dir[1];
+    const real fov = CFG_FOV(cfg);
+    const real d1 = dir[0], d2 = dir[1];
     /* rotate_minus_90(vec) = (vec[2], -vec[1])  SR:193,215 */
-    const float c1 = d2, c2 = -d1;
+    const real c1 = d2, c2 = -d1;
     /* first = dir + fov * cam ; last = dir - fov * cam   SR:216-217 */
-    const float f1 = d1 + fov * c1, f2 = d2 + fov * c2;
-    const float l1 = d1 - fov * c1, l2 = d2 - fov * c2;
+    const real f1 = d1 + fov * c1, f2 = d2 + fov * c2;
+    const real l1 = d1 - fov * c1, l2 = d2 - fov * c2;
     /* UNPINNED (Julia Base range.jl): range(first, last, length=N) on SVector is a
      * LinRange; element i is lerpi(i-1, max(N-1,1), first, last) =
      * T((1-t)*first + t*last) with t = (i-1)/lendiv in Float64.  SR:218,221 */
     const int32_t lendiv = (N - 1 > 1) ? N - 1 : 1;
     for (int32_t i = 1; i <= N; ++i) {
         const double t = (double)(i - 1) / (double)lendiv;
-        const float u1 = (float)((1.0 - t) * (double)f1 + t * (double)l1);
-        const float u2 = (float)((1.0 - t) * (double)f2 + t * (double)l2);
+        const real u1 = (real)((1.0 - t) * (double)f1 + t * (double)l1);
+        const real u2 = (real)((1.0 - t) * (double)f2 + t * (double)l2);
         /* UNPINNED (StaticArrays): normalize(a) = inv(norm(a)) * a, norm = sqrt(sum abs2) */
-        const float n = sqrtf(u1 * u1 + u2 * u2);
-        float r1, r2;
+        const real n = R_SQRT(u1 * u1 + u2 * u2);
+        real r1, r2;
         if (cfg->normalize_mode == RCW_NORMALIZE_DIVIDE) {
             r1 = u1 / n; r2 = u2 / n;
         } else {
-            const float inv = 1.0f / n;
+            const real inv = RC(1.0) / n;
             r1 = inv * u1; r2 = inv * u2;
         }
         rays[2 * (i - 1) + 0] = r1;
@@ -118,22 +143,22 @@ ORC_EXPORT void orc_ray_fan(const rcw_config* cfg, const float* dir /* (2) */,
  * grid DDA.  obst is Bool (H, W) column-major, 1 byte per tile.  Returns 0, or
  * RCW_ERR_OUT_OF_BOUNDS where Julia would raise BoundsError on obstacle_map[i, j].
  * ---------------------------------------------------------------------------------- */
-ORC_EXPORT int orc_cast_ray(const uint8_t* obst, int32_t H, int32_t W, float x, float y,
-                            float dx, float dy, int32_t tie_break, int32_t dist_mode,
-                            int64_t* i_hit, int64_t* j_hit, int64_t* hit_dim, float* dist)
+ORC_EXPORT int orc_cast_ray(const uint8_t* obst, int32_t H, int32_t W, real x, real y,
+                            real dx, real dy, int32_t tie_break, int32_t dist_mode,
+                            int64_t* i_hit, int64_t* j_hit, int64_t* hit_dim, real* dist)
 {
-    int64_t i = (int64_t)floorf(x) + 1;   /* wu_to_tu UT:5 */
-    int64_t j = (int64_t)floorf(y) + 1;
-    const float ddx = fabsf(1.0f / dx);
-    const float ddy = fabsf(1.0f / dy);
+    int64_t i = (int64_t)R_FLOOR(x) + 1;   /* wu_to_tu UT:5 */
+    int64_t j = (int64_t)R_FLOOR(y) + 1;
+    const real ddx = R_FABS(RC(1.0) / dx);
+    const real ddy = R_FABS(RC(1.0) / dy);
     int64_t si, sj;
-    float sx, sy;
-    if (dx < 0.0f) { si = -1; sx = (x - (float)(i - 1)) * ddx; }
-    else           { si = +1; sx = ((float)i - x) * ddx; }
-    if (dy < 0.0f) { sj = -1; sy = (y - (float)(j - 1)) * ddy; }
-    else           { sj = +1; sy = ((float)j - y) * ddy; }
+    real sx, sy;
+    if (dx < RC(0.0)) { si = -1; sx = (x - (real)(i - 1)) * ddx; }
+    else           { si = +1; sx = ((real)i - x) * ddx; }
+    if (dy < RC(0.0)) { sj = -1; sy = (y - (real)(j - 1)) * ddy; }
+    else           { sj = +1; sy = ((real)j - y) * ddy; }
     int64_t dim = 0;
-    float d = 0.0f;
+    real d = RC(0.0);
     for (;;) {
         if (i < 1 || i > H || j < 1 || j > W) return RCW_ERR_OUT_OF_BOUNDS;
         if (obst[(i - 1) + (int64_t)H * (j - 1)]) break;
@@ -154,25 +179,25 @@ ORC_EXPORT int orc_cast_ray(const uint8_t* obst, int32_t H, int32_t W, float x, 
  * Returns 0/1, or RCW_ERR_OUT_OF_BOUNDS for Julia's BoundsError at CD:35.
  * ---------------------------------------------------------------------------------- */
 ORC_EXPORT int orc_is_player_colliding(const uint8_t* layer, int32_t H, int32_t W,
-                                       float px, float py, float radius, int32_t oob_empty)
+                                       real px, real py, real radius, int32_t oob_empty)
 {
-    const float half = 0.5f;                           /* StdSquare(0.5) CD:24 */
-    const int64_t it = (int64_t)floorf(px) + 1;        /* wu_to_tu CD:27-28, UT:5 */
-    const int64_t jt = (int64_t)floorf(py) + 1;
+    const real half = RC(0.5);                           /* StdSquare(0.5) CD:24 */
+    const int64_t it = (int64_t)R_FLOOR(px) + 1;        /* wu_to_tu CD:27-28, UT:5 */
+    const int64_t jt = (int64_t)R_FLOOR(py) + 1;
     for (int64_t j = jt - 1; j <= jt + 1; ++j) {       /* CD:30 */
         for (int64_t i = it - 1; i <= it + 1; ++i) {   /* CD:31 */
-            const float cx = (float)i - half;          /* CD:33-34 */
-            const float cy = (float)j - half;
+            const real cx = (real)i - half;          /* CD:33-34 */
+            const real cy = (real)j - half;
             if (i < 1 || i > H || j < 1 || j > W) {
                 if (oob_empty) continue;   /* RCW_OOB_TREAT_EMPTY (not the reference) */
                 return RCW_ERR_OUT_OF_BOUNDS;
             }
             if (layer[(i - 1) + (int64_t)H * (j - 1)]) {   /* && short-circuit CD:35 */
-                const float qx = px - cx, qy = py - cy;    /* position .- tile CD:35 */
+                const real qx = px - cx, qy = py - cy;    /* position .- tile CD:35 */
                 /* get_projection: clamp.(q, -h, h) CD:9-12 */
-                const float sx = qx < -half ? -half : (qx > half ? half : qx);
-                const float sy = qy < -half ? -half : (qy > half ? half : qy);
-                const float vx = qx - sx, vy = qy - sy;    /* CD:16 */
+                const real sx = qx < -half ? -half : (qx > half ? half : qx);
+                const real sy = qy < -half ? -half : (qy > half ? half : qy);
+                const real vx = qx - sx, vy = qy - sy;    /* CD:16 */
                 if (vx * vx + vy * vy < radius * radius) return 1;   /* CD:18 */
             }
         }
@@ -187,11 +212,11 @@ typedef struct orc_batch {
     rcw_config cfg;
     int32_t B, H, W, N, nd, Hc, nchunks;
     uint64_t seed;
-    float* directions;      /* (2, nd) */
-    float* ray_table;       /* (2, N, nd) normalized ray directions per heading */
+    real* directions;      /* (2, nd) */
+    real* ray_table;       /* (2, N, nd) normalized ray directions per heading */
     uint8_t* wall;          /* (H, W, B) Bool layer WALL */
     uint8_t* goalmap;       /* (H, W, B) Bool layer GOAL */
-    float* pos;             /* (2, B) */
+    real* pos;             /* (2, B) */
     int32_t* dir;           /* (B) */
     int32_t* goal;          /* (2, B) 1-based */
     float* reward;          /* (B) */
@@ -201,8 +226,8 @@ typedef struct orc_batch {
     /* ray buffers SR:29-31,39 */
     int64_t* ray_stop;      /* (2, N, B) */
     int64_t* ray_dim;       /* (N, B) */
-    float* ray_dist;        /* (N, B) */
-    float* ray_dirs;        /* (2, N, B) */
+    real* ray_dist;        /* (N, B) */
+    real* ray_dirs;        /* (2, N, B) */
     /* camera view + compact descriptors */
     uint32_t* camera_view;  /* (Hc, N, B) */
     int32_t* col_height;    /* (N, B) indexed by image column k */
@@ -237,14 +262,14 @@ static void orc_cast_rays_agent(orc_batch* b, int32_t a)
     uint8_t obst_stack[1024];
     uint8_t* obst = HW <= sizeof obst_stack ? obst_stack : (uint8_t*)malloc(HW);
     for (size_t t = 0; t < HW; ++t) obst[t] = b->wall[HW * a + t] | b->goalmap[HW * a + t];
-    const float x = b->pos[2 * a], y = b->pos[2 * a + 1];
-    const float* fan = b->ray_table + (size_t)2 * N * b->dir[a];   /* SR:214-221 */
+    const real x = b->pos[2 * a], y = b->pos[2 * a + 1];
+    const real* fan = b->ray_table + (size_t)2 * N * b->dir[a];   /* SR:214-221 */
     for (int32_t i = 0; i < N; ++i) {                               /* SR:220 */
-        const float dx = fan[2 * i], dy = fan[2 * i + 1];
-        int64_t ih = 0, jh = 0, dim = 0; float dist = 0.0f;
+        const real dx = fan[2 * i], dy = fan[2 * i + 1];
+        int64_t ih = 0, jh = 0, dim = 0; real dist = RC(0.0);
         int rc = orc_cast_ray(obst, H, W, x, y, dx, dy, b->cfg.dda_tie_break,
                               b->cfg.dda_distance, &ih, &jh, &dim, &dist);   /* SR:223 */
-        if (rc != 0) { b->status[a] = rc; ih = 1; jh = 1; dim = 0; dist = 0.0f; }
+        if (rc != 0) { b->status[a] = rc; ih = 1; jh = 1; dim = 0; dist = RC(0.0); }
         const size_t r = (size_t)N * a + i;
         b->ray_dirs[2 * r] = dx; b->ray_dirs[2 * r + 1] = dy;       /* SR:222 */
         b->ray_stop[2 * r] = ih; b->ray_stop[2 * r + 1] = jh;       /* SR:224-225 */
@@ -260,24 +285,24 @@ static void orc_update_camera_view_agent(orc_batch* b, int32_t a)
     const int32_t H = b->H, N = b->N, Hc = b->Hc;
     const size_t HW = (size_t)H * b->W;
     const rcw_config* c = &b->cfg;
-    const float p1 = b->directions[2 * b->dir[a]], p2 = b->directions[2 * b->dir[a] + 1]; /* SR:400 */
+    const real p1 = b->directions[2 * b->dir[a]], p2 = b->directions[2 * b->dir[a] + 1]; /* SR:400 */
     uint32_t* view = b->camera_view + (size_t)Hc * N * a;
     for (int32_t i = 1; i <= N; ++i) {                              /* SR:401 */
         const size_t r = (size_t)N * a + (i - 1);
-        const float r1 = b->ray_dirs[2 * r], r2 = b->ray_dirs[2 * r + 1];
+        const real r1 = b->ray_dirs[2 * r], r2 = b->ray_dirs[2 * r + 1];
         /* projected = dist * sum(dir .* ray)  SR:404 */
-        const float dot = p1 * r1 + p2 * r2;
-        const float projected = b->ray_dist[r] * dot;
+        const real dot = p1 * r1 + p2 * r2;
+        const real projected = b->ray_dist[r] * dot;
         /* height_line = camh * num_rays / (2 * fov * projected)  SR:406 (left assoc.) */
-        const float num = c->camera_height_tile_wu * (float)N;
-        const float den = (2.0f * c->semi_field_of_view_wu) * projected;
-        const float height_line = num / den;
+        const real num = CFG_CAMH(c) * (real)N;
+        const real den = (RC(2.0) * CFG_FOV(c)) * projected;
+        const real height_line = num / den;
         int64_t h;
         if (isfinite(height_line)) {                                /* SR:407-411 */
-            const float fl = floorf(height_line);
+            const real fl = R_FLOOR(height_line);
             /* floor(Int, x): Julia raises InexactError outside Int64; saturate instead */
-            if (fl >= 9.2233720368547758e18f) h = INT64_MAX;
-            else if (fl <= -9.2233720368547758e18f) h = INT64_MIN;
+            if (fl >= RC(9.2233720368547758e18)) h = INT64_MAX;
+            else if (fl <= -RC(9.2233720368547758e18)) h = INT64_MIN;
             else h = (int64_t)fl;
         } else {
             h = Hc;
@@ -352,7 +377,7 @@ static void sd_circle(uint32_t* img, int64_t Ht, int64_t Wt, int64_t i_pos, int6
     }
 }
 /* wu_to_pu(x_wu, pu_per_wu) = floor(Int, x_wu * pu_per_wu) + 1  UT:6 (Float32 * Int -> Float32) */
-static int64_t orc_wu_to_pu(float x, int32_t pu) { return (int64_t)floorf(x * (float)pu) + 1; }
+static int64_t orc_wu_to_pu(real x, int32_t pu) { return (int64_t)R_FLOOR(x * (real)pu) + 1; }
 
 /* update_top_view!(env)  SR:446-483 (+ draw_tile_map! SR:342-372) for agent a */
 static void orc_update_top_view_agent(orc_batch* b, int32_t a)
@@ -381,13 +406,13 @@ static void orc_update_top_view_agent(orc_batch* b, int32_t a)
             }
         }
     }
-    const float px = b->pos[2 * a], py = b->pos[2 * a + 1];
+    const real px = b->pos[2 * a], py = b->pos[2 * a + 1];
     const int64_t ip = orc_wu_to_pu(px, (int32_t)pu), jp = orc_wu_to_pu(py, (int32_t)pu);     /* SR:468 */
-    const int64_t rp = orc_wu_to_pu(b->cfg.player_radius_wu, (int32_t)pu);                    /* SR:469 */
+    const int64_t rp = orc_wu_to_pu(CFG_RADIUS(&b->cfg), (int32_t)pu);                    /* SR:469 */
     for (int32_t i = 0; i < N; ++i) {                                   /* SR:473-477 */
         const size_t r = (size_t)N * a + i;
-        const float ex = px + b->ray_dist[r] * b->ray_dirs[2 * r];
-        const float ey = py + b->ray_dist[r] * b->ray_dirs[2 * r + 1];
+        const real ex = px + b->ray_dist[r] * b->ray_dirs[2 * r];
+        const real ey = py + b->ray_dist[r] * b->ray_dirs[2 * r + 1];
         sd_line(img, Ht, Wt, ip, jp, orc_wu_to_pu(ex, (int32_t)pu), orc_wu_to_pu(ey, (int32_t)pu), 0x00808080u);
     }
     sd_circle(img, Ht, Wt, ip - rp, jp - rp, 2 * rp + 1, 0x00c0c0c0u);  /* SR:480 */
@@ -425,10 +450,10 @@ static void orc_reset_agent(orc_batch* b, int32_t a, uint64_t seed)
         else break;
     }
     const int32_t pi = (int32_t)(lin % (uint64_t)H) + 1, pj = (int32_t)(lin / (uint64_t)H) + 1;
-    b->pos[2 * a] = (float)((double)pi - 0.5);                       /* SR:125 */
-    b->pos[2 * a + 1] = (float)((double)pj - 0.5);
+    b->pos[2 * a] = (real)((double)pi - 0.5);                       /* SR:125 */
+    b->pos[2 * a + 1] = (real)((double)pj - 0.5);
     b->dir[a] = (int32_t)orc_below(orc_draw(key, n++), (uint64_t)b->nd);   /* SR:128 */
-    b->reward[a] = 0.0f; b->done[a] = 0;                             /* SR:131-132 */
+    b->reward[a] = RC(0.0); b->done[a] = 0;                             /* SR:131-132 */
     b->episode[a] += 1;
     orc_render_agent(b, a);                                          /* SR:134, SR:329 */
 }
@@ -447,11 +472,11 @@ ORC_EXPORT int orc_create(const rcw_config* cfg, int32_t batch, uint64_t seed, i
     b->nd = cfg->num_directions; b->Hc = cfg->height_camera_view_pu; b->seed = seed;
     b->nchunks = (2 * H * W + 63) / 64; b->render = render;
     const size_t B = (size_t)batch, HW = (size_t)H * W, N = (size_t)b->N;
-    b->directions = (float*)malloc(sizeof(float) * 2 * b->nd);
-    b->ray_table = (float*)malloc(sizeof(float) * 2 * N * b->nd);
+    b->directions = (real*)malloc(sizeof(real) * 2 * b->nd);
+    b->ray_table = (real*)malloc(sizeof(real) * 2 * N * b->nd);
     b->wall = (uint8_t*)calloc(HW * B, 1);
     b->goalmap = (uint8_t*)calloc(HW * B, 1);
-    b->pos = (float*)calloc(2 * B, sizeof(float));
+    b->pos = (real*)calloc(2 * B, sizeof(real));
     b->dir = (int32_t*)calloc(B, sizeof(int32_t));
     b->goal = (int32_t*)calloc(2 * B, sizeof(int32_t));
     b->reward = (float*)calloc(B, sizeof(float));
@@ -460,8 +485,8 @@ ORC_EXPORT int orc_create(const rcw_config* cfg, int32_t batch, uint64_t seed, i
     b->status = (int32_t*)calloc(B, sizeof(int32_t));
     b->ray_stop = (int64_t*)calloc(2 * N * B, sizeof(int64_t));
     b->ray_dim = (int64_t*)calloc(N * B, sizeof(int64_t));
-    b->ray_dist = (float*)calloc(N * B, sizeof(float));
-    b->ray_dirs = (float*)calloc(2 * N * B, sizeof(float));
+    b->ray_dist = (real*)calloc(N * B, sizeof(real));
+    b->ray_dirs = (real*)calloc(2 * N * B, sizeof(real));
     b->camera_view = (uint32_t*)calloc(render ? (size_t)b->Hc * N * B : 1, sizeof(uint32_t));
     b->Ht = H * cfg->pu_per_tu; b->Wt = W * cfg->pu_per_tu;
     if (cfg->render_top_view) {
@@ -490,9 +515,9 @@ ORC_EXPORT int orc_create(const rcw_config* cfg, int32_t batch, uint64_t seed, i
     return RCW_OK;
 }
 
-ORC_EXPORT int orc_set_direction_table(orc_batch* b, const float* dirs)
+ORC_EXPORT int orc_set_direction_table(orc_batch* b, const real* dirs)
 {
-    memcpy(b->directions, dirs, sizeof(float) * 2 * b->nd);
+    memcpy(b->directions, dirs, sizeof(real) * 2 * b->nd);
     orc_build_ray_table(b);
 #pragma omp parallel for schedule(static)
     for (int32_t a = 0; a < b->B; ++a) orc_render_agent(b, a);
@@ -508,7 +533,7 @@ ORC_EXPORT int orc_reset(orc_batch* b, const uint8_t* mask, uint64_t seed)
     return RCW_OK;
 }
 
-ORC_EXPORT int orc_set_state(orc_batch* b, const int32_t* goal_ij, const float* pos,
+ORC_EXPORT int orc_set_state(orc_batch* b, const int32_t* goal_ij, const real* pos,
                              const int32_t* dir, const uint8_t* mask)
 {
     const int32_t H = b->H, W = b->W;
@@ -519,8 +544,8 @@ ORC_EXPORT int orc_set_state(orc_batch* b, const int32_t* goal_ij, const float* 
         if (gi < 2 || gi > H - 1 || gj < 2 || gj > W - 1) return RCW_ERR_INVALID_ARGUMENT;
         if (dir[a] < 0 || dir[a] >= b->nd) return RCW_ERR_INVALID_ARGUMENT;
         if (!isfinite(pos[2 * a]) || !isfinite(pos[2 * a + 1])) return RCW_ERR_INVALID_ARGUMENT;
-        if (!(pos[2 * a] >= 1.0f && pos[2 * a] < (float)(H - 1) && pos[2 * a + 1] >= 1.0f &&
-              pos[2 * a + 1] < (float)(W - 1))) return RCW_ERR_INVALID_ARGUMENT;
+        if (!(pos[2 * a] >= RC(1.0) && pos[2 * a] < (real)(H - 1) && pos[2 * a + 1] >= RC(1.0) &&
+              pos[2 * a + 1] < (real)(W - 1))) return RCW_ERR_INVALID_ARGUMENT;
     }
 #pragma omp parallel for schedule(static)
     for (int32_t a = 0; a < b->B; ++a) {
@@ -531,7 +556,7 @@ ORC_EXPORT int orc_set_state(orc_batch* b, const int32_t* goal_ij, const float* 
         gm[(b->goal[2 * a] - 1) + (size_t)H * (b->goal[2 * a + 1] - 1)] = 1;   /* SR:122 */
         b->pos[2 * a] = pos[2 * a]; b->pos[2 * a + 1] = pos[2 * a + 1];        /* SR:126 */
         b->dir[a] = dir[a];                                                     /* SR:129 */
-        b->reward[a] = 0.0f; b->done[a] = 0;                                    /* SR:131-132 */
+        b->reward[a] = RC(0.0); b->done[a] = 0;                                    /* SR:131-132 */
         orc_render_agent(b, a);
     }
     return RCW_OK;
@@ -543,16 +568,16 @@ static void orc_act_agent(orc_batch* b, int32_t a, int action)
     const int32_t H = b->H, W = b->W, nd = b->nd;
     const size_t HW = (size_t)H * W;
     if (action <= 2) {                                              /* SR:150 */
-        const float d1 = b->directions[2 * b->dir[a]], d2 = b->directions[2 * b->dir[a] + 1];
-        const float inc = b->cfg.position_increment_wu;
-        float nx, ny;
+        const real d1 = b->directions[2 * b->dir[a]], d2 = b->directions[2 * b->dir[a] + 1];
+        const real inc = CFG_INC(&b->cfg);
+        real nx, ny;
         if (action == 1) { nx = b->pos[2 * a] + inc * d1; ny = b->pos[2 * a + 1] + inc * d2; } /* UT:16 */
         else             { nx = b->pos[2 * a] - inc * d1; ny = b->pos[2 * a + 1] - inc * d2; } /* UT:17 */
         const int g = orc_is_player_colliding(b->goalmap + HW * a, H, W, nx, ny,
-                                              b->cfg.player_radius_wu,
+                                              CFG_RADIUS(&b->cfg),
                                               b->cfg.out_of_bounds == RCW_OOB_TREAT_EMPTY);   /* SR:162 */
         const int w = orc_is_player_colliding(b->wall + HW * a, H, W, nx, ny,
-                                              b->cfg.player_radius_wu,
+                                              CFG_RADIUS(&b->cfg),
                                               b->cfg.out_of_bounds == RCW_OOB_TREAT_EMPTY);   /* SR:163 */
         if (g < 0 || w < 0) {   /* Julia: BoundsError before any mutation */
             b->status[a] = RCW_ERR_OUT_OF_BOUNDS;
@@ -560,17 +585,17 @@ static void orc_act_agent(orc_batch* b, int32_t a, int action)
         }
         if (g || w) {                                               /* SR:165 */
             if (g) { b->reward[a] = b->cfg.goal_reward; b->done[a] = 1; }   /* SR:166-168 */
-            else   { b->reward[a] = 0.0f; b->done[a] = 0; }                 /* SR:170-171 */
+            else   { b->reward[a] = RC(0.0); b->done[a] = 0; }                 /* SR:170-171 */
         } else {
             b->pos[2 * a] = nx; b->pos[2 * a + 1] = ny;             /* SR:174 */
-            b->reward[a] = 0.0f; b->done[a] = 0;                    /* SR:175-176 */
+            b->reward[a] = RC(0.0); b->done[a] = 0;                    /* SR:175-176 */
         }
     } else {
         int32_t d = b->dir[a];
         if (action == 3) d = (d + 1) % nd;                          /* turn_left UT:13 */
         else             d = ((d - 1) % nd + nd) % nd;              /* turn_right UT:14 (floored mod) */
         b->dir[a] = d;                                              /* SR:185 */
-        b->reward[a] = 0.0f; b->done[a] = 0;                        /* SR:186-187 */
+        b->reward[a] = RC(0.0); b->done[a] = 0;                        /* SR:186-187 */
     }
 }
 
@@ -616,19 +641,19 @@ ORC_EXPORT const uint32_t* orc_camera_view(orc_batch* b) { return b->camera_view
 ORC_EXPORT const uint32_t* orc_top_view(orc_batch* b) { return b->top_view; }
 ORC_EXPORT const float* orc_reward(orc_batch* b) { return b->reward; }
 ORC_EXPORT const uint8_t* orc_done(orc_batch* b) { return b->done; }
-ORC_EXPORT const float* orc_position(orc_batch* b) { return b->pos; }
+ORC_EXPORT const real* orc_position(orc_batch* b) { return b->pos; }
 ORC_EXPORT const int32_t* orc_direction(orc_batch* b) { return b->dir; }
 ORC_EXPORT const int32_t* orc_goal(orc_batch* b) { return b->goal; }
 ORC_EXPORT const uint32_t* orc_episode(orc_batch* b) { return b->episode; }
 ORC_EXPORT const int32_t* orc_status(orc_batch* b) { return b->status; }
 ORC_EXPORT const int64_t* orc_ray_stop(orc_batch* b) { return b->ray_stop; }
 ORC_EXPORT const int64_t* orc_ray_dim(orc_batch* b) { return b->ray_dim; }
-ORC_EXPORT const float* orc_ray_dist(orc_batch* b) { return b->ray_dist; }
-ORC_EXPORT const float* orc_ray_dirs(orc_batch* b) { return b->ray_dirs; }
+ORC_EXPORT const real* orc_ray_dist(orc_batch* b) { return b->ray_dist; }
+ORC_EXPORT const real* orc_ray_dirs(orc_batch* b) { return b->ray_dirs; }
 ORC_EXPORT const int32_t* orc_col_height(orc_batch* b) { return b->col_height; }
 ORC_EXPORT const uint8_t* orc_col_colour(orc_batch* b) { return b->col_colour; }
-ORC_EXPORT const float* orc_directions(orc_batch* b) { return b->directions; }
-ORC_EXPORT const float* orc_ray_table(orc_batch* b) { return b->ray_table; }
+ORC_EXPORT const real* orc_directions(orc_batch* b) { return b->directions; }
+ORC_EXPORT const real* orc_ray_table(orc_batch* b) { return b->ray_table; }
 ORC_EXPORT int32_t orc_num_chunks(orc_batch* b) { return b->nchunks; }
 
 /* tile_map as BitArray{3}(2, H, W).chunks per agent: UInt64 (nchunks, B)  SR:54 */

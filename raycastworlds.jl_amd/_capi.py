@@ -52,7 +52,12 @@ class RcwConfig(C.Structure):
         ("write_columns", C.c_int32),
         ("out_of_bounds", C.c_int32),
         ("render_top_view", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("world_unit_bits", C.c_int32),
+        ("player_radius_wu_f64", C.c_double),
+        ("position_increment_wu_f64", C.c_double),
+        ("semi_field_of_view_wu_f64", C.c_double),
+        ("camera_height_tile_wu_f64", C.c_double),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -79,6 +84,12 @@ SIGNATURES = {
     "rcw_bind_obs": [_vp, _vp],
     "rcw_reset": [_vp, _vp, _u64],
     "rcw_set_state": [_vp, _vp, _vp, _vp, _vp],
+    "rcw_set_state64": [_vp, _vp, _vp, _vp, _vp],
+    "rcw_position64": [_vp, _vp],
+    "rcw_rays64": [_vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "rcw_set_direction_table64": [_vp, _vp],
+    "rcw_ray_table64": [_vp, _vp],
+    "rcw_direction_table64": [_vp, _vp],
     "rcw_step": [_vp, _vp],
     "rcw_step_device": [_vp, _vp],
     "rcw_sync": [_vp],
@@ -157,8 +168,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.rcw_abi_version() != 1:
-        raise ImportError(f"librcw_hip ABI {lib.rcw_abi_version()} != 1")
+    if lib.rcw_abi_version() != 2:
+        raise ImportError(f"librcw_hip ABI {lib.rcw_abi_version()} != 2")
     _lib = lib
     return lib
 

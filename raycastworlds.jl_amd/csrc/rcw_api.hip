@@ -59,8 +59,12 @@ struct rcw_handle {
     bool profiling = false;
     int prof_count = 0;
     std::vector<hipEvent_t> prof_ev;   // 3 per recorded step
-    std::vector<float> dir_table;   // (2, nd)
+    bool real64 = false;            // world-unit type T = Float64 (cfg.world_unit_bits = 64)
+    size_t real_size = sizeof(float);
+    std::vector<float> dir_table;   // (2, nd)        T = Float32
     std::vector<float> ray_table;   // (N, 5, nd)
+    std::vector<double> dir_table64;   //              T = Float64
+    std::vector<double> ray_table64;
 };
 
 namespace {
@@ -114,66 +118,74 @@ void free_all(rcw_handle* h)
     h->own_stream = nullptr;
 }
 
-// directions_wu  SR:65-69: theta = (i-1)*2*pi/nd in Float64, components rounded to Float32
-void build_direction_table(int nd, std::vector<float>& out)
+// directions_wu  SR:65-69: theta = (i-1)*2*pi/nd in Float64, components converted to T
+template <typename T>
+void build_direction_table(int nd, std::vector<T>& out)
 {
     out.resize((size_t)2 * nd);
     for (int i = 1; i <= nd; ++i) {
         const double theta = (double)((long long)(i - 1) * 2) * 3.141592653589793 / (double)nd;
-        out[2 * (size_t)(i - 1)] = (float)std::cos(theta);
-        out[2 * (size_t)(i - 1) + 1] = (float)std::sin(theta);
+        out[2 * (size_t)(i - 1)] = (T)std::cos(theta);
+        out[2 * (size_t)(i - 1) + 1] = (T)std::sin(theta);
     }
 }
 
 // Per heading d and ray i (SR:214-221, SR:404): the fan end points dir ± fov·rot₋₉₀(dir),
-// the LinRange element (Float64 lerp rounded to Float32), its normalisation, and the
-// derived |1/dx|, |1/dy| (cast_ray's delta distances) and dir·ray (SR:404).
-// Layout [nd][5][N]: see RCW_TABLE_ROWS.
-void build_ray_table(const rcw_config& c, const std::vector<float>& dirs, std::vector<float>& out)
+// the LinRange element (Float64 lerp converted to T), its normalisation, and the derived
+// |1/dx|, |1/dy| (cast_ray's delta distances) and dir·ray (SR:404).
+// Layout [nd][5][N]: see RCW_TABLE_ROWS.  T is the world-unit type; fov = convert(T, .) SR:267.
+template <typename T>
+void build_ray_table(const rcw_config& c, T fov, const std::vector<T>& dirs, std::vector<T>& out)
 {
     const int N = c.num_rays, nd = c.num_directions;
-    const float fov = c.semi_field_of_view_wu;
-    out.assign((size_t)nd * RCW_TABLE_ROWS * N, 0.0f);
+    out.assign((size_t)nd * RCW_TABLE_ROWS * N, (T)0);
     const int lendiv = N - 1 > 1 ? N - 1 : 1;   // LinRange lendiv = max(len - 1, 1)
     for (int d = 0; d < nd; ++d) {
-        const float d1 = dirs[2 * (size_t)d], d2 = dirs[2 * (size_t)d + 1];
-        const float cam1 = d2, cam2 = -d1;                    // rotate_minus_90 SR:193
-        const float fc1 = fov * cam1, fc2 = fov * cam2;
-        const float first1 = d1 + fc1, first2 = d2 + fc2;     // SR:216
-        const float last1 = d1 - fc1, last2 = d2 - fc2;       // SR:217
-        float* row = out.data() + (size_t)d * RCW_TABLE_ROWS * N;
+        const T d1 = dirs[2 * (size_t)d], d2 = dirs[2 * (size_t)d + 1];
+        const T cam1 = d2, cam2 = -d1;                        // rotate_minus_90 SR:193
+        const T fc1 = fov * cam1, fc2 = fov * cam2;
+        const T first1 = d1 + fc1, first2 = d2 + fc2;         // SR:216
+        const T last1 = d1 - fc1, last2 = d2 - fc2;           // SR:217
+        T* row = out.data() + (size_t)d * RCW_TABLE_ROWS * N;
         for (int i = 0; i < N; ++i) {
             const double t = (double)i / (double)lendiv;      // lerpi: t = j/d in Float64
             const double omt = 1.0 - t;
             const double a1 = omt * (double)first1, b1 = t * (double)last1;
             const double a2 = omt * (double)first2, b2 = t * (double)last2;
-            const float u1 = (float)(a1 + b1);
-            const float u2 = (float)(a2 + b2);
-            const float s1 = u1 * u1, s2 = u2 * u2;
-            const float nrm = std::sqrt(s1 + s2);             // norm(SVector) = sqrt(sum abs2)
-            float r1, r2;
+            const T u1 = (T)(a1 + b1);
+            const T u2 = (T)(a2 + b2);
+            const T s1 = u1 * u1, s2 = u2 * u2;
+            const T nrm = std::sqrt(s1 + s2);                 // norm(SVector) = sqrt(sum abs2)
+            T r1, r2;
             if (c.normalize_mode == RCW_NORMALIZE_DIVIDE) {
                 r1 = u1 / nrm; r2 = u2 / nrm;
             } else {
-                const float inv = 1.0f / nrm;                 // inv(norm(a)) * a
+                const T inv = (T)1 / nrm;                     // inv(norm(a)) * a
                 r1 = inv * u1; r2 = inv * u2;
             }
-            const float m1 = d1 * r1, m2 = d2 * r2;           // sum(dir .* ray) SR:404
+            const T m1 = d1 * r1, m2 = d2 * r2;               // sum(dir .* ray) SR:404
             row[i] = r1;
             row[(size_t)N + i] = r2;
-            row[2 * (size_t)N + i] = std::fabs(1.0f / r1);
-            row[3 * (size_t)N + i] = std::fabs(1.0f / r2);
+            row[2 * (size_t)N + i] = std::fabs((T)1 / r1);
+            row[3 * (size_t)N + i] = std::fabs((T)1 / r2);
             row[4 * (size_t)N + i] = m1 + m2;
         }
     }
 }
 
+void rebuild_ray_table(rcw_handle* h)
+{
+    if (h->real64) build_ray_table<double>(h->cfg, h->cfg.semi_field_of_view_wu_f64, h->dir_table64, h->ray_table64);
+    else build_ray_table<float>(h->cfg, h->cfg.semi_field_of_view_wu, h->dir_table, h->ray_table);
+}
+
 int upload_tables(rcw_handle* h)
 {
-    RCW_HIP(hipMemcpyAsync(h->d_dir_table, h->dir_table.data(), h->dir_table.size() * sizeof(float),
-                           hipMemcpyHostToDevice, h->stream));
-    RCW_HIP(hipMemcpyAsync(h->d_ray_table, h->ray_table.data(), h->ray_table.size() * sizeof(float),
-                           hipMemcpyHostToDevice, h->stream));
+    const void* dirs = h->real64 ? (const void*)h->dir_table64.data() : (const void*)h->dir_table.data();
+    const void* rays = h->real64 ? (const void*)h->ray_table64.data() : (const void*)h->ray_table.data();
+    const size_t nd2 = (size_t)2 * h->cfg.num_directions, nr = (size_t)h->cfg.num_directions * RCW_TABLE_ROWS * h->cfg.num_rays;
+    RCW_HIP(hipMemcpyAsync(h->d_dir_table, dirs, nd2 * h->real_size, hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipMemcpyAsync(h->d_ray_table, rays, nr * h->real_size, hipMemcpyHostToDevice, h->stream));
     RCW_HIP(hipStreamSynchronize(h->stream));
     return RCW_OK;
 }
@@ -191,6 +203,16 @@ int validate_config(const rcw_config* c, int32_t batch)
     if (c->num_directions < 1 || c->num_rays < 1 || c->height_camera_view_pu < 1)
         return fail(RCW_ERR_INVALID_ARGUMENT, "num_directions, num_rays, height_camera_view_pu must be >= 1");
     if (c->num_rays > (1 << 24)) return fail(RCW_ERR_INVALID_ARGUMENT, "num_rays not exactly representable in Float32");
+    if (c->world_unit_bits != 32 && c->world_unit_bits != 64)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "world_unit_bits must be 32 or 64 (got %d)", c->world_unit_bits);
+    if (c->world_unit_bits == 64) {
+        if (!(c->player_radius_wu_f64 > 0.0 && c->player_radius_wu_f64 < 0.5))
+            return fail(RCW_ERR_INVALID_ARGUMENT, "player_radius_wu_f64 must be in (0, 0.5)");
+        if (!(c->position_increment_wu_f64 > 0.0) || !std::isfinite(c->position_increment_wu_f64) ||
+            !(c->semi_field_of_view_wu_f64 > 0.0) || !std::isfinite(c->semi_field_of_view_wu_f64) ||
+            !(c->camera_height_tile_wu_f64 > 0.0) || !std::isfinite(c->camera_height_tile_wu_f64))
+            return fail(RCW_ERR_INVALID_ARGUMENT, "the *_f64 world-unit parameters must be positive and finite");
+    }
     if (!(c->player_radius_wu > 0.0f && c->player_radius_wu < 0.5f))   // "should be less than 0.5" SR:47
         return fail(RCW_ERR_INVALID_ARGUMENT, "player_radius_wu must be in (0, 0.5)");
     if (!(c->position_increment_wu > 0.0f) || !std::isfinite(c->position_increment_wu))
@@ -217,6 +239,14 @@ int sync_and_check(rcw_handle* h)
     if (e == RCW_ERR_OUT_OF_BOUNDS) return fail(e, "a tile index left the tile map (BoundsError in the reference)");
     if (e != 0) return fail(e, "device error %d", e);
     return RCW_OK;
+}
+
+// The Float32 entry points serve Float32 worlds, the *64 ones Float64 worlds.
+int check_real(rcw_handle* h, bool want64, const char* fn)
+{
+    if (h->real64 == want64) return RCW_OK;
+    return fail(RCW_ERR_UNSUPPORTED, "%s: the handle's world-unit type is %s; use the %s entry point", fn,
+                h->real64 ? "Float64" : "Float32", h->real64 ? "*64" : "Float32");
 }
 
 int check_handle(rcw_handle* h)
@@ -282,6 +312,11 @@ int rcw_config_default(rcw_config* c)
     c->agent_id_offset = 0;
     c->write_columns = 1;
     c->out_of_bounds = RCW_OOB_ERROR;
+    c->world_unit_bits = 32;                       // T = Float32 SR:259
+    c->player_radius_wu_f64 = 1.0 / 8.0;           // convert(Float64, .) of the same literals
+    c->position_increment_wu_f64 = 1.0 / 8.0;
+    c->semi_field_of_view_wu_f64 = 2.0 / 3.0;
+    c->camera_height_tile_wu_f64 = 1.0;
     return RCW_OK;
 }
 
@@ -311,6 +346,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     const int H = cfg->height_tile_map_tu, W = cfg->width_tile_map_tu, N = cfg->num_rays;
     const int nd = cfg->num_directions, Hc = cfg->height_camera_view_pu;
     h->nchunks = (2 * H * W + 63) / 64;   // BitArray chunks: cld(2HW, 64)
+    h->real64 = cfg->world_unit_bits == 64;
+    h->real_size = h->real64 ? sizeof(double) : sizeof(float);
     const size_t B = (size_t)batch;
 
 #define RCW_TRY(expr)                                       \
@@ -328,15 +365,15 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     h->stream = h->own_stream;
     RCW_TRY(hipEventCreate(&h->ev_start));
     RCW_TRY(hipEventCreate(&h->ev_stop));
-    RCW_TRY(hipMalloc(&h->d_pos, B * sizeof(float2)));
+    RCW_TRY(hipMalloc(&h->d_pos, B * 2 * h->real_size));
     RCW_TRY(hipMalloc(&h->d_dir, B * sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_goal, B * sizeof(int2)));
     RCW_TRY(hipMalloc(&h->d_reward, B * sizeof(float)));
     RCW_TRY(hipMalloc(&h->d_done, B));
     RCW_TRY(hipMalloc(&h->d_episode, B * sizeof(uint32_t)));
     RCW_TRY(hipMalloc(&h->d_tile_map, B * (size_t)h->nchunks * sizeof(uint64_t)));
-    RCW_TRY(hipMalloc(&h->d_dir_table, (size_t)nd * sizeof(float2)));
-    RCW_TRY(hipMalloc(&h->d_ray_table, (size_t)nd * RCW_TABLE_ROWS * N * sizeof(float)));
+    RCW_TRY(hipMalloc(&h->d_dir_table, (size_t)nd * 2 * h->real_size));
+    RCW_TRY(hipMalloc(&h->d_ray_table, (size_t)nd * RCW_TABLE_ROWS * N * h->real_size));
     RCW_TRY(hipMalloc(&h->d_obs, B * (size_t)N * Hc * sizeof(uint32_t)));
     RCW_TRY(hipMalloc(&h->d_col_h, B * (size_t)N * sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_col_c, B * (size_t)N));
@@ -347,7 +384,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     RCW_TRY(hipMalloc(&h->d_actions, B));
     RCW_TRY(hipMalloc(&h->d_mask, B));
     RCW_TRY(hipMalloc(&h->d_in_goal, B * sizeof(int2)));
-    RCW_TRY(hipMalloc(&h->d_in_pos, B * sizeof(float2)));
+    RCW_TRY(hipMalloc(&h->d_in_pos, B * 2 * h->real_size));
     RCW_TRY(hipMalloc(&h->d_in_dir, B * sizeof(int32_t)));
     RCW_TRY(hipHostMalloc((void**)&h->h_err, sizeof(int32_t), hipHostMallocDefault));
     for (int k = 0; k < 2; ++k) {
@@ -367,6 +404,12 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.goal_reward = cfg->goal_reward;
     d.num = cfg->camera_height_tile_wu * (float)N;                      // SR:406 numerator
     d.two_fov = 2.0f * cfg->semi_field_of_view_wu;                      // 2 * fov
+    d.real64 = h->real64 ? 1 : 0;
+    d.radius64 = cfg->player_radius_wu_f64;
+    d.radius_sq64 = cfg->player_radius_wu_f64 * cfg->player_radius_wu_f64;
+    d.inc64 = cfg->position_increment_wu_f64;
+    d.num64 = cfg->camera_height_tile_wu_f64 * (double)N;
+    d.two_fov64 = 2.0 * cfg->semi_field_of_view_wu_f64;
     d.floor_color = cfg->floor_color; d.ceiling_color = cfg->ceiling_color;
     d.colour[RCW_COLOUR_WALL_DIM_1] = cfg->wall_dim_1_color;
     d.colour[RCW_COLOUR_WALL_DIM_2] = cfg->wall_dim_2_color;
@@ -377,10 +420,11 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.auto_reset = cfg->auto_reset ? 1 : 0;
     d.agent_id_offset = cfg->agent_id_offset;
     d.seed = seed;
-    d.pos = (float2*)h->d_pos; d.dir = (int32_t*)h->d_dir; d.goal = (int2*)h->d_goal;
+    d.pos = (float2*)h->d_pos; d.pos64 = (double2*)h->d_pos; d.dir = (int32_t*)h->d_dir; d.goal = (int2*)h->d_goal;
     d.reward = (float*)h->d_reward; d.done = (uint8_t*)h->d_done; d.episode = (uint32_t*)h->d_episode;
     d.tile_map = (uint32_t*)h->d_tile_map;
     d.dir_table = (const float2*)h->d_dir_table; d.ray_table = (const float*)h->d_ray_table;
+    d.dir_table64 = (const double2*)h->d_dir_table; d.ray_table64 = (const double*)h->d_ray_table;
     d.obs = (uint32_t*)h->d_obs; d.col_h = (int32_t*)h->d_col_h; d.col_c = (uint8_t*)h->d_col_c;
     d.err = (int32_t*)h->d_err;
     d.top_view = (uint32_t*)h->d_top_view; d.pu = cfg->pu_per_tu;
@@ -399,8 +443,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
         return fail(RCW_ERR_UNSUPPORTED, "tile map + column buffer need %zu B of LDS (> 64 KiB)", rcw_step_lds_bytes(d));
     }
 
-    build_direction_table(nd, h->dir_table);
-    build_ray_table(h->cfg, h->dir_table, h->ray_table);
+    if (h->real64) build_direction_table<double>(nd, h->dir_table64); else build_direction_table<float>(nd, h->dir_table);
+    rebuild_ray_table(h);
     rc = upload_tables(h);
     if (rc == RCW_OK) {
         hipError_t e = rcw_launch_init_tile_map(d, h->stream);
@@ -423,16 +467,31 @@ int rcw_destroy(rcw_handle* h)
     return RCW_OK;
 }
 
+extern "C++" {
+template <typename T>
+int set_direction_table_impl(rcw_handle* h, const T* directions_wu, std::vector<T>& table)
+{
+    if (!directions_wu) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL direction table");
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    table.assign(directions_wu, directions_wu + (size_t)2 * h->cfg.num_directions);
+    rebuild_ray_table(h);
+    int rc = upload_tables(h); if (rc) return rc;
+    RCW_HIP(launch_step(h, nullptr, nullptr));   // re-render
+    return RCW_OK;
+}
+}  // extern "C++"
+
 int rcw_set_direction_table(rcw_handle* h, const float* directions_wu)
 {
     int rc = check_handle(h); if (rc) return rc;
-    if (!directions_wu) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL direction table");
-    RCW_HIP(hipStreamSynchronize(h->stream));
-    h->dir_table.assign(directions_wu, directions_wu + (size_t)2 * h->cfg.num_directions);
-    build_ray_table(h->cfg, h->dir_table, h->ray_table);
-    rc = upload_tables(h); if (rc) return rc;
-    RCW_HIP(launch_step(h, nullptr, nullptr));   // re-render
-    return RCW_OK;
+    rc = check_real(h, false, "rcw_set_direction_table"); if (rc) return rc;
+    return set_direction_table_impl<float>(h, directions_wu, h->dir_table);
+}
+int rcw_set_direction_table64(rcw_handle* h, const double* directions_wu)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, true, "rcw_set_direction_table64"); if (rc) return rc;
+    return set_direction_table_impl<double>(h, directions_wu, h->dir_table64);
 }
 
 int rcw_set_stream(rcw_handle* h, void* hip_stream)
@@ -465,10 +524,11 @@ int rcw_reset(rcw_handle* h, const uint8_t* mask_host, uint64_t seed)
     return RCW_OK;
 }
 
-int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_wu,
-                  const int32_t* direction_au, const uint8_t* mask_host)
+extern "C++" {
+template <typename T>
+int set_state_impl(rcw_handle* h, const int32_t* goal_ij, const T* position_wu, const int32_t* direction_au,
+                   const uint8_t* mask_host)
 {
-    int rc = check_handle(h); if (rc) return rc;
     if (!goal_ij || !position_wu || !direction_au) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL state array");
     const int H = h->cfg.height_tile_map_tu, W = h->cfg.width_tile_map_tu;
     for (int32_t a = 0; a < h->B; ++a) {
@@ -478,21 +538,37 @@ int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_w
             return fail(RCW_ERR_INVALID_ARGUMENT, "agent %d: goal (%d,%d) not an interior tile", a, gi, gj);
         if (direction_au[a] < 0 || direction_au[a] >= h->cfg.num_directions)
             return fail(RCW_ERR_INVALID_ARGUMENT, "agent %d: direction %d not in 0..%d", a, direction_au[a], h->cfg.num_directions - 1);
-        const float x = position_wu[2 * a], y = position_wu[2 * a + 1];
-        if (!(std::isfinite(x) && std::isfinite(y) && x >= 1.0f && x < (float)(H - 1) && y >= 1.0f && y < (float)(W - 1)))
+        const T x = position_wu[2 * a], y = position_wu[2 * a + 1];
+        if (!(std::isfinite(x) && std::isfinite(y) && x >= (T)1 && x < (T)(H - 1) && y >= (T)1 && y < (T)(W - 1)))
             return fail(RCW_ERR_INVALID_ARGUMENT, "agent %d: position (%g,%g) not inside the room", a, (double)x, (double)y);
     }
     const uint8_t* mask_dev = nullptr;
-    rc = upload_mask(h, mask_host, &mask_dev); if (rc) return rc;
+    int rc = upload_mask(h, mask_host, &mask_dev); if (rc) return rc;
     const size_t B = (size_t)h->B;
     RCW_HIP(hipMemcpyAsync(h->d_in_goal, goal_ij, B * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    RCW_HIP(hipMemcpyAsync(h->d_in_pos, position_wu, B * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    RCW_HIP(hipMemcpyAsync(h->d_in_pos, position_wu, B * 2 * sizeof(T), hipMemcpyHostToDevice, h->stream));
     RCW_HIP(hipMemcpyAsync(h->d_in_dir, direction_au, B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     RCW_HIP(hipStreamSynchronize(h->stream));
-    RCW_HIP(rcw_launch_set_state(h->dev, (const int2*)h->d_in_goal, (const float2*)h->d_in_pos,
-                                 (const int32_t*)h->d_in_dir, mask_dev, h->stream));
+    RCW_HIP(rcw_launch_set_state(h->dev, (const int2*)h->d_in_goal, h->d_in_pos, (const int32_t*)h->d_in_dir, mask_dev,
+                                 h->stream));
     RCW_HIP(launch_step(h, nullptr, mask_dev));
     return RCW_OK;
+}
+}  // extern "C++"
+
+int rcw_set_state(rcw_handle* h, const int32_t* goal_ij, const float* position_wu,
+                  const int32_t* direction_au, const uint8_t* mask_host)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, false, "rcw_set_state"); if (rc) return rc;
+    return set_state_impl<float>(h, goal_ij, position_wu, direction_au, mask_host);
+}
+int rcw_set_state64(rcw_handle* h, const int32_t* goal_ij, const double* position_wu,
+                    const int32_t* direction_au, const uint8_t* mask_host)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, true, "rcw_set_state64"); if (rc) return rc;
+    return set_state_impl<double>(h, goal_ij, position_wu, direction_au, mask_host);
 }
 
 int rcw_step(rcw_handle* h, const uint8_t* actions_host)
@@ -580,7 +656,18 @@ int rcw_top_view_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t 
 
 int rcw_reward(rcw_handle* h, float* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_reward, (size_t)h->B); }
 int rcw_done(rcw_handle* h, uint8_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_done, (size_t)h->B); }
-int rcw_position(rcw_handle* h, float* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_pos, (size_t)2 * h->B); }
+int rcw_position(rcw_handle* h, float* out)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, false, "rcw_position"); if (rc) return rc;
+    return copy_out(h, out, h->d_pos, (size_t)2 * h->B);
+}
+int rcw_position64(rcw_handle* h, double* out)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, true, "rcw_position64"); if (rc) return rc;
+    return copy_out(h, out, h->d_pos, (size_t)2 * h->B);
+}
 int rcw_direction(rcw_handle* h, int32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_dir, (size_t)h->B); }
 int rcw_goal(rcw_handle* h, int32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_goal, (size_t)2 * h->B); }
 int rcw_episode(rcw_handle* h, uint32_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_episode, (size_t)h->B); }
@@ -616,10 +703,11 @@ int rcw_tile_map_chunks(rcw_handle* h, uint64_t* out)
     return copy_out(h, out, h->d_tile_map, (size_t)h->nchunks * h->B);
 }
 
-int rcw_rays(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int64_t* hit_dimension,
-             float* distance_wu, float* directions_wu)
+extern "C++" {
+template <typename T>
+int rays_impl(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int64_t* hit_dimension,
+              T* distance_wu, T* directions_wu)
 {
-    int rc = check_handle(h); if (rc) return rc;
     if (first < 0 || count < 1 || first + (int64_t)count > h->B)
         return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
     const size_t n = (size_t)count * h->cfg.num_rays;
@@ -629,17 +717,33 @@ int rcw_rays(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int6
 #define RCW_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(RCW_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
     if (stop_ij) { RCW_TRY(hipMalloc(&bufs[0], 2 * n * sizeof(int64_t))); out.stop_ij = (int64_t*)bufs[0]; }
     if (hit_dimension) { RCW_TRY(hipMalloc(&bufs[1], n * sizeof(int64_t))); out.hit_dim = (int64_t*)bufs[1]; }
-    if (distance_wu) { RCW_TRY(hipMalloc(&bufs[2], n * sizeof(float))); out.dist = (float*)bufs[2]; }
-    if (directions_wu) { RCW_TRY(hipMalloc(&bufs[3], 2 * n * sizeof(float))); out.dirs = (float*)bufs[3]; }
+    if (distance_wu) { RCW_TRY(hipMalloc(&bufs[2], n * sizeof(T))); out.dist = bufs[2]; }
+    if (directions_wu) { RCW_TRY(hipMalloc(&bufs[3], 2 * n * sizeof(T))); out.dirs = bufs[3]; }
     RCW_TRY(rcw_launch_rays(h->dev, first, count, out, h->stream));
     RCW_TRY(hipStreamSynchronize(h->stream));
     if (stop_ij) RCW_TRY(hipMemcpy(stop_ij, bufs[0], 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (hit_dimension) RCW_TRY(hipMemcpy(hit_dimension, bufs[1], n * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (distance_wu) RCW_TRY(hipMemcpy(distance_wu, bufs[2], n * sizeof(float), hipMemcpyDeviceToHost));
-    if (directions_wu) RCW_TRY(hipMemcpy(directions_wu, bufs[3], 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (distance_wu) RCW_TRY(hipMemcpy(distance_wu, bufs[2], n * sizeof(T), hipMemcpyDeviceToHost));
+    if (directions_wu) RCW_TRY(hipMemcpy(directions_wu, bufs[3], 2 * n * sizeof(T), hipMemcpyDeviceToHost));
 #undef RCW_TRY
     cleanup();
     return RCW_OK;
+}
+}  // extern "C++"
+
+int rcw_rays(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int64_t* hit_dimension,
+             float* distance_wu, float* directions_wu)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, false, "rcw_rays"); if (rc) return rc;
+    return rays_impl<float>(h, first, count, stop_ij, hit_dimension, distance_wu, directions_wu);
+}
+int rcw_rays64(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int64_t* hit_dimension,
+               double* distance_wu, double* directions_wu)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = check_real(h, true, "rcw_rays64"); if (rc) return rc;
+    return rays_impl<double>(h, first, count, stop_ij, hit_dimension, distance_wu, directions_wu);
 }
 
 int rcw_columns(rcw_handle* h, int32_t first, int32_t count, int32_t* height_line_pu, uint8_t* colour_id)
@@ -678,13 +782,29 @@ int rcw_expand_columns(rcw_handle* h, const int32_t* height_line_pu_device, cons
 int rcw_ray_table(rcw_handle* h, float* out)
 {
     if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_real(h, false, "rcw_ray_table"); if (rc) return rc;
     std::memcpy(out, h->ray_table.data(), h->ray_table.size() * sizeof(float));
     return RCW_OK;
 }
 int rcw_direction_table(rcw_handle* h, float* out)
 {
     if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_real(h, false, "rcw_direction_table"); if (rc) return rc;
     std::memcpy(out, h->dir_table.data(), h->dir_table.size() * sizeof(float));
+    return RCW_OK;
+}
+int rcw_ray_table64(rcw_handle* h, double* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_real(h, true, "rcw_ray_table64"); if (rc) return rc;
+    std::memcpy(out, h->ray_table64.data(), h->ray_table64.size() * sizeof(double));
+    return RCW_OK;
+}
+int rcw_direction_table64(rcw_handle* h, double* out)
+{
+    if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_real(h, true, "rcw_direction_table64"); if (rc) return rc;
+    std::memcpy(out, h->dir_table64.data(), h->dir_table64.size() * sizeof(double));
     return RCW_OK;
 }
 

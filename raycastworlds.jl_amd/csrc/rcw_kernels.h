@@ -13,11 +13,13 @@ struct RcwDev {
     // geometry / config (all wave-uniform, live in SGPRs)
     int32_t B, H, W, N, nd, Hc;
     int32_t nwords;          // 32-bit words of one agent's tile_map (2 per UInt64 chunk)
+    int32_t real64;          // world-unit type T: 0 = Float32, 1 = Float64 (SR:259); the *64 members below
     float radius, radius_sq; // player_radius_wu, fl(r*r)            (CD:18)
     float inc;               // position_increment_wu                (UT:16-17)
     float goal_reward;       // SR:86
     float num;               // fl(camera_height_tile_wu * N)        (SR:406)
     float two_fov;           // fl(2 * semi_field_of_view_wu)        (SR:406)
+    double radius64, radius_sq64, inc64, num64, two_fov64;   // the same five in Float64
     uint32_t floor_color, ceiling_color;
     uint32_t colour[4];      // indexed by RCW_COLOUR_*              (SR:293-296)
     int32_t tie_le;          // RCW_DDA_TIE_X_FIRST_ON_LE
@@ -30,7 +32,8 @@ struct RcwDev {
     int64_t agent_id_offset;
     uint64_t seed;
     // state (SR:21-40), one entry per agent
-    float2* pos;             // player_position_wu
+    float2* pos;             // player_position_wu (T = Float32)
+    double2* pos64;          // player_position_wu (T = Float64)
     int32_t* dir;            // player_direction_au
     int2* goal;              // goal_position (1-based i, j)
     float* reward;
@@ -40,6 +43,8 @@ struct RcwDev {
     // constants
     const float2* dir_table; // directions_wu [nd]
     const float* ray_table;  // [nd][RCW_TABLE_ROWS][N]
+    const double2* dir_table64;   // the two tables in Float64
+    const double* ray_table64;
     // outputs
     uint32_t* obs;           // camera_view UInt32 (Hc, N, B)
     int32_t* col_h;          // (N, B) height_line_pu by image column
@@ -53,8 +58,8 @@ struct RcwDev {
 struct RcwRayOut {           // rcw_rays(): SR:29-31,39 for agents [first, first+count)
     int64_t* stop_ij;        // (2, N, count)
     int64_t* hit_dim;        // (N, count)
-    float* dist;             // (N, count)
-    float* dirs;             // (2, N, count)
+    void* dist;              // (N, count) in T
+    void* dirs;              // (2, N, count) in T
 };
 
 size_t rcw_step_lds_bytes(const RcwDev& p);
@@ -69,7 +74,7 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
 // update_top_view!(env) SR:446-483 for every (unmasked) agent; needs p.top_view
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
-hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const float2* pos,
+hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos /* float2* or double2* */,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_init_tile_map(const RcwDev& p, hipStream_t s);
 hipError_t rcw_launch_rays(const RcwDev& p, int32_t first, int32_t count, RcwRayOut out,

@@ -49,6 +49,43 @@ __device__ __forceinline__ void set_goal_bit(uint32_t* tm, int H, int i, int j, 
     if (v) tm[t >> 4] |= m; else tm[t >> 4] &= ~m;
 }
 
+// ---- the reference's world-unit type T (SingleRoom(; T = ...) SR:259), compiled in: every
+// Float32 operation of the path is the same operation in T.  R (reward) is always Float32. ----
+template <typename T> struct Real;
+template <> struct Real<float> {
+    typedef float2 vec2;
+    static __device__ __forceinline__ vec2* pos(const RcwDev& p) { return p.pos; }
+    static __device__ __forceinline__ const vec2* dir_table(const RcwDev& p) { return p.dir_table; }
+    static __device__ __forceinline__ const float* ray_table(const RcwDev& p) { return p.ray_table; }
+    static __device__ __forceinline__ float radius(const RcwDev& p) { return p.radius; }
+    static __device__ __forceinline__ float radius_sq(const RcwDev& p) { return p.radius_sq; }
+    static __device__ __forceinline__ float inc(const RcwDev& p) { return p.inc; }
+    static __device__ __forceinline__ float num(const RcwDev& p) { return p.num; }
+    static __device__ __forceinline__ float two_fov(const RcwDev& p) { return p.two_fov; }
+    static __device__ __forceinline__ vec2 make(float x, float y) { return make_float2(x, y); }
+};
+template <> struct Real<double> {
+    typedef double2 vec2;
+    static __device__ __forceinline__ vec2* pos(const RcwDev& p) { return p.pos64; }
+    static __device__ __forceinline__ const vec2* dir_table(const RcwDev& p) { return p.dir_table64; }
+    static __device__ __forceinline__ const double* ray_table(const RcwDev& p) { return p.ray_table64; }
+    static __device__ __forceinline__ double radius(const RcwDev& p) { return p.radius64; }
+    static __device__ __forceinline__ double radius_sq(const RcwDev& p) { return p.radius_sq64; }
+    static __device__ __forceinline__ double inc(const RcwDev& p) { return p.inc64; }
+    static __device__ __forceinline__ double num(const RcwDev& p) { return p.num64; }
+    static __device__ __forceinline__ double two_fov(const RcwDev& p) { return p.two_fov64; }
+    static __device__ __forceinline__ vec2 make(double x, double y) { return make_double2(x, y); }
+};
+__device__ __forceinline__ float rfloor(float x) { return floorf(x); }
+__device__ __forceinline__ double rfloor(double x) { return floor(x); }
+// floor(Int, x) saturated to Int32 (the reference raises InexactError only beyond Int64)
+__device__ __forceinline__ int floor_to_int32(float f)
+{
+    const int h = (int)fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);
+    return f >= 2147483648.0f ? INT_MAX : h;
+}
+__device__ __forceinline__ int floor_to_int32(double f) { return (int)fmin(fmax(f, -2147483648.0), 2147483647.0); }
+
 // In LDS the tile map is staged UNPACKED, one byte per tile (value = the tile's 2 bits), so a
 // lookup in the ray march is a single ds_read_u8 at the linear tile index.
 __device__ __forceinline__ void stage_tile_bytes(uint8_t* tb, const uint32_t* tm_hbm, int HW, int tid, int nthreads)
@@ -64,23 +101,25 @@ struct Collide { int wall, goal; };
 // Wave-parallel form: lane t < 9 tests tile t of the neighbourhood in the reference's visiting
 // order (t = 3 (j - jt + 1) + (i - it + 1)); three ballots recover "first event in order" per
 // layer.  Every lane of the wave gets the same (wave-uniform) result.  px, py are uniform.
-__device__ __forceinline__ Collide player_colliding(const uint8_t* tb, int H, int W, float px,
-                                                    float py, float radius_sq, int oob_empty)
+template <typename T>
+__device__ __forceinline__ Collide player_colliding(const uint8_t* tb, int H, int W, T px, T py, T radius_sq,
+                                                    int oob_empty)
 {
-    const int it = (int)floorf(px) + 1;   // wu_to_tu UT:5
-    const int jt = (int)floorf(py) + 1;
+    const int it = (int)rfloor(px) + 1;   // wu_to_tu UT:5
+    const int jt = (int)rfloor(py) + 1;
     const int t = (int)(threadIdx.x & 63u);
     const int tq = t / 3;
     const int i = it - 1 + (t - 3 * tq), j = jt - 1 + tq;
     const bool valid = t < 9;
     const bool inb = i >= 1 && i <= H && j >= 1 && j <= W;
     const uint32_t bits = (valid && inb) ? (uint32_t)tb[(i - 1) + H * (j - 1)] : 0u;
-    const float cx = (float)i - 0.5f, cy = (float)j - 0.5f;          // CD:33-34
-    const float qx = px - cx, qy = py - cy;                          // CD:35
-    const float sx = qx < -0.5f ? -0.5f : (qx > 0.5f ? 0.5f : qx);   // clamp CD:11
-    const float sy = qy < -0.5f ? -0.5f : (qy > 0.5f ? 0.5f : qy);
-    const float vx = qx - sx, vy = qy - sy;                          // CD:16
-    const float vx2 = vx * vx, vy2 = vy * vy;
+    const T half = (T)0.5;
+    const T cx = (T)i - half, cy = (T)j - half;                      // CD:33-34
+    const T qx = px - cx, qy = py - cy;                              // CD:35
+    const T sx = qx < -half ? -half : (qx > half ? half : qx);       // clamp CD:11
+    const T sy = qy < -half ? -half : (qy > half ? half : qy);
+    const T vx = qx - sx, vy = qy - sy;                              // CD:16
+    const T vx2 = vx * vx, vy2 = vy * vy;
     const bool hit = (vx2 + vy2) < radius_sq;                        // CD:18
     const unsigned long long m_oob = __ballot(valid && !inb && !oob_empty);
     const unsigned long long m_wall = __ballot(hit && (bits & 1u));
@@ -96,8 +135,9 @@ __device__ __forceinline__ Collide player_colliding(const uint8_t* tb, int H, in
 
 // ---- reset!(world)  SR:110-137 with the counter-based generator -------------------------
 // tm_a / tm_b: the agent's tile map words in up to two places (LDS copy and HBM).
-struct Pose { float x, y; int d; };
-__device__ __forceinline__ Pose reset_agent(const RcwDev& p, int a, uint32_t* tm_a, uint32_t* tm_b)
+template <typename T> struct Pose { T x, y; int d; };
+template <typename T>
+__device__ __forceinline__ Pose<T> reset_agent(const RcwDev& p, int a, uint32_t* tm_a, uint32_t* tm_b)
 {
     const int H = p.H, W = p.W;
     const uint32_t ep = p.episode[a];
@@ -121,11 +161,11 @@ __device__ __forceinline__ Pose reset_agent(const RcwDev& p, int a, uint32_t* tm
         else break;
     }
     const int pi = (int)(lin % (uint64_t)H) + 1, pj = (int)(lin / (uint64_t)H) + 1;
-    Pose o;
-    o.x = (float)((double)pi - 0.5);                                          // SR:125
-    o.y = (float)((double)pj - 0.5);
+    Pose<T> o;
+    o.x = (T)((double)pi - 0.5);                                              // SR:125
+    o.y = (T)((double)pj - 0.5);
     o.d = (int)rcw_below(rcw_draw(key, n++), (uint64_t)p.nd);                  // SR:128
-    p.pos[a] = make_float2(o.x, o.y);                                         // SR:126
+    Real<T>::pos(p)[a] = Real<T>::make(o.x, o.y);                             // SR:126
     p.dir[a] = o.d;                                                           // SR:129
     p.reward[a] = 0.0f;                                                       // SR:131
     p.done[a] = 0;                                                            // SR:132
@@ -135,7 +175,7 @@ __device__ __forceinline__ Pose reset_agent(const RcwDev& p, int a, uint32_t* tm
 
 // ---- RayCaster.cast_ray  (external; call site SR:223).  UNPINNED choices via p.tie_le /
 // p.dist_pre (include/rcw.h).  Leaves the map -> oob (Julia: BoundsError). ------------------
-struct RayHit { int t, dim; float dist; uint32_t bits; bool oob; };
+template <typename T> struct RayHit { int t, dim; T dist; uint32_t bits; bool oob; };
 // The march is written with selects, not branches (lanes of a wavefront disagree on the step
 // axis at almost every iteration; a divergent if/else costs more in exec-mask bookkeeping than
 // the few v_cndmask), and it carries only what the result needs: the two side distances, the
@@ -143,23 +183,22 @@ struct RayHit { int t, dim; float dist; uint32_t bits; bool oob; };
 // issue rate bounds this loop (B·N rays x trip count x instructions), so every instruction
 // counts.  A closed wall ring (SR:57-60) stops every ray; `cap` only guards a corrupt map
 // against hanging the wavefront, and is reported as out of bounds.
-template <bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ RayHit cast_ray(const uint8_t* tb, int H, int W, float x, float y,
-                                           float dx, float dy, float ddx, float ddy)
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__device__ __forceinline__ RayHit<T> cast_ray(const uint8_t* tb, int H, int W, T x, T y, T dx, T dy, T ddx, T ddy)
 {
-    const int i0 = (int)floorf(x) + 1;    // wu_to_tu UT:5
-    const int j0 = (int)floorf(y) + 1;
-    const bool neg_x = dx < 0.0f, neg_y = dy < 0.0f;
+    const int i0 = (int)rfloor(x) + 1;    // wu_to_tu UT:5
+    const int j0 = (int)rfloor(y) + 1;
+    const bool neg_x = dx < (T)0, neg_y = dy < (T)0;
     const int si = neg_x ? -1 : 1;
     const int tj = neg_y ? -H : H;
-    const float fx = neg_x ? x - (float)(i0 - 1) : (float)i0 - x;
-    const float fy = neg_y ? y - (float)(j0 - 1) : (float)j0 - y;
-    float sx = fx * ddx, sy = fy * ddy;
+    const T fx = neg_x ? x - (T)(i0 - 1) : (T)i0 - x;
+    const T fy = neg_y ? y - (T)(j0 - 1) : (T)j0 - y;
+    T sx = fx * ddx, sy = fy * ddy;
     int t = (i0 - 1) + H * (j0 - 1);
     const unsigned last = (unsigned)(H * W - 1);
     const int cap = H + W;
-    RayHit r;
-    r.dim = 0; r.dist = 0.0f;
+    RayHit<T> r;
+    r.dim = 0; r.dist = (T)0;
     int n = 0;
     for (;;) {
         const unsigned tc = (unsigned)t < last ? (unsigned)t : last;      // never read outside the map
@@ -167,7 +206,7 @@ __device__ __forceinline__ RayHit cast_ray(const uint8_t* tb, int H, int W, floa
         if (r.bits != 0u || n >= cap) break;
         ++n;
         const bool xf = TIE_LE ? (sx <= sy) : (sx < sy);
-        const float nx = sx + ddx, ny = sy + ddy;
+        const T nx = sx + ddx, ny = sy + ddy;
         if (DIST_PRE) r.dist = xf ? sx : sy;
         sx = xf ? nx : sx;
         sy = xf ? sy : ny;
@@ -176,24 +215,22 @@ __device__ __forceinline__ RayHit cast_ray(const uint8_t* tb, int H, int W, floa
     }
     r.oob = r.bits == 0u || (unsigned)t > last;
     if (!DIST_PRE) {
-        const float d1 = sx - ddx, d2 = sy - ddy;
-        r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : 0.0f);
+        const T d1 = sx - ddx, d2 = sy - ddy;
+        r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : (T)0);
     }
     r.t = t;
     return r;
 }
 
 // ---- column height  SR:404-411 ------------------------------------------------------------
-__device__ __forceinline__ int height_line_pu(const RcwDev& p, float dist, float dot)
+template <typename T>
+__device__ __forceinline__ int height_line_pu(const RcwDev& p, T dist, T dot)
 {
-    const float projected = dist * dot;               // SR:404
-    const float den = p.two_fov * projected;          // (2 * fov) * projected
-    const float height_line = p.num / den;            // SR:406
-    const float f = floorf(height_line);              // floor(Int, .) SR:408, saturated to Int32
-    const float fc = fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);
-    int h = (int)fc;
-    h = f >= 2147483648.0f ? INT_MAX : h;
-    return isfinite(height_line) ? h : p.Hc;          // SR:407-411
+    const T projected = dist * dot;                           // SR:404
+    const T den = Real<T>::two_fov(p) * projected;            // (2 * fov) * projected
+    const T height_line = Real<T>::num(p) / den;              // SR:406
+    const int h = floor_to_int32(rfloor(height_line));        // floor(Int, .) SR:408
+    return isfinite(height_line) ? h : p.Hc;                  // SR:407-411
 }
 __device__ __forceinline__ int column_padding(int Hc, int h)
 {
@@ -213,7 +250,7 @@ __device__ __forceinline__ uint32_t pixel(int r, int pad, int Hc, uint32_t colou
 // image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
 // of pixels the fill kernel then writes for it.
 // TIE_LE / DIST_PRE: the UNPINNED cast_ray choices (include/rcw.h), compiled in.
-template <bool TIE_LE, bool DIST_PRE>
+template <typename T, bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
                                                           const uint8_t* __restrict__ actions,
                                                           const uint8_t* __restrict__ mask)
@@ -224,17 +261,19 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     if (mask != nullptr && mask[a] == 0) return;
 
     uint8_t* tb = reinterpret_cast<uint8_t*>(lds);          // [H*W] the agent's tile map, a byte per tile
-    __shared__ float s_pose[4];
+    __shared__ T s_pose[2];
+    __shared__ int s_pose_d;
+    typedef typename Real<T>::vec2 vec2;
     const int HW = p.H * p.W;
 
     // ---- every load of the agent's state is issued up front (all wave-uniform addresses) ----
     uint32_t* tm_hbm = p.tile_map + (size_t)a * p.nwords;
     stage_tile_bytes(tb, tm_hbm, HW, tid, (int)blockDim.x);
     int act = actions ? (int)actions[a] : 0;
-    const float2 pos = p.pos[a];
+    const vec2 pos = Real<T>::pos(p)[a];
     const int d = p.dir[a];
     const int was_done = p.done[a];
-    const float2 dv = p.dir_table[d];                                       // SR:153
+    const vec2 dv = Real<T>::dir_table(p)[d];                               // SR:153
     const bool invalid = actions != nullptr && (act < 1 || act > RCW_NUM_ACTIONS);   // @assert SR:140
     if (invalid) act = 0;                                                   // this agent is not stepped
     const bool resample = act != 0 && p.auto_reset != 0 && was_done != 0;
@@ -248,26 +287,26 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     __syncthreads();
 
     // ---- phase 0: dynamics, computed redundantly by every lane (no broadcast needed) --------
-    float x = pos.x, y = pos.y;
+    T x = pos.x, y = pos.y;
     if (resample) {                                                         // wave-uniform, rare
         if (tid == 0) {
-            const Pose np = reset_agent(p, a, tm_hbm, nullptr);
-            s_pose[0] = np.x; s_pose[1] = np.y; s_pose[2] = __int_as_float(np.d);
+            const Pose<T> np = reset_agent<T>(p, a, tm_hbm, nullptr);
+            s_pose[0] = np.x; s_pose[1] = np.y; s_pose_d = np.d;
         }
         __syncthreads();
         stage_tile_bytes(tb, tm_hbm, HW, tid, (int)blockDim.x);             // the goal moved
         __syncthreads();
         x = s_pose[0]; y = s_pose[1];
-        d_new = __float_as_int(s_pose[2]);
+        d_new = s_pose_d;
     } else if (act != 0) {
         float reward = 0.0f;
         int done = 0;
         bool oob = false;
         if (act <= 2) {                                                     // SR:150
-            const float ix = p.inc * dv.x, iy = p.inc * dv.y;
-            const float nx = act == 1 ? pos.x + ix : pos.x - ix;            // UT:16-17
-            const float ny = act == 1 ? pos.y + iy : pos.y - iy;
-            const Collide c = player_colliding(tb, p.H, p.W, nx, ny, p.radius_sq, p.oob_empty);   // SR:162-163
+            const T ix = Real<T>::inc(p) * dv.x, iy = Real<T>::inc(p) * dv.y;
+            const T nx = act == 1 ? pos.x + ix : pos.x - ix;                // UT:16-17
+            const T ny = act == 1 ? pos.y + iy : pos.y - iy;
+            const Collide c = player_colliding<T>(tb, p.H, p.W, nx, ny, Real<T>::radius_sq(p), p.oob_empty);   // SR:162-163
             if (c.wall == 2 || c.goal == 2) oob = true;                     // BoundsError: no mutation
             else if (c.goal) { reward = p.goal_reward; done = 1; }          // SR:166-168
             else if (c.wall) { }                                            // SR:170-171
@@ -278,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
                 p.err[0] = RCW_ERR_OUT_OF_BOUNDS;
                 p.status[a] = RCW_ERR_OUT_OF_BOUNDS;
             } else {
-                p.pos[a] = make_float2(x, y);                               // SR:174
+                Real<T>::pos(p)[a] = Real<T>::make(x, y);                   // SR:174
                 p.dir[a] = d_new;                                           // SR:185
                 p.reward[a] = reward; p.done[a] = (uint8_t)done;            // SR:175-176, SR:186-187
             }
@@ -288,14 +327,14 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     d_new = __builtin_amdgcn_readfirstlane(d_new);
 
     // ---- phase 1: one lane per view column --------------------------------------------------
-    const float* tab = p.ray_table + (size_t)d_new * RCW_TABLE_ROWS * p.N;
+    const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * p.N;
     for (int i = tid; i < p.N; i += (int)blockDim.x) {                        // SR:220, SR:401
-        const float dx = tab[i], dy = tab[p.N + i];
-        const float ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
-        const float dot = tab[4 * p.N + i];
-        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+        const T dx = tab[i], dy = tab[p.N + i];
+        const T ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
+        const T dot = tab[4 * p.N + i];
+        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
-        const int h = r.oob ? p.Hc : height_line_pu(p, r.dist, dot);
+        const int h = r.oob ? p.Hc : height_line_pu<T>(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
         const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);
         const int k = p.N - 1 - i;                                          // SR:431 (0-based)
@@ -408,17 +447,19 @@ __global__ void rcw_init_tile_map_kernel(const RcwDev p)
     p.status[a] = 0;
 }
 
+template <typename T>
 __global__ void rcw_reset_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= p.B) return;
     if (mask != nullptr && mask[a] == 0) return;
-    reset_agent(p, a, p.tile_map + (size_t)a * p.nwords, nullptr);
+    reset_agent<T>(p, a, p.tile_map + (size_t)a * p.nwords, nullptr);
 }
 
 // inject post-reset state: SR:118-132 with caller-chosen draws
+template <typename T>
 __global__ void rcw_set_state_kernel(const RcwDev p, const int2* __restrict__ goal,
-                                     const float2* __restrict__ pos, const int32_t* __restrict__ dir,
+                                     const typename Real<T>::vec2* __restrict__ pos, const int32_t* __restrict__ dir,
                                      const uint8_t* __restrict__ mask)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,14 +471,14 @@ __global__ void rcw_set_state_kernel(const RcwDev p, const int2* __restrict__ go
     const int2 g = goal[a];
     p.goal[a] = g;                                // SR:121
     set_goal_bit(tm, p.H, g.x, g.y, true);        // SR:122
-    p.pos[a] = pos[a];                            // SR:126
+    Real<T>::pos(p)[a] = pos[a];                  // SR:126
     p.dir[a] = dir[a];                            // SR:129
     p.reward[a] = 0.0f;                           // SR:131
     p.done[a] = 0;                                // SR:132
 }
 
 // cast_rays!(world) SR:195-231 with the ray buffers materialised (rcw_rays)
-template <bool TIE_LE, bool DIST_PRE>
+template <typename T, bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int first, RcwRayOut out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -447,19 +488,21 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
     uint8_t* tb = reinterpret_cast<uint8_t*>(lds);
     stage_tile_bytes(tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kBlock);
     __syncthreads();
-    const float2 pos = p.pos[a];
+    const typename Real<T>::vec2 pos = Real<T>::pos(p)[a];
     const int d = p.dir[a];
-    const float* tab = p.ray_table + (size_t)d * RCW_TABLE_ROWS * p.N;
+    const T* tab = Real<T>::ray_table(p) + (size_t)d * RCW_TABLE_ROWS * p.N;
+    T* out_dist = static_cast<T*>(out.dist);
+    T* out_dirs = static_cast<T*>(out.dirs);
     for (int i = tid; i < p.N; i += kBlock) {
-        const float dx = tab[i], dy = tab[p.N + i];
-        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
-                                                    tab[3 * p.N + i]);
+        const T dx = tab[i], dy = tab[p.N + i];
+        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+                                                          tab[3 * p.N + i]);
         const int hit_j = r.t / p.H, hit_i = r.t - hit_j * p.H;           // 0-based stop tile
         const size_t q = (size_t)local * p.N + i;
         if (out.stop_ij) { out.stop_ij[2 * q] = r.oob ? 1 : hit_i + 1; out.stop_ij[2 * q + 1] = r.oob ? 1 : hit_j + 1; }
         if (out.hit_dim) out.hit_dim[q] = r.oob ? 0 : r.dim;
-        if (out.dist) out.dist[q] = r.oob ? 0.0f : r.dist;
-        if (out.dirs) { out.dirs[2 * q] = dx; out.dirs[2 * q + 1] = dy; }
+        if (out_dist) out_dist[q] = r.oob ? (T)0 : r.dist;
+        if (out_dirs) { out_dirs[2 * q] = dx; out_dirs[2 * q + 1] = dy; }
     }
 }
 
@@ -473,7 +516,8 @@ __device__ __forceinline__ void put_pixel(uint32_t* img, int Ht, int Wt, int i, 
 {
     if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) img[(size_t)(i - 1) + (size_t)Ht * (j - 1)] = c;
 }
-__device__ __forceinline__ int wu_to_pu(float x, int pu) { return (int)floorf(x * (float)pu) + 1; }   // UT:6
+template <typename T>
+__device__ __forceinline__ int wu_to_pu(T x, int pu) { return (int)rfloor(x * (T)pu) + 1; }   // UT:6
 
 __device__ __forceinline__ uint32_t top_view_tile_pixel(const uint8_t* tb, int H, int pu, int ip0, int jp0)
 {
@@ -484,7 +528,7 @@ __device__ __forceinline__ uint32_t top_view_tile_pixel(const uint8_t* tb, int H
     return (bits & 1u) ? 0x00FFFFFFu : ((bits & 2u) ? 0x00FF0000u : 0x00000000u); // findfirst SR:355-360, colours SR:288
 }
 
-template <bool TIE_LE, bool DIST_PRE>
+template <typename T, bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -520,19 +564,19 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
     __syncthreads();   // (waits for the stores above: the lines below overwrite some of those pixels)
 
     // ---- one line per ray from the player to the ray's stop point  SR:473-477 ----
-    const float2 pos = p.pos[a];
+    const typename Real<T>::vec2 pos = Real<T>::pos(p)[a];
     const int d = p.dir[a];
-    const int ip = wu_to_pu(pos.x, pu), jp = wu_to_pu(pos.y, pu);            // SR:468
-    const float* tab = p.ray_table + (size_t)d * RCW_TABLE_ROWS * p.N;
+    const int ip = wu_to_pu<T>(pos.x, pu), jp = wu_to_pu<T>(pos.y, pu);      // SR:468
+    const T* tab = Real<T>::ray_table(p) + (size_t)d * RCW_TABLE_ROWS * p.N;
     for (int i = tid; i < p.N; i += kBlock) {
-        const float dx = tab[i], dy = tab[p.N + i];
-        const RayHit r = cast_ray<TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
-                                                    tab[3 * p.N + i]);
-        const float dist = r.oob ? 0.0f : r.dist;
-        const float ox = dist * dx, oy = dist * dy;                          // ray_distance_wu * ray_direction_wu
-        const float ex = pos.x + ox, ey = pos.y + oy;
+        const T dx = tab[i], dy = tab[p.N + i];
+        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+                                                          tab[3 * p.N + i]);
+        const T dist = r.oob ? (T)0 : r.dist;
+        const T ox = dist * dx, oy = dist * dy;                              // ray_distance_wu * ray_direction_wu
+        const T ex = pos.x + ox, ey = pos.y + oy;
         int i1 = ip, j1 = jp;
-        const int i2 = wu_to_pu(ex, pu), j2 = wu_to_pu(ey, pu);
+        const int i2 = wu_to_pu<T>(ex, pu), j2 = wu_to_pu<T>(ey, pu);
         // SD.Line: Bresenham, all octants, both end points (assumed)
         const int di = abs(i2 - i1), dj = -abs(j2 - j1);
         const int si = i1 < i2 ? 1 : -1, sj = j1 < j2 ? 1 : -1;
@@ -549,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
 
     // ---- the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed) ----
     if (tid == 0) {
-        const int rp = wu_to_pu(p.radius, pu);                               // SR:469
+        const int rp = wu_to_pu<T>(Real<T>::radius(p), pu);                  // SR:469
         int x = 0, y = rp, dd = 1 - rp;
         while (x <= y) {
             put_pixel(img, Ht, Wt, ip + x, jp + y, 0x00c0c0c0u); put_pixel(img, Ht, Wt, ip - x, jp + y, 0x00c0c0c0u);
@@ -592,44 +636,53 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     return hipGetLastError();
 }
 
+// Dispatch on the compiled-in choices: world-unit type T (p.real64) and the two UNPINNED cast_ray
+// switches.  KERNEL is a template name taking <T, TIE_LE, DIST_PRE>.
+#define RCW_DISPATCH(KERNEL, GRID, BLOCK, LDS, ...)                                                          \
+    do {                                                                                                     \
+        if (p.real64) {                                                                                      \
+            if (p.tie_le) { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<double, true, true>), GRID, BLOCK, LDS, s, __VA_ARGS__);   \
+                            else            hipLaunchKernelGGL((KERNEL<double, true, false>), GRID, BLOCK, LDS, s, __VA_ARGS__); } \
+            else          { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<double, false, true>), GRID, BLOCK, LDS, s, __VA_ARGS__);  \
+                            else            hipLaunchKernelGGL((KERNEL<double, false, false>), GRID, BLOCK, LDS, s, __VA_ARGS__); } \
+        } else {                                                                                             \
+            if (p.tie_le) { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<float, true, true>), GRID, BLOCK, LDS, s, __VA_ARGS__);    \
+                            else            hipLaunchKernelGGL((KERNEL<float, true, false>), GRID, BLOCK, LDS, s, __VA_ARGS__); }  \
+            else          { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<float, false, true>), GRID, BLOCK, LDS, s, __VA_ARGS__);   \
+                            else            hipLaunchKernelGGL((KERNEL<float, false, false>), GRID, BLOCK, LDS, s, __VA_ARGS__); } \
+        }                                                                                                    \
+    } while (0)
+
 hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s)
 {
-    const dim3 grid(p.B), block(p.cast_block);
-    const size_t lds = rcw_step_lds_bytes(p);
-    if (p.tie_le) {
-        if (p.dist_pre) hipLaunchKernelGGL((rcw_cast_kernel<true, true>), grid, block, lds, s, p, actions_dev, mask_dev);
-        else            hipLaunchKernelGGL((rcw_cast_kernel<true, false>), grid, block, lds, s, p, actions_dev, mask_dev);
-    } else {
-        if (p.dist_pre) hipLaunchKernelGGL((rcw_cast_kernel<false, true>), grid, block, lds, s, p, actions_dev, mask_dev);
-        else            hipLaunchKernelGGL((rcw_cast_kernel<false, false>), grid, block, lds, s, p, actions_dev, mask_dev);
-    }
+    RCW_DISPATCH(rcw_cast_kernel, dim3(p.B), dim3(p.cast_block), rcw_step_lds_bytes(p), p, actions_dev, mask_dev);
     return hipGetLastError();
 }
 
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
-    const size_t lds = rcw_step_lds_bytes(p);
-    if (p.tie_le) {
-        if (p.dist_pre) hipLaunchKernelGGL((rcw_top_view_kernel<true, true>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
-        else            hipLaunchKernelGGL((rcw_top_view_kernel<true, false>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
-    } else {
-        if (p.dist_pre) hipLaunchKernelGGL((rcw_top_view_kernel<false, true>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
-        else            hipLaunchKernelGGL((rcw_top_view_kernel<false, false>), dim3(p.B), dim3(kBlock), lds, s, p, mask_dev);
-    }
+    RCW_DISPATCH(rcw_top_view_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), p, mask_dev);
     return hipGetLastError();
 }
 
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
-    hipLaunchKernelGGL(rcw_reset_kernel, dim3((p.B + 63) / 64), dim3(64), 0, s, p, mask_dev);
+    if (p.real64) hipLaunchKernelGGL(rcw_reset_kernel<double>, dim3((p.B + 63) / 64), dim3(64), 0, s, p, mask_dev);
+    else          hipLaunchKernelGGL(rcw_reset_kernel<float>, dim3((p.B + 63) / 64), dim3(64), 0, s, p, mask_dev);
     return hipGetLastError();
 }
 
-hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const float2* pos,
+// pos: float2* for a Float32 world, double2* for a Float64 world
+hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s)
 {
-    hipLaunchKernelGGL(rcw_set_state_kernel, dim3((p.B + 63) / 64), dim3(64), 0, s, p, goal, pos, dir, mask_dev);
+    if (p.real64)
+        hipLaunchKernelGGL(rcw_set_state_kernel<double>, dim3((p.B + 63) / 64), dim3(64), 0, s, p, goal,
+                           static_cast<const double2*>(pos), dir, mask_dev);
+    else
+        hipLaunchKernelGGL(rcw_set_state_kernel<float>, dim3((p.B + 63) / 64), dim3(64), 0, s, p, goal,
+                           static_cast<const float2*>(pos), dir, mask_dev);
     return hipGetLastError();
 }
 
@@ -641,16 +694,10 @@ hipError_t rcw_launch_init_tile_map(const RcwDev& p, hipStream_t s)
 
 hipError_t rcw_launch_rays(const RcwDev& p, int32_t first, int32_t count, RcwRayOut out, hipStream_t s)
 {
-    const size_t lds = rcw_step_lds_bytes(p);
-    if (p.tie_le) {
-        if (p.dist_pre) hipLaunchKernelGGL((rcw_rays_kernel<true, true>), dim3(count), dim3(kBlock), lds, s, p, first, out);
-        else            hipLaunchKernelGGL((rcw_rays_kernel<true, false>), dim3(count), dim3(kBlock), lds, s, p, first, out);
-    } else {
-        if (p.dist_pre) hipLaunchKernelGGL((rcw_rays_kernel<false, true>), dim3(count), dim3(kBlock), lds, s, p, first, out);
-        else            hipLaunchKernelGGL((rcw_rays_kernel<false, false>), dim3(count), dim3(kBlock), lds, s, p, first, out);
-    }
+    RCW_DISPATCH(rcw_rays_kernel, dim3(count), dim3(kBlock), rcw_step_lds_bytes(p), p, first, out);
     return hipGetLastError();
 }
+#undef RCW_DISPATCH
 
 hipError_t rcw_launch_expand(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c,
                              int32_t count, uint32_t* frames, hipStream_t s)

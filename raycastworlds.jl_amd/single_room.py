@@ -129,7 +129,9 @@ class SingleRoomWorld:
         return self._get(self._env._lib.rcw_done, np.uint8, (self._env.batch,)).astype(bool)
 
     @property
-    def player_position_wu(self) -> np.ndarray:        # SR:24, (B, 2)
+    def player_position_wu(self) -> np.ndarray:        # SR:24, (B, 2) in T
+        if self._env.T is np.float64:
+            return self._get(self._env._lib.rcw_position64, np.float64, (self._env.batch, 2))
         return self._get(self._env._lib.rcw_position, np.float32, (self._env.batch, 2))
 
     @property
@@ -151,8 +153,9 @@ class SingleRoomWorld:
 
     @property
     def directions_wu(self) -> np.ndarray:             # SR:28, (nd, 2)
-        out = np.empty((self.num_directions, 2), dtype=np.float32)
-        _capi.check(self._env._lib.rcw_direction_table(self._env._h, _as_ptr(out)))
+        out = np.empty((self.num_directions, 2), dtype=self._env.T)
+        fn = self._env._lib.rcw_direction_table64 if self._env.T is np.float64 else self._env._lib.rcw_direction_table
+        _capi.check(fn(self._env._h, _as_ptr(out)))
         return out
 
     @property
@@ -176,18 +179,19 @@ class SingleRoomWorld:
         N = env.cfg.num_rays
         stop = np.empty((n, N, 2), dtype=np.int64)
         dim = np.empty((n, N), dtype=np.int64)
-        dist = np.empty((n, N), dtype=np.float32)
-        dirs = np.empty((n, N, 2), dtype=np.float32)
-        _capi.check(env._lib.rcw_rays(env._h, first, n, _as_ptr(stop), _as_ptr(dim), _as_ptr(dist), _as_ptr(dirs)))
+        dist = np.empty((n, N), dtype=env.T)
+        dirs = np.empty((n, N, 2), dtype=env.T)
+        fn = env._lib.rcw_rays64 if env.T is np.float64 else env._lib.rcw_rays
+        _capi.check(fn(env._h, first, n, _as_ptr(stop), _as_ptr(dim), _as_ptr(dist), _as_ptr(dirs)))
         return stop, dim, dist, dirs
 
 
 class SingleRoom:
     """`SingleRoom(; kwargs...)` (SR:258-324) for `batch` independent agents on one MI355X.
 
-    Keyword arguments and defaults are the reference's (SR:258-272). `T`/`R` other than
-    Float32 and a caller-supplied Julia `rng` are not supported; `seed`
-    keys the device generator instead. `device` is the HIP device index.
+    Keyword arguments and defaults are the reference's (SR:258-272). `T` is "Float32" (default)
+    or "Float64"; `R` is Float32; a caller-supplied Julia `rng` is replaced by `seed`, which
+    keys the device generator. `device` is the HIP device index.
     """
 
     def __init__(
@@ -216,9 +220,13 @@ class SingleRoom:
         out_of_bounds: int = 0,
         render_top_view: bool = False,
     ):
-        if str(T) not in ("Float32", "float32", "<class 'numpy.float32'>") or str(R) not in (
-            "Float32", "float32", "<class 'numpy.float32'>"):
-            raise NotImplementedError("only T = R = Float32 is built (SURVEY.md §8f row 2)")
+        f32_names = ("Float32", "float32", "<class 'numpy.float32'>")
+        f64_names = ("Float64", "float64", "<class 'numpy.float64'>", "<class 'float'>")
+        if str(T) not in f32_names + f64_names:
+            raise NotImplementedError(f"world-unit type T = {T!r}: only Float32 and Float64 are built")
+        if str(R) not in f32_names:
+            raise NotImplementedError("only R = Float32 rewards are built")
+        self.T = np.float64 if str(T) in f64_names else np.float32
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.height_tile_map_tu = height_tile_map_tu
@@ -238,6 +246,12 @@ class SingleRoom:
         cfg.normalize_mode = normalize_mode
         cfg.out_of_bounds = out_of_bounds
         cfg.render_top_view = 1 if render_top_view else 0
+        # convert(T, .) of the caller's values (SR:263-270): for T = Float64 the Float64 value itself
+        cfg.world_unit_bits = 64 if self.T is np.float64 else 32
+        cfg.player_radius_wu_f64 = float(player_radius_wu)
+        cfg.position_increment_wu_f64 = float(position_increment_wu)
+        cfg.semi_field_of_view_wu_f64 = float(semi_field_of_view_wu)
+        cfg.camera_height_tile_wu_f64 = float(camera_height_tile_wu)
         self.cfg = cfg
         self.batch = int(batch)
         self.device = int(device)
@@ -370,8 +384,9 @@ class SingleRoom:
 
     def ray_table(self) -> np.ndarray:
         """(nd, 5, N) float32: per heading [dx | dy | |1/dx| | |1/dy| | dir·ray]."""
-        out = np.empty((self.cfg.num_directions, 5, self.cfg.num_rays), dtype=np.float32)
-        _capi.check(self._lib.rcw_ray_table(self._h, _as_ptr(out)))
+        out = np.empty((self.cfg.num_directions, 5, self.cfg.num_rays), dtype=self.T)
+        fn = self._lib.rcw_ray_table64 if self.T is np.float64 else self._lib.rcw_ray_table
+        _capi.check(fn(self._h, _as_ptr(out)))
         return out
 
     def device_name(self) -> str:
@@ -382,14 +397,16 @@ class SingleRoom:
     # ---- state injection (how "identical seeds" is realised) ---------
     def set_state(self, goal_position, player_position_wu, player_direction_au, mask=None):
         g = np.ascontiguousarray(goal_position, dtype=np.int32).reshape(self.batch, 2)
-        p = np.ascontiguousarray(player_position_wu, dtype=np.float32).reshape(self.batch, 2)
+        p = np.ascontiguousarray(player_position_wu, dtype=self.T).reshape(self.batch, 2)
         d = np.ascontiguousarray(player_direction_au, dtype=np.int32).reshape(self.batch)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.batch)
-        _capi.check(self._lib.rcw_set_state(self._h, _as_ptr(g), _as_ptr(p), _as_ptr(d), _as_ptr(m)))
+        fn = self._lib.rcw_set_state64 if self.T is np.float64 else self._lib.rcw_set_state
+        _capi.check(fn(self._h, _as_ptr(g), _as_ptr(p), _as_ptr(d), _as_ptr(m)))
 
     def set_direction_table(self, directions_wu):
-        d = np.ascontiguousarray(directions_wu, dtype=np.float32).reshape(self.cfg.num_directions, 2)
-        _capi.check(self._lib.rcw_set_direction_table(self._h, _as_ptr(d)))
+        d = np.ascontiguousarray(directions_wu, dtype=self.T).reshape(self.cfg.num_directions, 2)
+        fn = self._lib.rcw_set_direction_table64 if self.T is np.float64 else self._lib.rcw_set_direction_table
+        _capi.check(fn(self._h, _as_ptr(d)))
 
     def set_stream(self, hip_stream: Optional[int]):
         _capi.check(self._lib.rcw_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))

@@ -21,7 +21,9 @@ def assert_state_equal(env, orc, frames=True, rays=False, where=""):
     pos = w.player_position_wu
     np.testing.assert_allclose(pos, orc.position, rtol=0, atol=POSITION_ATOL, err_msg=f"position {where}")
     # the engine is in fact bit-exact on positions too
-    np.testing.assert_array_equal(pos.view(np.uint32), orc.position.view(np.uint32), err_msg=f"position bits {where}")
+    assert pos.dtype == orc.position.dtype, (pos.dtype, orc.position.dtype)
+    bits = np.uint64 if pos.dtype == np.float64 else np.uint32
+    np.testing.assert_array_equal(pos.view(bits), orc.position.view(bits), err_msg=f"position bits {where}")
     np.testing.assert_array_equal(w.reward, orc.reward, err_msg=f"reward {where}")
     np.testing.assert_array_equal(w.done.astype(np.uint8), orc.done, err_msg=f"done {where}")
     np.testing.assert_array_equal(w.tile_map_chunks, orc.tile_map_chunks(), err_msg=f"tile_map {where}")
@@ -34,8 +36,9 @@ def assert_state_equal(env, orc, frames=True, rays=False, where=""):
         stop, dim, dist, dirs = w.rays()
         np.testing.assert_array_equal(stop, orc.ray_stop, err_msg=f"ray_stop {where}")
         np.testing.assert_array_equal(dim, orc.ray_dim, err_msg=f"ray_dim {where}")
-        np.testing.assert_array_equal(dist.view(np.uint32), orc.ray_dist.view(np.uint32), err_msg=f"ray_dist {where}")
-        np.testing.assert_array_equal(dirs.view(np.uint32), orc.ray_dirs.view(np.uint32), err_msg=f"ray_dirs {where}")
+        assert dist.dtype == orc.ray_dist.dtype
+        np.testing.assert_array_equal(dist.view(bits), orc.ray_dist.view(bits), err_msg=f"ray_dist {where}")
+        np.testing.assert_array_equal(dirs.view(bits), orc.ray_dirs.view(bits), err_msg=f"ray_dirs {where}")
 
 
 def frame_checksum(frames: np.ndarray) -> int:

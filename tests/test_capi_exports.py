@@ -38,7 +38,7 @@ def test_config_struct_matches_header(rcw, oracle):
     from raycastworlds_jl_amd import _capi
 
     cfg = _capi.default_config()          # rcw_config_default: host-only, no device touched
-    assert C.sizeof(_capi.RcwConfig) == C.sizeof(oracle.RcwConfig) == 128
+    assert C.sizeof(_capi.RcwConfig) == C.sizeof(oracle.RcwConfig) == 160
     ref = oracle.default_config()
     for name, _ in _capi.RcwConfig._fields_:
         if name == "reserved":

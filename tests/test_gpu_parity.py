@@ -14,9 +14,15 @@ pytestmark = pytest.mark.gpu
 
 def _make(rcw, oracle, batch, seed=0, **kw):
     env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=seed, **kw)
-    okw = {k: v for k, v in kw.items() if k not in ("auto_reset",)}
+    okw = {k: v for k, v in kw.items() if k not in ("auto_reset", "T")}
     if kw.get("auto_reset"):
         okw["auto_reset"] = 1
+    if kw.get("T") == "Float64":
+        # convert(Float64, .) of the same kwargs (SR:263-270)
+        okw["world_unit_bits"] = 64
+        for k in ("player_radius_wu", "position_increment_wu", "semi_field_of_view_wu", "camera_height_tile_wu"):
+            if k in kw:
+                okw[k + "_f64"] = float(kw[k])
     orc = oracle.OracleBatch(batch, seed=seed, **okw)
     return env, orc
 
@@ -329,7 +335,7 @@ def test_error_paths_fail_loudly(rcw):
         SR(batch=4, device=99)
     assert ei.value.code == _capi.RCW_ERR_NO_DEVICE
     with pytest.raises(NotImplementedError):
-        SR(batch=4, T="Float64")
+        SR(batch=4, T="Float16")
     env = SR(batch=4, **CFG1)
     with pytest.raises(ValueError):
         env.set_state([[1, 2]] * 4, [[4.5, 4.5]] * 4, [0] * 4)            # goal on the wall ring
@@ -346,4 +352,57 @@ def test_error_paths_fail_loudly(rcw):
     env.sync()                                                             # the handle is still healthy
     rcw.act_(env, 1)
     env.sync()
+    env.close()
+
+
+def test_float64_world_units(rcw, oracle):
+    """T = Float64 (SingleRoom(; T = Float64) SR:259): every operation of the path in Float64, compared
+    with the oracle compiled for T = Float64 (positions, distances, tables as doubles)."""
+    rng = np.random.default_rng(64)
+    cases = [
+        dict(T="Float64", **CFG1),
+        dict(T="Float64", **CFG2),
+        dict(T="Float64"),                                     # reference default 8 x 16, 512 rays
+        dict(T="Float64", semi_field_of_view_wu=0.9, player_radius_wu=0.2, position_increment_wu=0.07,
+             height_tile_map_tu=9, width_tile_map_tu=11, num_rays=77, render_top_view=True, pu_per_tu=12),
+        dict(T="Float64", auto_reset=True, **CFG1),
+    ]
+    for kw in cases:
+        env, orc = _make(rcw, oracle, 16, seed=33, **kw)
+        assert env.world.player_position_wu.dtype == np.float64
+        np.testing.assert_array_equal(env.world.directions_wu, orc.directions)
+        tab = env.ray_table()                                  # (nd, 5, N) float64
+        np.testing.assert_array_equal(tab[:, 0, :], orc.ray_table[:, :, 0])
+        np.testing.assert_array_equal(tab[:, 1, :], orc.ray_table[:, :, 1])
+        assert_state_equal(env, orc, rays=True, where=f"create {kw}")
+        for s in range(80):
+            a = rng.integers(1, 5, env.batch).astype(np.uint8)
+            rcw.act_(env, a)
+            assert orc.step(a) == 0
+            try:
+                env.sync()
+            except IndexError:
+                np.testing.assert_array_equal(env.world.status, orc.status)
+                env.clear_error(); orc.clear_status()
+            if s % 20 == 19:
+                assert_state_equal(env, orc, rays=True, where=f"step {s} {kw}")
+                if kw.get("render_top_view"):
+                    np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        # all headings from an off-centre pose
+        if env.cfg.num_directions == 128 and env.batch == 16:
+            goal = np.tile(np.array([[3, 6]], dtype=np.int32), (16, 1))
+            pos = np.tile(np.array([[4.3125, 2.71875]], dtype=np.float64), (16, 1))
+            for d0 in range(0, 128, 16):
+                d = np.arange(d0, d0 + 16, dtype=np.int32)
+                env.set_state(goal, pos, d)
+                orc.set_state(goal, pos, d)
+                assert_state_equal(env, orc, rays=True, where=f"headings {d0}.. {kw}")
+        env.close()
+    # the Float32 entry points refuse a Float64 handle (and say which to use)
+    env = rcw.SingleRoomModule.SingleRoom(batch=2, T="Float64", **CFG1)
+    import ctypes as C
+    from raycastworlds_jl_amd import _capi
+    buf = np.zeros((2, 2), np.float32)
+    rc = env._lib.rcw_position(env._h, buf.ctypes.data_as(C.c_void_p))
+    assert rc == _capi.RCW_ERR_UNSUPPORTED and "Float64" in _capi.last_error()
     env.close()

@@ -104,3 +104,49 @@ def test_top_view_certain_parts_by_hand(oracle):
     assert px(ip + 5, jp) == 0xC0C0C0 and px(ip, jp + 5) == 0xC0C0C0 and px(ip - 5, jp) == 0xC0C0C0   # circle's axis points
     # facing +x: the central ray runs straight down the i axis to the wall face x = 7 -> pixel 7*32+1 = 225
     assert px(200, jp) == 0x808080 and px(225, jp) == 0x808080 and px(226, jp) != 0x808080
+
+
+@pytest.mark.parametrize("H,W,N,steps", [(8, 8, 64, 50), (8, 16, 40, 40), (7, 9, 21, 30)])
+def test_float64_rollout_bit_exact(oracle, H, W, N, steps):
+    """T = Float64: the Python restatement with numpy Float64 scalars vs the C oracle compiled with
+    -DORC_REAL64, bit for bit (positions, distances, ray directions as doubles)."""
+    orc = oracle.OracleBatch(1, seed=7 * H + N, height_tile_map_tu=H, width_tile_map_tu=W, num_rays=N,
+                             world_unit_bits=64, out_of_bounds=1, render_top_view=1, pu_per_tu=16)
+    try:
+        w = pyref.World(H=H, W=W, num_rays=N, T=np.float64)
+        assert orc.position.dtype == np.float64
+        np.testing.assert_array_equal(orc.directions, np.array(w.directions, dtype=np.float64))
+        w.set_state(orc.goal[0], orc.position[0], orc.direction[0])
+        rng = np.random.default_rng(N)
+        for s in range(steps):
+            a = int(rng.integers(1, 5))
+            orc.step([a])
+            try:
+                w.step(a)
+            except IndexError:
+                w.cast_rays(); w.update_camera_view()
+            np.testing.assert_array_equal(orc.position[0], np.array(w.pos, dtype=np.float64), err_msg=f"step {s}")
+            assert orc.direction[0] == w.dir
+            np.testing.assert_array_equal(orc.col_height[0], np.array(w.col_height, dtype=np.int32))
+            np.testing.assert_array_equal(orc.col_colour[0], np.array(w.col_colour, dtype=np.uint8))
+            dist = np.array([h[3] for h in w.ray_hits], dtype=np.float64)
+            np.testing.assert_array_equal(orc.ray_dist[0].view(np.uint64), dist.view(np.uint64))
+            np.testing.assert_array_equal(orc.ray_dirs[0].view(np.uint64), np.array(w.ray_dirs, dtype=np.float64).view(np.uint64))
+        np.testing.assert_array_equal(orc.camera_view[0], w.camera_view)
+        w.update_top_view(16)
+        np.testing.assert_array_equal(w.top_view, orc.top_view[0])
+    finally:
+        pyref.set_world_unit_type(np.float32)
+
+
+def test_float64_differs_from_float32_where_it_should(oracle):
+    """convert(Float64, 2/3) is not Float32(2/3) widened: the two worlds cast different fans."""
+    o32 = oracle.OracleBatch(1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    o64 = oracle.OracleBatch(1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, world_unit_bits=64)
+    for o in (o32, o64):
+        o.set_state([[2, 2]], [[4.5, 4.5]], [5])
+    assert o64.ray_dirs.dtype == np.float64 and o32.ray_dirs.dtype == np.float32
+    assert not np.array_equal(o32.ray_dirs[0].astype(np.float64), o64.ray_dirs[0])
+    np.testing.assert_allclose(o32.ray_dirs[0], o64.ray_dirs[0], atol=1e-6)
+    np.testing.assert_array_equal(o32.col_height, o64.col_height)      # same picture at this pose
+    assert o64.directions[32, 0] == 6.123233995736766e-17 and o64.directions[32, 1] == 1.0

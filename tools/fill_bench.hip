@@ -70,6 +70,8 @@ __global__ __launch_bounds__(BLOCK) void fill_window(u32x4* out, size_t nvec, ui
     }
     for (; i < nvec; i += stride) { if (NT) __builtin_nontemporal_store(val, out + i); else out[i] = val; }
 }
+// Z: launch floor — a kernel that does nothing, at the cast kernel's grid shapes
+__global__ void empty_kernel(int* p) { if (p && threadIdx.x == 12345) *p = 1; }
 // E: 1024-thread WG per frame
 template <bool NT>
 __global__ __launch_bounds__(1024) void fill_wg1024(u32x4* out, int vec_per_wg, uint32_t v)
@@ -128,6 +130,9 @@ int main(int argc, char** argv)
 #define RUNF(NT, BLOCK, UNROLL, G) { char nm[80]; snprintf(nm, sizeof nm, "F window %s block=%d unroll=%d grid=%d", NT ? "nt" : "plain", BLOCK, UNROLL, G); \
         rep(nm, time_it([&](int i) { hipLaunchKernelGGL((fill_window<NT, BLOCK, UNROLL>), dim3(G), dim3(BLOCK), 0, s, buf, nvec, i); }, s, it)); }
     for (int g : {128, 256, 512, 1024}) { RUNF(false, 256, 1, g) RUNF(true, 256, 1, g) RUNF(false, 256, 4, g) RUNF(false, 1024, 1, g) RUNF(false, 1024, 4, g) RUNF(false, 512, 2, g) }
+    for (int blk : {64, 128, 256}) { char nm[64]; snprintf(nm, sizeof nm, "Z empty kernel grid=4096 block=%d", blk);
+        rep(nm, time_it([&](int) { hipLaunchKernelGGL(empty_kernel, dim3(frames), dim3(blk), 0, s, (int*)nullptr); }, s, 200)); }
+    rep("Z empty kernel grid=256 block=256", time_it([&](int) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s, (int*)nullptr); }, s, 200));
     rep("E wg1024 nt", time_it([&](int i) { hipLaunchKernelGGL(fill_wg1024<true>, dim3(frames), dim3(1024), 0, s, buf, vpf, i); }, s, it));
     rep("E wg1024 plain", time_it([&](int i) { hipLaunchKernelGGL(fill_wg1024<false>, dim3(frames), dim3(1024), 0, s, buf, vpf, i); }, s, it));
     CK(hipFree(buf));
