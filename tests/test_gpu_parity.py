@@ -406,3 +406,18 @@ def test_float64_world_units(rcw, oracle):
     rc = env._lib.rcw_position(env._h, buf.ctypes.data_as(C.c_void_p))
     assert rc == _capi.RCW_ERR_UNSUPPORTED and "Float64" in _capi.last_error()
     env.close()
+
+
+def test_extreme_shapes(rcw, oracle):
+    """The largest shapes the LDS staging admits: 4096 view columns, a 200 x 200 tile map (40 KB of
+    tile bytes in LDS, rays up to 400 steps long), a 1024-pixel-high camera view."""
+    rng = np.random.default_rng(21)
+    for kw, batch, steps in ((dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=4096), 4, 12),
+                             (dict(height_tile_map_tu=200, width_tile_map_tu=200, num_rays=128), 6, 12),
+                             (dict(height_camera_view_pu=1024, **CFG1), 6, 12)):
+        env, orc = _make(rcw, oracle, batch, seed=2, **kw)
+        assert_state_equal(env, orc, rays=True, where=f"create {kw}")
+        _rollout(rcw, env, orc, steps, rng, check_every=4, rays_every=4)
+        env.close()
+    with pytest.raises(rcw.SingleRoomModule._capi.RcwError):
+        rcw.SingleRoomModule.SingleRoom(batch=1, height_tile_map_tu=300, width_tile_map_tu=300)   # > 65536 tiles
