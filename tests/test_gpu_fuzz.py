@@ -1,0 +1,18 @@
+"""Differential fuzzing in the suite: tools/fuzz_parity.py over 120 random configurations with a
+fixed seed (map size, columns, headings, field of view, radius, step, camera/image heights, Float32
+and Float64 world units, the unpinned switches, both BoundsError policies, auto-reset, top view)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_configurations_stay_in_parity():
+    res = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "2025"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "120 random configurations, 0 mismatches" in res.stdout

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): differential fuzzing of the HIP path against the CPU oracle over random
+configurations (map size, columns, headings, field of view, radius, step, camera height, image
+height, world-unit type, the three unpinned switches, both BoundsError policies, auto-reset).
+
+    python tools/fuzz_parity.py [configs] [seed]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+import raycastworlds_jl_amd as RCW
+from helpers import assert_state_equal
+from oracle import oracle as O
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails = 0
+O.set_num_threads(8)
+for c in range(n_cfg):
+    if c % 10 == 0:
+        print(f"config {c} ...", flush=True)
+    T64 = bool(rng.integers(0, 2))
+    radius = float(rng.choice([1 / 8, 0.05, 0.2, 0.3, 0.49]))
+    inc = float(rng.choice([1 / 8, 1 / 16, 0.1, 0.03, radius]))
+    kw = dict(height_tile_map_tu=int(rng.integers(4, 24)), width_tile_map_tu=int(rng.integers(4, 24)),
+              num_rays=int(rng.choice([1, 2, 7, 64, 100, 256, 333])), num_directions=int(rng.choice([4, 16, 36, 128, 360])),
+              player_radius_wu=radius, position_increment_wu=min(inc, radius),
+              semi_field_of_view_wu=float(rng.choice([2 / 3, 0.25, 1.0, 1.7])),
+              camera_height_tile_wu=float(rng.choice([1.0, 0.5, 2.5])),
+              height_camera_view_pu=int(rng.choice([256, 64, 100, 37, 512])),
+              dda_tie_break=int(rng.integers(0, 2)), dda_distance=int(rng.integers(0, 2)),
+              normalize_mode=int(rng.integers(0, 2)), out_of_bounds=int(rng.integers(0, 2)),
+              auto_reset=bool(rng.integers(0, 2)), render_top_view=bool(rng.integers(0, 4) == 0),
+              pu_per_tu=int(rng.choice([4, 8, 13, 32])))
+    B = int(rng.integers(1, 40))
+    seed = int(rng.integers(0, 2**31))
+    okw = {k: v for k, v in kw.items()}
+    okw["auto_reset"] = int(kw["auto_reset"]); okw["render_top_view"] = int(kw["render_top_view"])
+    if T64:
+        okw["world_unit_bits"] = 64
+        for k in ("player_radius_wu", "position_increment_wu", "semi_field_of_view_wu", "camera_height_tile_wu"):
+            okw[k + "_f64"] = float(kw[k])
+    try:
+        env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, T="Float64" if T64 else "Float32", **kw)
+        orc = O.OracleBatch(B, seed=seed, **okw)
+        assert_state_equal(env, orc, rays=True, where="create")
+        for s in range(int(rng.integers(5, 60))):
+            a = rng.integers(1, 5, B).astype(np.uint8)
+            RCW.act_(env, a)
+            assert orc.step(a) == 0
+            try:
+                env.sync()
+            except IndexError:
+                np.testing.assert_array_equal(env.world.status, orc.status)
+                env.clear_error(); orc.clear_status()
+        assert_state_equal(env, orc, rays=True, where="rollout")
+        np.testing.assert_array_equal(env.world.episode, orc.episode)
+        if kw["render_top_view"]:
+            np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        env.close(); orc.close()
+    except Exception as e:   # noqa: BLE001
+        fails += 1
+        print(f"config {c} FAILED: T64={T64} B={B} seed={seed} {kw}\n   {type(e).__name__}: {str(e)[:300]}")
+        if fails >= 5:
+            break
+print(f"{n_cfg} random configurations, {fails} mismatches")
+sys.exit(1 if fails else 0)
