@@ -150,3 +150,35 @@ def test_float64_differs_from_float32_where_it_should(oracle):
     np.testing.assert_allclose(o32.ray_dirs[0], o64.ray_dirs[0], atol=1e-6)
     np.testing.assert_array_equal(o32.col_height, o64.col_height)      # same picture at this pose
     assert o64.directions[32, 0] == 6.123233995736766e-17 and o64.directions[32, 1] == 1.0
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_arbitrary_poses_two_restatements_agree(oracle, bits):
+    """Injected poses on tile boundaries, a hair off them, inside the goal tile, for every 7th heading:
+    the edge cases of cast_ray (zero side distance, ties, a ray that starts inside an obstacle)."""
+    T = np.float64 if bits == 64 else np.float32
+    rng = np.random.default_rng(bits)
+    H, W, N = 9, 7, 16
+    orc = oracle.OracleBatch(1, height_tile_map_tu=H, width_tile_map_tu=W, num_rays=N, world_unit_bits=bits)
+    try:
+        w = pyref.World(H=H, W=W, num_rays=N, T=T)
+        for trial in range(60):
+            kind = rng.integers(0, 4, 2)
+            vals = []
+            for axis, hi in enumerate((H, W)):
+                k = float(rng.integers(1, hi - 1))
+                v = [rng.uniform(1.0, hi - 1.0), k, k + float(rng.choice([1e-7, -1e-7, 3e-5])), k + 0.5][kind[axis]]
+                vals.append(min(max(T(v), T(1)), np.nextafter(T(hi - 1), T(0))))
+            goal = (int(rng.integers(2, H)), int(rng.integers(2, W)))
+            d = int(rng.integers(0, 128))
+            pos = np.array([vals], dtype=T)
+            orc.set_state([goal], pos, [d])
+            w.set_state(goal, pos[0], d)
+            np.testing.assert_array_equal(orc.col_height[0], np.array(w.col_height, dtype=np.int32), err_msg=f"trial {trial}")
+            np.testing.assert_array_equal(orc.col_colour[0], np.array(w.col_colour, dtype=np.uint8))
+            np.testing.assert_array_equal(orc.ray_stop[0], np.array([(h[0], h[1]) for h in w.ray_hits], dtype=np.int64))
+            np.testing.assert_array_equal(orc.ray_dim[0], np.array([h[2] for h in w.ray_hits], dtype=np.int64))
+            np.testing.assert_array_equal(orc.ray_dist[0], np.array([h[3] for h in w.ray_hits], dtype=T))
+            np.testing.assert_array_equal(orc.camera_view[0], w.camera_view)
+    finally:
+        pyref.set_world_unit_type(np.float32)

@@ -48,6 +48,25 @@ for c in range(n_cfg):
         env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, T="Float64" if T64 else "Float32", **kw)
         orc = O.OracleBatch(B, seed=seed, **okw)
         assert_state_equal(env, orc, rays=True, where="create")
+        if rng.integers(0, 2):
+            # arbitrary injected poses: uniform, exactly on tile boundaries, a hair off them, tile centres,
+            # possibly inside the goal tile (a ray that starts inside an obstacle)
+            H, W = kw["height_tile_map_tu"], kw["width_tile_map_tu"]
+            real = np.float64 if T64 else np.float32
+            def coords(n, hi):
+                kind = rng.integers(0, 4, n)
+                u = rng.uniform(1.0, hi - 1.0, n)
+                k = rng.integers(1, hi - 1, n).astype(np.float64)
+                eps = rng.choice([1e-7, -1e-7, 1e-12, 3e-5], n)
+                out = np.where(kind == 0, u, np.where(kind == 1, k, np.where(kind == 2, k + eps, k + 0.5)))
+                out = np.clip(out, 1.0, np.nextafter(real(hi - 1), real(0))).astype(real)
+                return np.where(out < 1, real(1), out)
+            pos = np.stack([coords(B, H), coords(B, W)], axis=1).astype(real)
+            goal = np.stack([rng.integers(2, H, B), rng.integers(2, W, B)], axis=1).astype(np.int32)
+            d = rng.integers(0, kw["num_directions"], B).astype(np.int32)
+            env.set_state(goal, pos, d)
+            orc.set_state(goal, pos, d)
+            assert_state_equal(env, orc, rays=True, where="set_state with arbitrary poses")
         for s in range(int(rng.integers(5, 60))):
             a = rng.integers(1, 5, B).astype(np.uint8)
             RCW.act_(env, a)
