@@ -68,6 +68,11 @@ for c in range(n_cfg):
             orc.set_state(goal, pos, d)
             assert_state_equal(env, orc, rays=True, where="set_state with arbitrary poses")
         for s in range(int(rng.integers(5, 60))):
+            if rng.integers(0, 12) == 0:                       # a masked reset with a fresh seed now and then
+                mask = (rng.random(B) < 0.4).astype(np.uint8)
+                sd = int(rng.integers(0, 2**31))
+                RCW.reset_(env, mask=mask, seed=sd)
+                orc.reset(mask=mask, seed=sd)
             a = rng.integers(1, 5, B).astype(np.uint8)
             RCW.act_(env, a)
             assert orc.step(a) == 0
