@@ -430,7 +430,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.top_view = (uint32_t*)h->d_top_view; d.pu = cfg->pu_per_tu;
     d.status = (int32_t*)h->d_status;
     d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;
-    d.fill_grid = 256; d.fill_plain = 0;
+    // fill kernel: one workgroup per CU (256 on an MI355X in SPX mode; a partitioned device reports fewer)
+    d.fill_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; d.fill_plain = 0;
     // cast kernel: two view columns per lane (measured best at 4096 x 256), 64..256 threads per agent
     { const int lanes = (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
     if (const char* v = std::getenv("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
