@@ -1,8 +1,8 @@
 // HIP kernels (gfx950 / CDNA4) for the batched SingleRoom step/render path.
 //
 // A step is two launches on the handle's stream:
-//   rcw_cast_kernel   one workgroup (4 wavefronts) per agent.  The agent's tile_map (2·H·W
-//            bits) is staged in LDS; every lane runs the (wave-uniform) dynamics
+//   rcw_cast_kernel   one workgroup per agent.  The agent's tile_map (2·H·W bits) is staged in
+//            LDS, unpacked to a byte per tile; every lane runs the (wave-uniform) dynamics
 //            act!(world, a) SR:139-191 redundantly so nothing has to be broadcast — the opt-in
 //            re-sample SR:110-137 runs on lane 0 and goes through LDS; then one lane per
 //            view column: table lookup of the ray (SR:214-221), grid DDA against
@@ -17,10 +17,13 @@
 // This is an integer/indexing + streaming-store path: no MFMA, the roofline is HBM write
 // bandwidth, and the frame (4·H_cam·N bytes per agent-step) is written exactly once.
 //
-// Floating point: every operation below is a single IEEE-754 Float32 rounding, exactly
-// as the reference (Julia never contracts a*b+c): this file MUST be compiled with
-// -ffp-contract=off and without fast-math; division and sqrt are the correctly rounded
-// forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), denormals are kept.
+//   rcw_top_view_kernel  (opt-in) the reference's other per-step image, update_top_view! SR:446-483.
+//
+// Floating point: every operation below is a single IEEE-754 rounding in the world-unit type T
+// (Float32, or Float64 for SingleRoom(; T = Float64)), exactly as the reference (Julia never
+// contracts a*b+c): this file MUST be compiled with -ffp-contract=off and without fast-math;
+// division and sqrt are the correctly rounded forms (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt), denormals are kept.
 #include "rcw_kernels.h"
 #include "rcw_rng.h"
 #include "../../include/rcw.h"
