@@ -15,14 +15,8 @@ import math
 
 import numpy as np
 
-f32 = np.float32          # rebound per World to the world-unit type T (Float32 or Float64)
 
 
-
-def set_world_unit_type(T):
-    """Select the reference's T (np.float32 or np.float64) for everything below."""
-    global f32
-    f32 = T
 
 
 WALL, GOAL = 1, 2           # SR:17-18
@@ -44,42 +38,42 @@ def turn_right(d, nd):      # UT:14
     return (d - 1) % nd
 
 
-def is_player_colliding(obstacle_map, pos, radius):
+def is_player_colliding(obstacle_map, pos, radius, T=np.float32):
     """CD:21-42.  obstacle_map[i][j] 1-based; raises IndexError where Julia raises BoundsError."""
     H, W = len(obstacle_map) - 1, len(obstacle_map[1]) - 1
-    half = f32(0.5)
+    half = T(0.5)
     it, jt = wu_to_tu(pos[0]), wu_to_tu(pos[1])
     for j in range(jt - 1, jt + 2):             # CD:30
         for i in range(it - 1, it + 2):         # CD:31
-            tile = (f32(i) - half, f32(j) - half)   # CD:33-34
+            tile = (T(i) - half, T(j) - half)   # CD:33-34
             if not (1 <= i <= H and 1 <= j <= W):
                 raise IndexError("BoundsError")
             if obstacle_map[i][j]:              # CD:35 (&& short-circuits)
-                q = (f32(pos[0]) - tile[0], f32(pos[1]) - tile[1])
+                q = (T(pos[0]) - tile[0], T(pos[1]) - tile[1])
                 proj = tuple(min(max(c, -half), half) for c in q)   # clamp.(q, -h, h) CD:11
                 v = (q[0] - proj[0], q[1] - proj[1])                # CD:16
-                if v[0] * v[0] + v[1] * v[1] < f32(radius) * f32(radius):   # CD:18
+                if v[0] * v[0] + v[1] * v[1] < T(radius) * T(radius):   # CD:18
                     return True
     return False
 
 
-def cast_ray(obstacle_map, x, y, dx, dy, tie_le=False, dist_pre=False):
+def cast_ray(obstacle_map, x, y, dx, dy, tie_le=False, dist_pre=False, T=np.float32):
     """RayCaster.cast_ray (external, call site SR:223): canonical grid DDA.  UNPINNED."""
     H, W = len(obstacle_map) - 1, len(obstacle_map[1]) - 1
-    x, y, dx, dy = f32(x), f32(y), f32(dx), f32(dy)
+    x, y, dx, dy = T(x), T(y), T(dx), T(dy)
     i, j = wu_to_tu(x), wu_to_tu(y)
     with np.errstate(divide="ignore", invalid="ignore"):
-        ddx = abs(f32(1) / dx)
-        ddy = abs(f32(1) / dy)
+        ddx = abs(T(1) / dx)
+        ddy = abs(T(1) / dy)
         if dx < 0:
-            si, sx = -1, (x - f32(i - 1)) * ddx
+            si, sx = -1, (x - T(i - 1)) * ddx
         else:
-            si, sx = 1, (f32(i) - x) * ddx
+            si, sx = 1, (T(i) - x) * ddx
         if dy < 0:
-            sj, sy = -1, (y - f32(j - 1)) * ddy
+            sj, sy = -1, (y - T(j - 1)) * ddy
         else:
-            sj, sy = 1, (f32(j) - y) * ddy
-        dim, dist = 0, f32(0)
+            sj, sy = 1, (T(j) - y) * ddy
+        dim, dist = 0, T(0)
         while True:
             if not (1 <= i <= H and 1 <= j <= W):
                 raise IndexError("BoundsError")
@@ -94,7 +88,7 @@ def cast_ray(obstacle_map, x, y, dx, dy, tie_le=False, dist_pre=False):
                 dist = sx - ddx
             elif dim == 2:
                 dist = sy - ddy
-    return i, j, dim, f32(dist)
+    return i, j, dim, T(dist)
 
 
 class World:
@@ -102,11 +96,10 @@ class World:
 
     def __init__(self, H=8, W=16, nd=128, radius=1 / 8, inc=1 / 8, fov=2 / 3, num_rays=512,
                  camera_height=1.0, Hc=256, tie_le=False, dist_pre=False, normalize_divide=False, T=np.float32):
-        set_world_unit_type(T)
-        self.T = T
+        self.T = T                                   # the reference's world-unit type (SR:259); R stays Float32
         self.H, self.W, self.nd, self.N, self.Hc = H, W, nd, num_rays, Hc
-        self.radius, self.inc, self.fov = f32(radius), f32(inc), f32(fov)
-        self.camh = f32(camera_height)
+        self.radius, self.inc, self.fov = self.T(radius), self.T(inc), self.T(fov)
+        self.camh = self.T(camera_height)
         self.tie_le, self.dist_pre, self.normalize_divide = tie_le, dist_pre, normalize_divide
         # tile_map[o][i][j], 1-based (SR:54-60)
         self.tile_map = [None] + [[[False] * (W + 1) for _ in range(H + 1)] for _ in range(2)]
@@ -120,12 +113,12 @@ class World:
         self.directions = []
         for i in range(1, nd + 1):
             theta = (i - 1) * 2 * math.pi / nd
-            self.directions.append((f32(math.cos(theta)), f32(math.sin(theta))))
+            self.directions.append((self.T(math.cos(theta)), self.T(math.sin(theta))))
         self.goal = (2, 2)
         self.tile_map[GOAL][2][2] = True
-        self.pos = (f32(1.5), f32(1.5))
+        self.pos = (self.T(1.5), self.T(1.5))
         self.dir = 0
-        self.reward = f32(0)
+        self.reward = np.float32(0)
         self.done = False
         self.camera_view = np.zeros((self.N, Hc), dtype=np.uint32)   # [k-1][row-1] == Julia [row, k]
 
@@ -134,9 +127,9 @@ class World:
         self.tile_map[GOAL][self.goal[0]][self.goal[1]] = False     # SR:118
         self.goal = (int(goal[0]), int(goal[1]))
         self.tile_map[GOAL][self.goal[0]][self.goal[1]] = True      # SR:122
-        self.pos = (f32(pos[0]), f32(pos[1]))
+        self.pos = (self.T(pos[0]), self.T(pos[1]))
         self.dir = int(d)
-        self.reward = f32(0)
+        self.reward = np.float32(0)
         self.done = False
         self.cast_rays()
         self.update_camera_view()
@@ -151,19 +144,19 @@ class World:
                 new = (self.pos[0] + self.inc * d[0], self.pos[1] + self.inc * d[1])
             else:             # UT:17
                 new = (self.pos[0] - self.inc * d[0], self.pos[1] - self.inc * d[1])
-            g = is_player_colliding(goal_map, new, self.radius)     # SR:162
-            w = is_player_colliding(wall_map, new, self.radius)     # SR:163
+            g = is_player_colliding(goal_map, new, self.radius, self.T)     # SR:162
+            w = is_player_colliding(wall_map, new, self.radius, self.T)     # SR:163
             if g or w:
                 if g:
-                    self.reward, self.done = f32(1), True           # SR:166-168
+                    self.reward, self.done = np.float32(1), True           # SR:166-168
                 else:
-                    self.reward, self.done = f32(0), False          # SR:170-171
+                    self.reward, self.done = np.float32(0), False          # SR:170-171
             else:
                 self.pos = new                                      # SR:174
-                self.reward, self.done = f32(0), False
+                self.reward, self.done = np.float32(0), False
         else:
             self.dir = turn_left(self.dir, self.nd) if action == 3 else turn_right(self.dir, self.nd)
-            self.reward, self.done = f32(0), False                  # SR:186-187
+            self.reward, self.done = np.float32(0), False                  # SR:186-187
 
     def ray_fan(self):
         """SR:214-221: normalized ray directions for the current heading."""
@@ -175,13 +168,13 @@ class World:
         rays = []
         for i in range(1, self.N + 1):
             t = (i - 1) / lendiv                                    # Float64 (lerpi)
-            u = (f32((1 - t) * float(first[0]) + t * float(last[0])),
-                 f32((1 - t) * float(first[1]) + t * float(last[1])))
+            u = (self.T((1 - t) * float(first[0]) + t * float(last[0])),
+                 self.T((1 - t) * float(first[1]) + t * float(last[1])))
             n = np.sqrt(u[0] * u[0] + u[1] * u[1])                  # norm
             if self.normalize_divide:
                 rays.append((u[0] / n, u[1] / n))
             else:
-                inv = f32(1) / n                                    # inv(norm(a)) * a
+                inv = self.T(1) / n                                    # inv(norm(a)) * a
                 rays.append((inv * u[0], inv * u[1]))
         return rays
 
@@ -193,7 +186,7 @@ class World:
             for j in range(1, W + 1):
                 obst[i][j] = self.tile_map[WALL][i][j] or self.tile_map[GOAL][i][j]
         self.ray_dirs = self.ray_fan()
-        self.ray_hits = [cast_ray(obst, self.pos[0], self.pos[1], r[0], r[1], self.tie_le, self.dist_pre)
+        self.ray_hits = [cast_ray(obst, self.pos[0], self.pos[1], r[0], r[1], self.tie_le, self.dist_pre, self.T)
                          for r in self.ray_dirs]                    # SR:223
 
     def update_camera_view(self):
@@ -207,7 +200,7 @@ class World:
             ih, jh, dim, dist = self.ray_hits[i - 1]
             with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
                 projected = dist * (d[0] * r[0] + d[1] * r[1])      # SR:404
-                height_line = self.camh * f32(N) / (f32(2) * self.fov * projected)   # SR:406
+                height_line = self.camh * self.T(N) / (self.T(2) * self.fov * projected)   # SR:406
             if np.isfinite(height_line):                             # SR:407-411
                 h = int(math.floor(float(height_line)))
             else:
@@ -252,7 +245,7 @@ class World:
                 img[i0:i0 + pu_per_tu, j0 + pu_per_tu - 1] = 0x00CCCCCC        # SR:367
 
         def wu_to_pu(x):                                          # UT:6
-            return int(math.floor(float(f32(x) * f32(pu_per_tu)))) + 1
+            return int(math.floor(float(self.T(x) * self.T(pu_per_tu)))) + 1
 
         ip, jp = wu_to_pu(self.pos[0]), wu_to_pu(self.pos[1])     # SR:468
         rp = wu_to_pu(self.radius)                                # SR:469

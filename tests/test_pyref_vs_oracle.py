@@ -136,7 +136,7 @@ def test_float64_rollout_bit_exact(oracle, H, W, N, steps):
         w.update_top_view(16)
         np.testing.assert_array_equal(w.top_view, orc.top_view[0])
     finally:
-        pyref.set_world_unit_type(np.float32)
+        orc.close()
 
 
 def test_float64_differs_from_float32_where_it_should(oracle):
@@ -181,4 +181,4 @@ def test_arbitrary_poses_two_restatements_agree(oracle, bits):
             np.testing.assert_array_equal(orc.ray_dist[0], np.array([h[3] for h in w.ray_hits], dtype=T))
             np.testing.assert_array_equal(orc.camera_view[0], w.camera_view)
     finally:
-        pyref.set_world_unit_type(np.float32)
+        orc.close()
