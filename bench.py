@@ -134,6 +134,11 @@ def main():
     gen.manual_seed(1234 + rank)
     actions = torch.randint(1, 5, (total, B), dtype=torch.uint8, device="cuda", generator=gen)
     torch.cuda.synchronize()
+    # engine and torch share ONE stream (the deployment shape: policy kernels and env kernels in order on
+    # a single queue, no cross-stream waits)
+    stream = torch.cuda.Stream()
+    env.set_stream(stream.cuda_stream)
+    torch.cuda.set_stream(stream)
 
     def barrier():
         if dist is not None:

@@ -169,6 +169,9 @@ RCW_API int rcw_set_direction_table(rcw_handle* h, const float* directions_wu);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the
  * handle's own stream.  The caller keeps the stream alive. */
 RCW_API int rcw_set_stream(rcw_handle* h, void* hip_stream);
+/* The stream the handle's work is ordered on (hipStream_t as void*), e.g. to make it wait for the
+ * producer of device-resident actions or to order a consumer of the observations behind a step. */
+RCW_API int rcw_get_stream(rcw_handle* h, void** hip_stream);
 /* Render into a caller-owned DEVICE buffer of B*N*H_cam UInt32 instead of the
  * library's (NULL restores it).  Takes effect at the next render; does not synchronise, so a
  * caller can alternate two buffers while the previous frame batch is still being consumed. */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rcw_destroy": [_vp],
     "rcw_set_direction_table": [_vp, _vp],
     "rcw_set_stream": [_vp, _vp],
+    "rcw_get_stream": [_vp, C.POINTER(_vp)],
     "rcw_bind_obs": [_vp, _vp],
     "rcw_reset": [_vp, _vp, _u64],
     "rcw_set_state": [_vp, _vp, _vp, _vp, _vp],

@@ -503,6 +503,13 @@ int rcw_set_stream(rcw_handle* h, void* hip_stream)
     return RCW_OK;
 }
 
+int rcw_get_stream(rcw_handle* h, void** hip_stream)
+{
+    if (!h || !hip_stream) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *hip_stream = (void*)h->stream;
+    return RCW_OK;
+}
+
 int rcw_bind_obs(rcw_handle* h, void* device_ptr)
 {
     int rc = check_handle(h); if (rc) return rc;

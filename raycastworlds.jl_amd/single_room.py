@@ -408,6 +408,18 @@ class SingleRoom:
         fn = self._lib.rcw_set_direction_table64 if self.T is np.float64 else self._lib.rcw_set_direction_table
         _capi.check(fn(self._h, _as_ptr(d)))
 
+    def stream_ptr(self) -> int:
+        """The hipStream_t (as an int) the engine's work is ordered on."""
+        p = C.c_void_p()
+        _capi.check(self._lib.rcw_get_stream(self._h, C.byref(p)))
+        return int(p.value or 0)
+
+    def torch_stream(self):
+        """The engine's stream as a torch stream object (for wait_stream / wait_event)."""
+        import torch
+
+        return torch.cuda.ExternalStream(self.stream_ptr(), device=f"cuda:{self.device}")
+
     def set_stream(self, hip_stream: Optional[int]):
         _capi.check(self._lib.rcw_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
@@ -490,6 +502,11 @@ def act_(env: SingleRoom, action) -> None:
 
             if action.dtype != torch.uint8 or action.numel() != env.batch or not action.is_contiguous():
                 raise ValueError("device actions must be a contiguous uint8 tensor of length batch")
+            # The actions were produced on torch's current stream; unless the engine runs on that very
+            # stream, make the engine's stream wait for them (an event record + wait, no host sync).
+            producer = torch.cuda.current_stream(action.device)
+            if producer.cuda_stream != env.stream_ptr():
+                env.torch_stream().wait_stream(producer)
             _capi.check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
             return None
     a = host_actions(env.batch, action)

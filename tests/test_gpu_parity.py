@@ -421,3 +421,20 @@ def test_extreme_shapes(rcw, oracle):
         env.close()
     with pytest.raises(rcw.SingleRoomModule._capi.RcwError):
         rcw.SingleRoomModule.SingleRoom(batch=1, height_tile_map_tu=300, width_tile_map_tu=300)   # > 65536 tiles
+
+
+def test_device_actions_are_ordered_behind_their_producer(rcw, oracle):
+    """Actions computed by torch kernels on torch's stream, engine on its own stream: act_ makes the
+    engine wait for the producer (no host synchronisation in between)."""
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 4096, seed=23, out_of_bounds=1, **CFG1)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    big = torch.randn(4096, 4096, device="cuda")
+    for s in range(12):
+        # a deliberately slow producer: a large matmul feeds the argmax that becomes the actions
+        logits = (big @ torch.randn(4096, 4, device="cuda", generator=g))
+        actions = (logits.argmax(dim=1) + 1).to(torch.uint8)
+        rcw.act_(env, actions)                 # no synchronize() between producer and engine
+        orc.step(actions.cpu().numpy())
+    assert_state_equal(env, orc, frames=False, where="ordered behind the producer")
+    env.close()
