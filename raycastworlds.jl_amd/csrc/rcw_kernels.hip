@@ -546,7 +546,30 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
 
     // ---- draw_tile_map!: each tile's square and its one-pixel frame.  Tiles do not overlap, so the
     // reference's tile-by-tile order does not matter; rows of a column are contiguous (column-major).
-    if ((Ht & 3) == 0) {
+    if ((pu & 3) == 0) {
+        // One wavefront per image column (its tile column j and frame flag are wave-uniform), lanes
+        // along the contiguous rows, four pixels per lane — they never straddle a tile when pu % 4 == 0.
+        const int wave = tid >> 6, lane = tid & 63;
+        u32x4* out = reinterpret_cast<u32x4*>(img);
+        for (int jp0 = wave; jp0 < Wt; jp0 += kBlock / 64) {
+            const int j = jp0 / pu;
+            const int rj = jp0 - j * pu;
+            const bool frame_col = rj == 0 || rj == pu - 1;                  // SR:366-367
+            for (int ip0 = lane * 4; ip0 < Ht; ip0 += 256) {
+                const int i = ip0 / pu;
+                const int ri = ip0 - i * pu;
+                const uint32_t bits = tb[i + p.H * j];
+                const uint32_t fill = (bits & 1u) ? 0x00FFFFFFu : ((bits & 2u) ? 0x00FF0000u : 0x00000000u);   // SR:355-360
+                const uint32_t inner = frame_col ? 0x00ccccccu : fill;
+                u32x4 v;
+                v.x = ri == 0 ? 0x00ccccccu : inner;                         // SR:364: first row of the tile
+                v.y = inner;
+                v.z = inner;
+                v.w = ri + 3 == pu - 1 ? 0x00ccccccu : inner;                // SR:365: last row of the tile
+                out[(size_t)jp0 * (Ht >> 2) + (ip0 >> 2)] = v;
+            }
+        }
+    } else if ((Ht & 3) == 0) {
         const int vpc = Ht >> 2;
         u32x4* out = reinterpret_cast<u32x4*>(img);
         for (int idx = tid; idx < vpc * Wt; idx += kBlock) {
