@@ -39,11 +39,3 @@ def assert_state_equal(env, orc, frames=True, rays=False, where=""):
         assert dist.dtype == orc.ray_dist.dtype
         np.testing.assert_array_equal(dist.view(bits), orc.ray_dist.view(bits), err_msg=f"ray_dist {where}")
         np.testing.assert_array_equal(dirs.view(bits), orc.ray_dirs.view(bits), err_msg=f"ray_dirs {where}")
-
-
-def frame_checksum(frames: np.ndarray) -> int:
-    """Order-sensitive 64-bit checksum of a uint32 frame batch (FNV-style over words)."""
-    x = frames.astype(np.uint64).reshape(-1)
-    idx = np.arange(1, x.size + 1, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        return int(np.bitwise_xor.reduce((x + np.uint64(0x9E3779B97F4A7C15)) * (idx * np.uint64(0xBF58476D1CE4E5B9) | np.uint64(1))))
