@@ -14,9 +14,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def rcw():
-    """The product package (host mirror + ctypes binding of librcw_hip.so)."""
+    """The product package (host mirror + ctypes binding of librcw_hip.so).  The shared library is a
+    build artefact (git-ignored): compile it with hipcc if this checkout does not have it yet."""
     import raycastworlds_jl_amd as RCW
+    from raycastworlds_jl_amd import _capi
+    from raycastworlds_jl_amd import build as _build
 
+    if not os.path.exists(_capi.LIB_PATH):
+        _build.build()
     return RCW
 
 
