@@ -122,6 +122,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import raycastworlds_jl_amd as RCW
+    from raycastworlds_jl_amd import _capi
+
+    if not os.path.exists(_capi.LIB_PATH):       # a checkout without the (git-ignored) build artefact
+        if rank == 0:
+            from raycastworlds_jl_amd import build as _build
+
+            _build.build()
+        if dist is not None:
+            dist.barrier()
 
     kw, per_gpu = WORKLOADS[args.workload]
     B = args.batch or per_gpu
