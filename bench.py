@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="agents per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--top-view", action="store_true",
+                    help="also render the reference's top view every step (update_top_view! SR:446-483, opt-in in the "
+                         "engine) and report that kernel's own roofline block; NOT the headline workload")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share GPU 0 and rendezvous over gloo (checks the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -136,7 +139,7 @@ def main():
     B = args.batch or per_gpu
     N, Hc = kw["num_rays"], 256
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=0, device=local_rank, auto_reset=not args.no_auto_reset,
-                                          agent_id_offset=rank * B, **kw)
+                                          agent_id_offset=rank * B, render_top_view=args.top_view, **kw)
     # U{1..4} actions per agent per step (test/runtests.jl:28), pre-generated on the device
     total = args.warmup + args.steps
     gen = torch.Generator(device="cuda")
@@ -185,14 +188,14 @@ def main():
     env.profile(True)
     for s in range(args.warmup, args.warmup + nprof):
         RCW.act_(env, actions[s])
-    cast_ms, fill_ms, nrec = env.profile_read()
+    cast_ms, top_ms, fill_ms, nrec = env.profile_read()
     env.profile(False)
     sync_counting_bounds_errors()
     if dist is not None:
-        t = torch.tensor([dt, kernel_ms, cast_ms, fill_ms], dtype=torch.float64,
+        t = torch.tensor([dt, kernel_ms, cast_ms, fill_ms, top_ms], dtype=torch.float64,
                          device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms, cast_ms, fill_ms = (float(v) for v in t)
+        dt, kernel_ms, cast_ms, fill_ms, top_ms = (float(v) for v in t)
 
     if rank == 0:
         frame_bytes = 4 * Hc * N                          # bytes per env-step
@@ -255,6 +258,16 @@ def main():
                 },
             },
         }
+        if args.top_view:
+            pu = env.cfg.pu_per_tu
+            top_bytes = 4 * (kw["height_tile_map_tu"] * pu) * (kw["width_tile_map_tu"] * pu) * B
+            top_gbs = top_bytes / (top_ms / 1e3) / 1e9
+            out["config"]["render_top_view"] = True
+            out["top_view"] = {
+                "kernel": "rcw_top_view_kernel", "bound": "hbm", "bytes_per_launch": top_bytes, "launch_ms": top_ms,
+                "achieved": top_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top_gbs / HBM_PEAK_GBS,
+                "note": "update_top_view! SR:446-483, 4*(H*pu)*(W*pu) bytes per agent written once; opt-in, not in `value` of the headline run",
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, B)
         print(json.dumps(out), flush=True)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RCW_ABI_VERSION 2
+#define RCW_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define RCW_API __attribute__((visibility("default")))
@@ -96,6 +96,13 @@ extern "C" {
 #define RCW_OOB_ERROR       0
 #define RCW_OOB_TREAT_EMPTY 1
 
+/* R of SingleRoom(; R = ...) SR:266: the element type of world.reward / world.goal_reward (SR:33-34).  The
+ * reference only ever stores zero(R) (SR:81, SR:131, SR:170-186) and goal_reward = one(R) (SR:82) in it. */
+#define RCW_REWARD_FLOAT32 0   /* default */
+#define RCW_REWARD_FLOAT64 1
+#define RCW_REWARD_INT32   2
+#define RCW_REWARD_INT64   3
+
 /* Mirrors the keyword arguments of SingleRoom(; ...) SR:258-272 and the colour
  * constants SR:288-296.  Fill with rcw_config_default() and then override. */
 typedef struct rcw_config {
@@ -110,7 +117,7 @@ typedef struct rcw_config {
     float    position_increment_wu;   /* SR:264  default 1/8                               */
     float    semi_field_of_view_wu;   /* SR:267  default Float32(2/3)                      */
     float    camera_height_tile_wu;   /* SR:270  default 1                                 */
-    float    goal_reward;             /* SR:86   one(R)                                    */
+    float    goal_reward;             /* SR:82   one(R) for R = Float32; other R: goal_reward_f64 */
     uint32_t floor_color;             /* SR:291  0x00404040                                */
     uint32_t ceiling_color;           /* SR:292  0x00FFFFFF                                */
     uint32_t wall_dim_1_color;        /* SR:293  0x00808080                                */
@@ -126,9 +133,8 @@ typedef struct rcw_config {
     int64_t  agent_id_offset;         /* global id of local agent 0 (multi-GPU sharding);
                                          keys the reset RNG so results do not depend on
                                          how agents are sharded                            */
-    int32_t  write_columns;           /* ignored since the step became cast + fill: the
-                                         compact per-column descriptor (height_line_pu,
-                                         colour id) is always kept in device memory        */
+    int32_t  reward_type;             /* RCW_REWARD_*: R of SingleRoom(; R = ...) SR:266; the reward array
+                                         (rcw_reward_typed, rcw_reward_device_ptr) has this element type  */
     int32_t  out_of_bounds;           /* RCW_OOB_ERROR (default, reference behaviour) |
                                          RCW_OOB_TREAT_EMPTY                               */
     int32_t  render_top_view;         /* 1: every reset/step also renders the top view
@@ -146,7 +152,8 @@ typedef struct rcw_config {
     double   position_increment_wu_f64;
     double   semi_field_of_view_wu_f64;
     double   camera_height_tile_wu_f64;
-    int32_t  reserved[4];
+    double   goal_reward_f64;         /* SR:82 one(R) for R = Float64 / Int32 / Int64 (converted to R)     */
+    int32_t  reserved[2];
 } rcw_config;
 
 typedef struct rcw_handle rcw_handle;   /* opaque */
@@ -219,6 +226,17 @@ RCW_API int rcw_step(rcw_handle* h, const uint8_t* actions_host);
  * The error is returned by the next rcw_sync()/getter and cleared by rcw_clear_error. */
 RCW_API int rcw_step_device(rcw_handle* h, const uint8_t* actions_device);
 
+/* The three renderers of the reference as separate calls, for every agent, stream-ordered like rcw_step:
+ *   rcw_cast_rays            RCW.cast_rays!(world) SR:195-231: recompute the rays (and with them the compact
+ *                            column descriptors) from the current state; no pixel is written.
+ *   rcw_update_camera_view   RCW.update_camera_view!(env) SR:374-444: refill camera_view from the stored ray
+ *                            results, without casting (as in the reference, whose update_*_view! never cast).
+ *   rcw_update_top_view      RCW.update_top_view!(env) SR:446-483 (needs cfg.render_top_view).
+ * rcw_step / rcw_reset / rcw_set_state already do all of them; these exist because the reference exports them. */
+RCW_API int rcw_cast_rays(rcw_handle* h);
+RCW_API int rcw_update_camera_view(rcw_handle* h);
+RCW_API int rcw_update_top_view(rcw_handle* h);
+
 RCW_API int rcw_sync(rcw_handle* h);
 RCW_API int rcw_clear_error(rcw_handle* h);
 
@@ -235,8 +253,11 @@ RCW_API int rcw_obs_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32
  * circle are ASSUMED — parity unpinned. */
 RCW_API int rcw_top_view_device_ptr(rcw_handle* h, void** device_ptr);
 RCW_API int rcw_top_view_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t count);
-/* RLBase.reward SR:583 / RLBase.is_terminated SR:584 */
+/* RLBase.reward SR:583 / RLBase.is_terminated SR:584.  rcw_reward serves R = Float32 handles; rcw_reward_typed
+ * copies B elements of the handle's R (cfg.reward_type) whatever it is; the device array behind
+ * rcw_reward_device_ptr has that element type too. */
 RCW_API int rcw_reward(rcw_handle* h, float* out_host /* (B) */);
+RCW_API int rcw_reward_typed(rcw_handle* h, void* out_host /* (B) of R */);
 RCW_API int rcw_done(rcw_handle* h, uint8_t* out_host /* (B) */);
 RCW_API int rcw_reward_device_ptr(rcw_handle* h, void** device_ptr);
 RCW_API int rcw_done_device_ptr(rcw_handle* h, void** device_ptr);
@@ -272,6 +293,39 @@ RCW_API int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** 
 RCW_API int rcw_expand_columns(rcw_handle* h, const int32_t* height_line_pu_device,
                        const uint8_t* colour_id_device, int32_t count, void* frames_device);
 
+/* ---- multi-GPU: the observation gather north_star names, for a host without torch (Julia) ---------------
+ * Agents shard by rank (cfg.agent_id_offset); stepping needs no communication.  The only exchange is the
+ * optional all-gather of the observation batch over RCCL (xGMI inside a node).  librccl is loaded at run time
+ * (dlopen of librccl.so.1 — the copy already in the process if there is one) the first time a comm call is
+ * made, so single-GPU users do not need it.
+ *   rcw_comm_unique_id   ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks
+ *                        (a file, a socket, MPI, Julia's Distributed — the transport is the caller's).
+ *   rcw_comm_init        ncclCommInitRank on the handle's device; collective over all `world` ranks.
+ *   rcw_gather_columns   ncclAllGather of the compact descriptors (5 bytes per column) on the handle's stream:
+ *                        height_line_pu Int32 (N, B*world) and colour id UInt8 (N, B*world) in DEVICE memory,
+ *                        rank r's agents at [r*B, (r+1)*B).
+ *   rcw_gather_observations   the GLOBAL observation batch UInt32 (H_cam, N, B*world) in caller-owned DEVICE
+ *                        memory on every rank.  RCW_GATHER_COLUMNS: gather descriptors, expand to pixels locally
+ *                        (rcw_expand_columns) — 5 bytes per column over the links instead of 4*H_cam;
+ *                        RCW_GATHER_FRAMES: ncclAllGather of the pixels themselves.
+ * All of them are stream-ordered behind the step that produced the frames and return without waiting. */
+#define RCW_UNIQUE_ID_BYTES 128
+#define RCW_GATHER_COLUMNS 0
+#define RCW_GATHER_FRAMES  1
+RCW_API int rcw_comm_unique_id(void* out_id /* RCW_UNIQUE_ID_BYTES */);
+RCW_API int rcw_comm_init(rcw_handle* h, const void* unique_id, int32_t rank, int32_t world);
+RCW_API int rcw_comm_destroy(rcw_handle* h);
+RCW_API int rcw_comm_info(rcw_handle* h, int32_t* rank, int32_t* world /* 0, 0 before rcw_comm_init */);
+RCW_API int rcw_gather_columns(rcw_handle* h, int32_t* height_line_pu_all_device, uint8_t* colour_id_all_device);
+RCW_API int rcw_gather_observations(rcw_handle* h, int32_t mode, void* frames_all_device);
+
+/* Device buffers for a host that has no GPU array package of its own (the gather outputs above, rcw_bind_obs,
+ * rcw_expand_columns): plain hipMalloc / hipFree on the handle's device, and a copy to host memory that is
+ * ordered behind the handle's stream (it waits for the work enqueued so far, then copies). */
+RCW_API int rcw_device_malloc(rcw_handle* h, uint64_t bytes, void** device_ptr);
+RCW_API int rcw_device_free(rcw_handle* h, void* device_ptr);
+RCW_API int rcw_memcpy_to_host(rcw_handle* h, void* dst_host, const void* src_device, uint64_t bytes);
+
 /* The (direction, ray) table the kernels use, for inspection and parity tests:
  * Float32 (N, 5, num_directions) = per direction [dx | dy | |1/dx| | |1/dy| | dir.ray]. */
 RCW_API int rcw_ray_table(rcw_handle* h, float* out_host);
@@ -281,11 +335,11 @@ RCW_API int rcw_direction_table(rcw_handle* h, float* out_host /* (2, nd) */);
 RCW_API int rcw_timer_start(rcw_handle* h);
 RCW_API int rcw_timer_stop(rcw_handle* h, float* elapsed_ms);
 
-/* Per-kernel timing: while enabled, HIP events bracket the cast kernel and the fill kernel of
- * each step (at most 256 steps are recorded).  rcw_profile_read returns their mean durations
- * over the recorded steps. */
+/* Per-kernel timing: while enabled, HIP events bracket the cast kernel, the top view kernel (when
+ * cfg.render_top_view) and the fill kernel of each step (at most 256 steps are recorded).
+ * rcw_profile_read returns their mean durations over the recorded steps (top_view_ms = 0 without it). */
 RCW_API int rcw_profile(rcw_handle* h, int32_t enable);
-RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* fill_ms, int32_t* steps);
+RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* fill_ms, int32_t* steps);
 
 /* Introspection */
 RCW_API int rcw_batch(rcw_handle* h, int32_t* out);

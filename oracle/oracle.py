@@ -45,7 +45,7 @@ class RcwConfig(C.Structure):
         ("normalize_mode", C.c_int32),
         ("auto_reset", C.c_int32),
         ("agent_id_offset", C.c_int64),
-        ("write_columns", C.c_int32),
+        ("reward_type", C.c_int32),
         ("out_of_bounds", C.c_int32),
         ("render_top_view", C.c_int32),
         ("world_unit_bits", C.c_int32),
@@ -53,14 +53,15 @@ class RcwConfig(C.Structure):
         ("position_increment_wu_f64", C.c_double),
         ("semi_field_of_view_wu_f64", C.c_double),
         ("camera_height_tile_wu_f64", C.c_double),
-        ("reserved", C.c_int32 * 4),
+        ("goal_reward_f64", C.c_double),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
 def default_config(**overrides) -> RcwConfig:
     """Reference defaults SR:258-272, SR:288-296 (restated, not read from the product)."""
     cfg = RcwConfig()
-    cfg.abi_version = 2
+    cfg.abi_version = 3
     cfg.height_tile_map_tu = 8
     cfg.width_tile_map_tu = 16
     cfg.num_directions = 128
@@ -78,7 +79,8 @@ def default_config(**overrides) -> RcwConfig:
     cfg.wall_dim_2_color = 0x00C0C0C0
     cfg.goal_dim_1_color = 0x00800000
     cfg.goal_dim_2_color = 0x00C00000
-    cfg.write_columns = 1
+    cfg.reward_type = 0          # R = Float32 SR:266
+    cfg.goal_reward_f64 = 1.0    # one(R) SR:82
     cfg.world_unit_bits = 32
     cfg.player_radius_wu_f64 = 1 / 8
     cfg.position_increment_wu_f64 = 1 / 8
@@ -240,7 +242,9 @@ class OracleBatch:
 
     @property
     def reward(self):
-        return self._g("reward", np.float32, (self.B,))
+        """world.reward in the batch's R (cfg.reward_type: Float32 / Float64 / Int32 / Int64)."""
+        dt = (np.float32, np.float64, np.int32, np.int64)[self.cfg.reward_type]
+        return self._g("reward", dt, (self.B,))
 
     @property
     def done(self):

@@ -39,7 +39,8 @@
 
 /* World-unit type T of the reference (SR:259).  This file is compiled twice: as is (Float32,
  * librcw_oracle.so) and with -DORC_REAL64 (Float64, librcw_oracle64.so); every arithmetic
- * operation of the path is the same operation in T.  R (reward) is Float32 in both. */
+ * operation of the path is the same operation in T.  R (the reward type, SR:266) is independent of T:
+ * cfg.reward_type, orc_set_reward below. */
 #ifdef ORC_REAL64
 typedef double real;
 #define RC(x) x
@@ -219,7 +220,7 @@ typedef struct orc_batch {
     real* pos;             /* (2, B) */
     int32_t* dir;           /* (B) */
     int32_t* goal;          /* (2, B) 1-based */
-    float* reward;          /* (B) */
+    void* reward;           /* (B) of R = cfg.reward_type (SR:33) */
     uint8_t* done;          /* (B) */
     uint32_t* episode;      /* (B) */
     int32_t* status;        /* (B) sticky per-agent error */
@@ -425,6 +426,17 @@ static void orc_render_agent(orc_batch* b, int32_t a)
     orc_update_camera_view_agent(b, a);   /* SR:338 / SR:329 */
 }
 
+/* world.reward::R (SR:33): zero(R) (SR:81,131,170-186) or goal_reward = one(R) (SR:82,167), in the batch's R */
+static void orc_set_reward(orc_batch* b, int32_t a, int goal)
+{
+    switch (b->cfg.reward_type) {
+    case RCW_REWARD_FLOAT64: ((double*)b->reward)[a] = goal ? b->cfg.goal_reward_f64 : 0.0; break;
+    case RCW_REWARD_INT32:   ((int32_t*)b->reward)[a] = goal ? (int32_t)b->cfg.goal_reward_f64 : 0; break;
+    case RCW_REWARD_INT64:   ((int64_t*)b->reward)[a] = goal ? (int64_t)b->cfg.goal_reward_f64 : 0; break;
+    default:                 ((float*)b->reward)[a] = goal ? b->cfg.goal_reward : 0.0f; break;
+    }
+}
+
 /* reset!(world)  SR:110-137 with the build's generator */
 static void orc_reset_agent(orc_batch* b, int32_t a, uint64_t seed)
 {
@@ -453,7 +465,7 @@ static void orc_reset_agent(orc_batch* b, int32_t a, uint64_t seed)
     b->pos[2 * a] = (real)((double)pi - 0.5);                       /* SR:125 */
     b->pos[2 * a + 1] = (real)((double)pj - 0.5);
     b->dir[a] = (int32_t)orc_below(orc_draw(key, n++), (uint64_t)b->nd);   /* SR:128 */
-    b->reward[a] = RC(0.0); b->done[a] = 0;                             /* SR:131-132 */
+    orc_set_reward(b, a, 0); b->done[a] = 0;                             /* SR:131-132 */
     b->episode[a] += 1;
     orc_render_agent(b, a);                                          /* SR:134, SR:329 */
 }
@@ -479,7 +491,7 @@ ORC_EXPORT int orc_create(const rcw_config* cfg, int32_t batch, uint64_t seed, i
     b->pos = (real*)calloc(2 * B, sizeof(real));
     b->dir = (int32_t*)calloc(B, sizeof(int32_t));
     b->goal = (int32_t*)calloc(2 * B, sizeof(int32_t));
-    b->reward = (float*)calloc(B, sizeof(float));
+    b->reward = calloc(B, 8);
     b->done = (uint8_t*)calloc(B, 1);
     b->episode = (uint32_t*)calloc(B, sizeof(uint32_t));
     b->status = (int32_t*)calloc(B, sizeof(int32_t));
@@ -556,7 +568,7 @@ ORC_EXPORT int orc_set_state(orc_batch* b, const int32_t* goal_ij, const real* p
         gm[(b->goal[2 * a] - 1) + (size_t)H * (b->goal[2 * a + 1] - 1)] = 1;   /* SR:122 */
         b->pos[2 * a] = pos[2 * a]; b->pos[2 * a + 1] = pos[2 * a + 1];        /* SR:126 */
         b->dir[a] = dir[a];                                                     /* SR:129 */
-        b->reward[a] = RC(0.0); b->done[a] = 0;                                    /* SR:131-132 */
+        orc_set_reward(b, a, 0); b->done[a] = 0;                                    /* SR:131-132 */
         orc_render_agent(b, a);
     }
     return RCW_OK;
@@ -584,18 +596,18 @@ static void orc_act_agent(orc_batch* b, int32_t a, int action)
             return;
         }
         if (g || w) {                                               /* SR:165 */
-            if (g) { b->reward[a] = b->cfg.goal_reward; b->done[a] = 1; }   /* SR:166-168 */
-            else   { b->reward[a] = RC(0.0); b->done[a] = 0; }                 /* SR:170-171 */
+            if (g) { orc_set_reward(b, a, 1); b->done[a] = 1; }   /* SR:166-168 */
+            else   { orc_set_reward(b, a, 0); b->done[a] = 0; }                 /* SR:170-171 */
         } else {
             b->pos[2 * a] = nx; b->pos[2 * a + 1] = ny;             /* SR:174 */
-            b->reward[a] = RC(0.0); b->done[a] = 0;                    /* SR:175-176 */
+            orc_set_reward(b, a, 0); b->done[a] = 0;                    /* SR:175-176 */
         }
     } else {
         int32_t d = b->dir[a];
         if (action == 3) d = (d + 1) % nd;                          /* turn_left UT:13 */
         else             d = ((d - 1) % nd + nd) % nd;              /* turn_right UT:14 (floored mod) */
         b->dir[a] = d;                                              /* SR:185 */
-        b->reward[a] = RC(0.0); b->done[a] = 0;                        /* SR:186-187 */
+        orc_set_reward(b, a, 0); b->done[a] = 0;                        /* SR:186-187 */
     }
 }
 
@@ -639,7 +651,7 @@ ORC_EXPORT void orc_clear_status(orc_batch* b) { memset(b->status, 0, sizeof(int
 /* ---- getters ----------------------------------------------------------------------- */
 ORC_EXPORT const uint32_t* orc_camera_view(orc_batch* b) { return b->camera_view; }
 ORC_EXPORT const uint32_t* orc_top_view(orc_batch* b) { return b->top_view; }
-ORC_EXPORT const float* orc_reward(orc_batch* b) { return b->reward; }
+ORC_EXPORT const void* orc_reward(orc_batch* b) { return b->reward; }
 ORC_EXPORT const uint8_t* orc_done(orc_batch* b) { return b->done; }
 ORC_EXPORT const real* orc_position(orc_batch* b) { return b->pos; }
 ORC_EXPORT const int32_t* orc_direction(orc_batch* b) { return b->dir; }

@@ -20,6 +20,12 @@ RCW_ERR_OUT_OF_MEMORY = -4
 RCW_ERR_OUT_OF_BOUNDS = -5
 RCW_ERR_HIP = -6
 RCW_ERR_UNSUPPORTED = -7
+RCW_ABI_VERSION = 3
+
+# R of SingleRoom(; R = ...) SR:266 (include/rcw.h RCW_REWARD_*)
+RCW_REWARD_FLOAT32, RCW_REWARD_FLOAT64, RCW_REWARD_INT32, RCW_REWARD_INT64 = 0, 1, 2, 3
+RCW_GATHER_COLUMNS, RCW_GATHER_FRAMES = 0, 1
+RCW_UNIQUE_ID_BYTES = 128
 
 
 class RcwConfig(C.Structure):
@@ -49,7 +55,7 @@ class RcwConfig(C.Structure):
         ("normalize_mode", C.c_int32),
         ("auto_reset", C.c_int32),
         ("agent_id_offset", C.c_int64),
-        ("write_columns", C.c_int32),
+        ("reward_type", C.c_int32),
         ("out_of_bounds", C.c_int32),
         ("render_top_view", C.c_int32),
         ("world_unit_bits", C.c_int32),
@@ -57,7 +63,8 @@ class RcwConfig(C.Structure):
         ("position_increment_wu_f64", C.c_double),
         ("semi_field_of_view_wu_f64", C.c_double),
         ("camera_height_tile_wu_f64", C.c_double),
-        ("reserved", C.c_int32 * 4),
+        ("goal_reward_f64", C.c_double),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -93,6 +100,9 @@ SIGNATURES = {
     "rcw_direction_table64": [_vp, _vp],
     "rcw_step": [_vp, _vp],
     "rcw_step_device": [_vp, _vp],
+    "rcw_cast_rays": [_vp],
+    "rcw_update_camera_view": [_vp],
+    "rcw_update_top_view": [_vp],
     "rcw_sync": [_vp],
     "rcw_clear_error": [_vp],
     "rcw_obs_device_ptr": [_vp, C.POINTER(_vp)],
@@ -100,6 +110,7 @@ SIGNATURES = {
     "rcw_top_view_device_ptr": [_vp, C.POINTER(_vp)],
     "rcw_top_view_copy": [_vp, _vp, _i32, _i32],
     "rcw_reward": [_vp, _vp],
+    "rcw_reward_typed": [_vp, _vp],
     "rcw_done": [_vp, _vp],
     "rcw_reward_device_ptr": [_vp, C.POINTER(_vp)],
     "rcw_done_device_ptr": [_vp, C.POINTER(_vp)],
@@ -119,7 +130,16 @@ SIGNATURES = {
     "rcw_timer_start": [_vp],
     "rcw_timer_stop": [_vp, C.POINTER(C.c_float)],
     "rcw_profile": [_vp, _i32],
-    "rcw_profile_read": [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)],
+    "rcw_profile_read": [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)],
+    "rcw_comm_unique_id": [_vp],
+    "rcw_comm_init": [_vp, _vp, _i32, _i32],
+    "rcw_comm_destroy": [_vp],
+    "rcw_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
+    "rcw_gather_columns": [_vp, _vp, _vp],
+    "rcw_gather_observations": [_vp, _i32, _vp],
+    "rcw_device_malloc": [_vp, _u64, C.POINTER(_vp)],
+    "rcw_device_free": [_vp, _vp],
+    "rcw_memcpy_to_host": [_vp, _vp, _vp, _u64],
     "rcw_batch": [_vp, C.POINTER(_i32)],
     "rcw_get_config": [_vp, C.POINTER(RcwConfig)],
     "rcw_device_name": [_vp, C.c_char_p, _i32],
@@ -153,6 +173,26 @@ def _preload_hip_runtime() -> None:
             pass
 
 
+def preload_rccl() -> None:
+    """One RCCL per process, for the same reason: PyTorch's wheel bundles its own librccl.so (soname
+    librccl.so.1).  librcw_hip loads RCCL lazily with dlopen("librccl.so.1"), which returns whatever copy
+    is resident; loading torch's first makes rcw_comm_* and torch.distributed share one instance."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load librcw_hip.so; loud failure when it has not been built."""
     global _lib
@@ -169,8 +209,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.rcw_abi_version() != 2:
-        raise ImportError(f"librcw_hip ABI {lib.rcw_abi_version()} != 2")
+    if lib.rcw_abi_version() != RCW_ABI_VERSION:
+        raise ImportError(f"librcw_hip ABI {lib.rcw_abi_version()} != {RCW_ABI_VERSION}: rebuild with `make -C raycastworlds.jl_amd/csrc`")
     _lib = lib
     return lib
 

@@ -6,6 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded at run time (load_rccl)
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,7 +61,14 @@ struct rcw_handle {
     int action_slot = 0;
     bool profiling = false;
     int prof_count = 0;
-    std::vector<hipEvent_t> prof_ev;   // 3 per recorded step
+    std::vector<hipEvent_t> prof_ev;   // 4 per recorded step: start | after cast | after top view | after fill
+    void* d_rays[4] = {nullptr, nullptr, nullptr, nullptr};   // rcw_rays scratch (grow-only)
+    size_t rays_cap[4] = {0, 0, 0, 0};
+    size_t reward_size = sizeof(float);
+    // RCCL (loaded on demand): the observation gather
+    void* comm = nullptr;              // ncclComm_t
+    int32_t comm_rank = 0, comm_world = 0;
+    void* d_gather_h = nullptr; void* d_gather_c = nullptr;   // gathered descriptors (B * world columns)
     bool real64 = false;            // world-unit type T = Float64 (cfg.world_unit_bits = 64)
     size_t real_size = sizeof(float);
     std::vector<float> dir_table;   // (2, nd)        T = Float32
@@ -78,14 +88,16 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
 {
     const RcwDev& d = h->dev;
     const bool prof = h->profiling && h->prof_count < kProfileSlots;
+    hipEvent_t* ev = prof ? &h->prof_ev[4 * h->prof_count] : nullptr;
     hipError_t e;
-    if (prof && (e = hipEventRecord(h->prof_ev[3 * h->prof_count + 0], h->stream)) != hipSuccess) return e;
+    if (prof && (e = hipEventRecord(ev[0], h->stream)) != hipSuccess) return e;
     if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
+    if (prof && (e = hipEventRecord(ev[1], h->stream)) != hipSuccess) return e;
     if (d.top_view && (e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;   // SR:337
-    if (prof && (e = hipEventRecord(h->prof_ev[3 * h->prof_count + 1], h->stream)) != hipSuccess) return e;
+    if (prof && (e = hipEventRecord(ev[2], h->stream)) != hipSuccess) return e;
     if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
     if (prof) {
-        if ((e = hipEventRecord(h->prof_ev[3 * h->prof_count + 2], h->stream)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e;
         h->prof_count++;
     }
     return hipSuccess;
@@ -109,6 +121,10 @@ void free_all(rcw_handle* h)
         h->h_actions[k] = nullptr;
         h->ev_actions[k] = nullptr;
     }
+    for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
+    if (h->d_gather_h) (void)hipFree(h->d_gather_h);
+    if (h->d_gather_c) (void)hipFree(h->d_gather_c);
+    h->d_gather_h = h->d_gather_c = nullptr;
     for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
     h->prof_ev.clear();
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -198,11 +214,24 @@ int validate_config(const rcw_config* c, int32_t batch)
     if (c->height_tile_map_tu < 3 || c->width_tile_map_tu < 3)
         return fail(RCW_ERR_INVALID_ARGUMENT, "tile map must be at least 3x3 (got %dx%d)",
                     c->height_tile_map_tu, c->width_tile_map_tu);
-    if ((long long)c->height_tile_map_tu * c->width_tile_map_tu > 65536)
-        return fail(RCW_ERR_UNSUPPORTED, "tile map larger than 65536 tiles does not fit the LDS staging");
+    // the cast kernel stages a byte per tile in dynamic LDS next to a few static words: 64 KiB per workgroup in all
+    if ((long long)c->height_tile_map_tu * c->width_tile_map_tu > 65536 - 256)
+        return fail(RCW_ERR_UNSUPPORTED, "tile map larger than 65280 tiles does not fit the LDS staging");
     if (c->num_directions < 1 || c->num_rays < 1 || c->height_camera_view_pu < 1)
         return fail(RCW_ERR_INVALID_ARGUMENT, "num_directions, num_rays, height_camera_view_pu must be >= 1");
     if (c->num_rays > (1 << 24)) return fail(RCW_ERR_INVALID_ARGUMENT, "num_rays not exactly representable in Float32");
+    if (c->num_directions > (1 << 20) || (long long)c->num_directions * c->num_rays > (1ll << 24))
+        return fail(RCW_ERR_UNSUPPORTED, "num_directions * num_rays = %lld: the (direction, ray) table is limited to 2^24 entries",
+                    (long long)c->num_directions * c->num_rays);
+    if (c->height_camera_view_pu > (1 << 20))
+        return fail(RCW_ERR_UNSUPPORTED, "height_camera_view_pu larger than 2^20");
+    if (c->reward_type < RCW_REWARD_FLOAT32 || c->reward_type > RCW_REWARD_INT64)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "reward_type must be one of RCW_REWARD_* (got %d)", c->reward_type);
+    if (!std::isfinite(c->goal_reward) || !std::isfinite(c->goal_reward_f64))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "goal_reward must be finite");
+    if ((c->reward_type == RCW_REWARD_INT32 || c->reward_type == RCW_REWARD_INT64) &&
+        (c->goal_reward_f64 != std::floor(c->goal_reward_f64) || std::fabs(c->goal_reward_f64) > 2147483647.0))
+        return fail(RCW_ERR_INVALID_ARGUMENT, "goal_reward_f64 = %g is not an integer the reward type holds", c->goal_reward_f64);
     if (c->world_unit_bits != 32 && c->world_unit_bits != 64)
         return fail(RCW_ERR_INVALID_ARGUMENT, "world_unit_bits must be 32 or 64 (got %d)", c->world_unit_bits);
     if (c->world_unit_bits == 64) {
@@ -276,6 +305,65 @@ int copy_out(rcw_handle* h, T* out_host, const void* dev, size_t count)
     return rc;
 }
 
+
+// ---- RCCL, loaded on demand ------------------------------------------------------------------------------
+// librcw_hip does not link librccl: a single-GPU user never needs it, and inside a process that already
+// carries one (PyTorch bundles its own copy under the same soname) a second instance must not be loaded.
+// dlopen("librccl.so.1") returns the resident copy when there is one and the system one otherwise.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.lib) return RCW_OK;
+    const char* names[] = {std::getenv("RCW_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+    }
+    if (!lib) return fail(RCW_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded (%s); set RCW_RCCL_LIBRARY", dlerror());
+    RcclApi api;
+    api.lib = lib;
+#define RCW_SYM(field, name)                                                                       \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(lib, name));                          \
+    if (!api.field) { dlclose(lib); return fail(RCW_ERR_UNSUPPORTED, "librccl lacks %s", name); }
+    RCW_SYM(GetUniqueId, "ncclGetUniqueId")
+    RCW_SYM(CommInitRank, "ncclCommInitRank")
+    RCW_SYM(CommDestroy, "ncclCommDestroy")
+    RCW_SYM(AllGather, "ncclAllGather")
+    RCW_SYM(GroupStart, "ncclGroupStart")
+    RCW_SYM(GroupEnd, "ncclGroupEnd")
+    RCW_SYM(GetErrorString, "ncclGetErrorString")
+    RCW_SYM(GetVersion, "ncclGetVersion")
+#undef RCW_SYM
+    g_rccl = api;
+    return RCW_OK;
+}
+
+#define RCW_NCCL(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail(RCW_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+int need_comm(rcw_handle* h, const char* fn)
+{
+    if (!h->comm) return fail(RCW_ERR_INVALID_ARGUMENT, "%s: call rcw_comm_init first", fn);
+    return RCW_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,7 +386,7 @@ int rcw_config_default(rcw_config* c)
     c->position_increment_wu = (float)(1.0 / 8.0);   // SR:264
     c->semi_field_of_view_wu = (float)(2.0 / 3.0);   // convert(T, 2/3) SR:267
     c->camera_height_tile_wu = 1.0f;    // SR:270
-    c->goal_reward = 1.0f;              // one(R) SR:86
+    c->goal_reward = 1.0f;              // one(R) SR:82
     c->floor_color = 0x00404040u;       // SR:291
     c->ceiling_color = 0x00FFFFFFu;     // SR:292
     c->wall_dim_1_color = 0x00808080u;  // SR:293
@@ -310,7 +398,8 @@ int rcw_config_default(rcw_config* c)
     c->normalize_mode = RCW_NORMALIZE_INV_NORM_TIMES;
     c->auto_reset = 0;
     c->agent_id_offset = 0;
-    c->write_columns = 1;
+    c->reward_type = RCW_REWARD_FLOAT32;           // R = Float32 SR:266
+    c->goal_reward_f64 = 1.0;                      // one(R) SR:82
     c->out_of_bounds = RCW_OOB_ERROR;
     c->world_unit_bits = 32;                       // T = Float32 SR:259
     c->player_radius_wu_f64 = 1.0 / 8.0;           // convert(Float64, .) of the same literals
@@ -368,7 +457,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     RCW_TRY(hipMalloc(&h->d_pos, B * 2 * h->real_size));
     RCW_TRY(hipMalloc(&h->d_dir, B * sizeof(int32_t)));
     RCW_TRY(hipMalloc(&h->d_goal, B * sizeof(int2)));
-    RCW_TRY(hipMalloc(&h->d_reward, B * sizeof(float)));
+    h->reward_size = (cfg->reward_type == RCW_REWARD_FLOAT64 || cfg->reward_type == RCW_REWARD_INT64) ? 8 : 4;
+    RCW_TRY(hipMalloc(&h->d_reward, B * h->reward_size));
     RCW_TRY(hipMalloc(&h->d_done, B));
     RCW_TRY(hipMalloc(&h->d_episode, B * sizeof(uint32_t)));
     RCW_TRY(hipMalloc(&h->d_tile_map, B * (size_t)h->nchunks * sizeof(uint64_t)));
@@ -402,6 +492,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.radius_sq = cfg->player_radius_wu * cfg->player_radius_wu;        // radius * radius CD:18
     d.inc = cfg->position_increment_wu;
     d.goal_reward = cfg->goal_reward;
+    d.goal_reward64 = cfg->goal_reward_f64;
+    d.reward_type = cfg->reward_type;
     d.num = cfg->camera_height_tile_wu * (float)N;                      // SR:406 numerator
     d.two_fov = 2.0f * cfg->semi_field_of_view_wu;                      // 2 * fov
     d.real64 = h->real64 ? 1 : 0;
@@ -421,13 +513,22 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.agent_id_offset = cfg->agent_id_offset;
     d.seed = seed;
     d.pos = (float2*)h->d_pos; d.pos64 = (double2*)h->d_pos; d.dir = (int32_t*)h->d_dir; d.goal = (int2*)h->d_goal;
-    d.reward = (float*)h->d_reward; d.done = (uint8_t*)h->d_done; d.episode = (uint32_t*)h->d_episode;
+    d.reward = h->d_reward; d.done = (uint8_t*)h->d_done; d.episode = (uint32_t*)h->d_episode;
     d.tile_map = (uint32_t*)h->d_tile_map;
     d.dir_table = (const float2*)h->d_dir_table; d.ray_table = (const float*)h->d_ray_table;
     d.dir_table64 = (const double2*)h->d_dir_table; d.ray_table64 = (const double*)h->d_ray_table;
     d.obs = (uint32_t*)h->d_obs; d.col_h = (int32_t*)h->d_col_h; d.col_c = (uint8_t*)h->d_col_c;
     d.err = (int32_t*)h->d_err;
     d.top_view = (uint32_t*)h->d_top_view; d.pu = cfg->pu_per_tu;
+    // player_radius_pu = wu_to_pu(player_radius_wu, pu_per_tu) SR:469 = floor(Int, r * pu) + 1 in T (UT:6)
+    d.top_rp = h->real64 ? (int32_t)std::floor(cfg->player_radius_wu_f64 * (double)cfg->pu_per_tu) + 1
+                         : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
+    // the write-once kernel needs the image's bit plane in LDS (160 KiB per CU; leave room for a second workgroup
+    // only where that is possible); larger images take the in-place kernel
+    d.top_lds = cfg->render_top_view && rcw_top_view_lds_bytes(d) <= 150 * 1024 ? 1 : 0;
+    d.top_variant = 1;
+    if (const char* v = std::getenv("RCW_TOP_VARIANT")) d.top_variant = std::atoi(v);
+    if (const char* v = std::getenv("RCW_TOP_INPLACE")) { if (std::atoi(v)) d.top_lds = 0; }
     d.status = (int32_t*)h->d_status;
     d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;
     // fill kernel: one workgroup per CU (256 on an MI355X in SPX mode; a partitioned device reports fewer)
@@ -439,13 +540,22 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = std::getenv("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
     if (const char* v = std::getenv("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
 
+    if (cfg->render_top_view) {
+        hipError_t e = rcw_prepare_top_view(d);
+        if (e != hipSuccess) { free_all(h); delete h; return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e)); }
+    }
     if (rcw_step_lds_bytes(d) > 64 * 1024) {
         free_all(h); delete h;
         return fail(RCW_ERR_UNSUPPORTED, "tile map + column buffer need %zu B of LDS (> 64 KiB)", rcw_step_lds_bytes(d));
     }
 
-    if (h->real64) build_direction_table<double>(nd, h->dir_table64); else build_direction_table<float>(nd, h->dir_table);
-    rebuild_ray_table(h);
+    try {
+        if (h->real64) build_direction_table<double>(nd, h->dir_table64); else build_direction_table<float>(nd, h->dir_table);
+        rebuild_ray_table(h);
+    } catch (const std::bad_alloc&) {
+        free_all(h); delete h;
+        return fail(RCW_ERR_OUT_OF_MEMORY, "host allocation of the (direction, ray) table failed");
+    }
     rc = upload_tables(h);
     if (rc == RCW_OK) {
         hipError_t e = rcw_launch_init_tile_map(d, h->stream);
@@ -463,6 +573,8 @@ int rcw_destroy(rcw_handle* h)
     if (!h) return RCW_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr;
     free_all(h);
     delete h;
     return RCW_OK;
@@ -474,8 +586,12 @@ int set_direction_table_impl(rcw_handle* h, const T* directions_wu, std::vector<
 {
     if (!directions_wu) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL direction table");
     RCW_HIP(hipStreamSynchronize(h->stream));
-    table.assign(directions_wu, directions_wu + (size_t)2 * h->cfg.num_directions);
-    rebuild_ray_table(h);
+    try {
+        table.assign(directions_wu, directions_wu + (size_t)2 * h->cfg.num_directions);
+        rebuild_ray_table(h);
+    } catch (const std::bad_alloc&) {
+        return fail(RCW_ERR_OUT_OF_MEMORY, "host allocation of the (direction, ray) table failed");
+    }
     int rc = upload_tables(h); if (rc) return rc;
     RCW_HIP(launch_step(h, nullptr, nullptr));   // re-render
     return RCW_OK;
@@ -607,6 +723,28 @@ int rcw_step_device(rcw_handle* h, const uint8_t* actions_device)
     return RCW_OK;
 }
 
+int rcw_cast_rays(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(rcw_launch_cast(h->dev, nullptr, nullptr, h->stream));   // no action: rays + descriptors only
+    return RCW_OK;
+}
+
+int rcw_update_camera_view(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    RCW_HIP(rcw_launch_fill(h->dev, h->dev.col_h, h->dev.col_c, h->dev.obs, (long long)h->dev.B * h->dev.N, nullptr, h->stream));
+    return RCW_OK;
+}
+
+int rcw_update_top_view(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
+    RCW_HIP(rcw_launch_top_view(h->dev, nullptr, h->stream));
+    return RCW_OK;
+}
+
 int rcw_sync(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
@@ -662,7 +800,18 @@ int rcw_top_view_copy(rcw_handle* h, uint32_t* out_host, int32_t first, int32_t 
     return rc;
 }
 
-int rcw_reward(rcw_handle* h, float* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_reward, (size_t)h->B); }
+int rcw_reward(rcw_handle* h, float* out)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (h->cfg.reward_type != RCW_REWARD_FLOAT32)
+        return fail(RCW_ERR_UNSUPPORTED, "rcw_reward: the handle's reward type is not Float32; use rcw_reward_typed");
+    return copy_out(h, out, h->d_reward, (size_t)h->B);
+}
+int rcw_reward_typed(rcw_handle* h, void* out)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    return copy_out(h, static_cast<uint8_t*>(out), h->d_reward, (size_t)h->B * h->reward_size);
+}
 int rcw_done(rcw_handle* h, uint8_t* out) { int rc = check_handle(h); if (rc) return rc; return copy_out(h, out, h->d_done, (size_t)h->B); }
 int rcw_position(rcw_handle* h, float* out)
 {
@@ -720,21 +869,25 @@ int rays_impl(rcw_handle* h, int32_t first, int32_t count, int64_t* stop_ij, int
         return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
     const size_t n = (size_t)count * h->cfg.num_rays;
     RcwRayOut out{};
-    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-    auto cleanup = [&]() { for (void* b : bufs) if (b) (void)hipFree(b); };
-#define RCW_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(RCW_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    if (stop_ij) { RCW_TRY(hipMalloc(&bufs[0], 2 * n * sizeof(int64_t))); out.stop_ij = (int64_t*)bufs[0]; }
-    if (hit_dimension) { RCW_TRY(hipMalloc(&bufs[1], n * sizeof(int64_t))); out.hit_dim = (int64_t*)bufs[1]; }
-    if (distance_wu) { RCW_TRY(hipMalloc(&bufs[2], n * sizeof(T))); out.dist = bufs[2]; }
-    if (directions_wu) { RCW_TRY(hipMalloc(&bufs[3], 2 * n * sizeof(T))); out.dirs = bufs[3]; }
-    RCW_TRY(rcw_launch_rays(h->dev, first, count, out, h->stream));
-    RCW_TRY(hipStreamSynchronize(h->stream));
-    if (stop_ij) RCW_TRY(hipMemcpy(stop_ij, bufs[0], 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (hit_dimension) RCW_TRY(hipMemcpy(hit_dimension, bufs[1], n * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (distance_wu) RCW_TRY(hipMemcpy(distance_wu, bufs[2], n * sizeof(T), hipMemcpyDeviceToHost));
-    if (directions_wu) RCW_TRY(hipMemcpy(directions_wu, bufs[3], 2 * n * sizeof(T), hipMemcpyDeviceToHost));
-#undef RCW_TRY
-    cleanup();
+    // device scratch lives in the handle and only ever grows: no hipMalloc/hipFree per call
+    const size_t want[4] = {stop_ij ? 2 * n * sizeof(int64_t) : 0, hit_dimension ? n * sizeof(int64_t) : 0,
+                            distance_wu ? n * sizeof(T) : 0, directions_wu ? 2 * n * sizeof(T) : 0};
+    for (int k = 0; k < 4; ++k) {
+        if (want[k] <= h->rays_cap[k]) continue;
+        if (h->d_rays[k]) { RCW_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
+        RCW_HIP(hipMalloc(&h->d_rays[k], want[k]));
+        h->rays_cap[k] = want[k];
+    }
+    if (stop_ij) out.stop_ij = (int64_t*)h->d_rays[0];
+    if (hit_dimension) out.hit_dim = (int64_t*)h->d_rays[1];
+    if (distance_wu) out.dist = h->d_rays[2];
+    if (directions_wu) out.dirs = h->d_rays[3];
+    RCW_HIP(rcw_launch_rays(h->dev, first, count, out, h->stream));
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    if (stop_ij) RCW_HIP(hipMemcpy(stop_ij, h->d_rays[0], want[0], hipMemcpyDeviceToHost));
+    if (hit_dimension) RCW_HIP(hipMemcpy(hit_dimension, h->d_rays[1], want[1], hipMemcpyDeviceToHost));
+    if (distance_wu) RCW_HIP(hipMemcpy(distance_wu, h->d_rays[2], want[2], hipMemcpyDeviceToHost));
+    if (directions_wu) RCW_HIP(hipMemcpy(directions_wu, h->d_rays[3], want[3], hipMemcpyDeviceToHost));
     return RCW_OK;
 }
 }  // extern "C++"
@@ -787,6 +940,114 @@ int rcw_expand_columns(rcw_handle* h, const int32_t* height_line_pu_device, cons
     return RCW_OK;
 }
 
+// ---- the observation gather (RCCL over xGMI) --------------------------------------------------------------
+int rcw_comm_unique_id(void* out_id)
+{
+    if (!out_id) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = load_rccl(); if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == RCW_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    RCW_NCCL(g_rccl.GetUniqueId(&id));
+    std::memcpy(out_id, &id, sizeof id);
+    return RCW_OK;
+}
+
+int rcw_comm_init(rcw_handle* h, const void* unique_id, int32_t rank, int32_t world)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "bad rank %d / world %d", rank, world);
+    if (h->comm) return fail(RCW_ERR_INVALID_ARGUMENT, "the handle already has a communicator (rcw_comm_destroy first)");
+    rc = load_rccl(); if (rc) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCW_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+    h->comm = comm; h->comm_rank = rank; h->comm_world = world;
+    return RCW_OK;
+}
+
+int rcw_comm_destroy(rcw_handle* h)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!h->comm) return RCW_OK;
+    RCW_HIP(hipStreamSynchronize(h->stream));
+    RCW_NCCL(g_rccl.CommDestroy((ncclComm_t)h->comm));
+    h->comm = nullptr; h->comm_rank = 0; h->comm_world = 0;
+    return RCW_OK;
+}
+
+int rcw_comm_info(rcw_handle* h, int32_t* rank, int32_t* world)
+{
+    if (!h || !rank || !world) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *rank = h->comm_rank; *world = h->comm_world;
+    return RCW_OK;
+}
+
+int rcw_gather_columns(rcw_handle* h, int32_t* height_all, uint8_t* colour_all)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = need_comm(h, "rcw_gather_columns"); if (rc) return rc;
+    if (!height_all || !colour_all) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    const size_t n = (size_t)h->B * h->cfg.num_rays;
+    // one fused group: the two all-gathers progress together on the handle's stream, behind the step
+    RCW_NCCL(g_rccl.GroupStart());
+    ncclResult_t r1 = g_rccl.AllGather(h->d_col_h, height_all, n, ncclInt32, (ncclComm_t)h->comm, h->stream);
+    ncclResult_t r2 = g_rccl.AllGather(h->d_col_c, colour_all, n, ncclUint8, (ncclComm_t)h->comm, h->stream);
+    RCW_NCCL(g_rccl.GroupEnd());
+    RCW_NCCL(r1); RCW_NCCL(r2);
+    return RCW_OK;
+}
+
+int rcw_gather_observations(rcw_handle* h, int32_t mode, void* frames_all)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    rc = need_comm(h, "rcw_gather_observations"); if (rc) return rc;
+    if (!frames_all) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if ((uintptr_t)frames_all & 15u) return fail(RCW_ERR_INVALID_ARGUMENT, "frames must be 16-byte aligned");
+    const size_t N = (size_t)h->cfg.num_rays, Hc = (size_t)h->cfg.height_camera_view_pu;
+    if (mode == RCW_GATHER_FRAMES) {
+        RCW_NCCL(g_rccl.AllGather(h->dev.obs, frames_all, (size_t)h->B * N * Hc, ncclUint32, (ncclComm_t)h->comm, h->stream));
+        return RCW_OK;
+    }
+    if (mode != RCW_GATHER_COLUMNS) return fail(RCW_ERR_INVALID_ARGUMENT, "unknown gather mode %d", mode);
+    const size_t all = (size_t)h->B * h->comm_world;
+    if ((long long)all > 0x7fffffffll) return fail(RCW_ERR_UNSUPPORTED, "global batch too large");
+    if (!h->d_gather_h) {
+        RCW_HIP(hipMalloc(&h->d_gather_h, all * N * sizeof(int32_t)));
+        RCW_HIP(hipMalloc(&h->d_gather_c, all * N));
+    }
+    rc = rcw_gather_columns(h, (int32_t*)h->d_gather_h, (uint8_t*)h->d_gather_c); if (rc) return rc;
+    RCW_HIP(rcw_launch_expand(h->dev, (const int32_t*)h->d_gather_h, (const uint8_t*)h->d_gather_c, (int32_t)all,
+                              (uint32_t*)frames_all, h->stream));
+    return RCW_OK;
+}
+
+int rcw_device_malloc(rcw_handle* h, uint64_t bytes, void** device_ptr)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!device_ptr || bytes == 0) return fail(RCW_ERR_INVALID_ARGUMENT, "bad argument");
+    *device_ptr = nullptr;
+    RCW_HIP(hipMalloc(device_ptr, (size_t)bytes));
+    return RCW_OK;
+}
+int rcw_device_free(rcw_handle* h, void* device_ptr)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!device_ptr) return RCW_OK;
+    RCW_HIP(hipStreamSynchronize(h->stream));   // work enqueued on the handle may still use it
+    RCW_HIP(hipFree(device_ptr));
+    return RCW_OK;
+}
+int rcw_memcpy_to_host(rcw_handle* h, void* dst_host, const void* src_device, uint64_t bytes)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!dst_host || !src_device) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    rc = sync_and_check(h);
+    RCW_HIP(hipMemcpy(dst_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost));
+    return rc;
+}
+
 int rcw_ray_table(rcw_handle* h, float* out)
 {
     if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -837,7 +1098,7 @@ int rcw_profile(rcw_handle* h, int32_t enable)
     int rc = check_handle(h); if (rc) return rc;
     RCW_HIP(hipStreamSynchronize(h->stream));
     if (enable && h->prof_ev.empty()) {
-        h->prof_ev.resize(3 * kProfileSlots, nullptr);
+        h->prof_ev.resize(4 * kProfileSlots, nullptr);
         for (auto& ev : h->prof_ev) RCW_HIP(hipEventCreate(&ev));
     }
     h->profiling = enable != 0;
@@ -845,20 +1106,22 @@ int rcw_profile(rcw_handle* h, int32_t enable)
     return RCW_OK;
 }
 
-int rcw_profile_read(rcw_handle* h, float* cast_ms, float* fill_ms, int32_t* steps)
+int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* fill_ms, int32_t* steps)
 {
     int rc = check_handle(h); if (rc) return rc;
-    if (!cast_ms || !fill_ms || !steps) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!cast_ms || !top_view_ms || !fill_ms || !steps) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
     RCW_HIP(hipStreamSynchronize(h->stream));
-    double c = 0.0, f = 0.0;
+    double c = 0.0, t = 0.0, f = 0.0;
     for (int k = 0; k < h->prof_count; ++k) {
-        float a = 0.0f, b = 0.0f;
-        RCW_HIP(hipEventElapsedTime(&a, h->prof_ev[3 * k], h->prof_ev[3 * k + 1]));
-        RCW_HIP(hipEventElapsedTime(&b, h->prof_ev[3 * k + 1], h->prof_ev[3 * k + 2]));
-        c += a; f += b;
+        float a = 0.0f, b = 0.0f, d = 0.0f;
+        RCW_HIP(hipEventElapsedTime(&a, h->prof_ev[4 * k], h->prof_ev[4 * k + 1]));
+        RCW_HIP(hipEventElapsedTime(&b, h->prof_ev[4 * k + 1], h->prof_ev[4 * k + 2]));
+        RCW_HIP(hipEventElapsedTime(&d, h->prof_ev[4 * k + 2], h->prof_ev[4 * k + 3]));
+        c += a; t += b; f += d;
     }
     *steps = h->prof_count;
     *cast_ms = h->prof_count ? (float)(c / h->prof_count) : 0.0f;
+    *top_view_ms = h->prof_count && h->dev.top_view ? (float)(t / h->prof_count) : 0.0f;
     *fill_ms = h->prof_count ? (float)(f / h->prof_count) : 0.0f;
     return RCW_OK;
 }

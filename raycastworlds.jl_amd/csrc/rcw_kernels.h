@@ -16,7 +16,9 @@ struct RcwDev {
     int32_t real64;          // world-unit type T: 0 = Float32, 1 = Float64 (SR:259); the *64 members below
     float radius, radius_sq; // player_radius_wu, fl(r*r)            (CD:18)
     float inc;               // position_increment_wu                (UT:16-17)
-    float goal_reward;       // SR:86
+    float goal_reward;       // SR:82 one(R), R = Float32
+    double goal_reward64;    // one(R) for the other reward types (converted on store)
+    int32_t reward_type;     // RCW_REWARD_*: element type R of `reward` (SR:33, SR:266)
     float num;               // fl(camera_height_tile_wu * N)        (SR:406)
     float two_fov;           // fl(2 * semi_field_of_view_wu)        (SR:406)
     double radius64, radius_sq64, inc64, num64, two_fov64;   // the same five in Float64
@@ -36,7 +38,7 @@ struct RcwDev {
     double2* pos64;          // player_position_wu (T = Float64)
     int32_t* dir;            // player_direction_au
     int2* goal;              // goal_position (1-based i, j)
-    float* reward;
+    void* reward;            // R[B]
     uint8_t* done;
     uint32_t* episode;       // resets seen (keys the generator)
     uint32_t* tile_map;      // BitArray{3}(2,H,W).chunks viewed as 32-bit words, [B][nwords]
@@ -51,6 +53,10 @@ struct RcwDev {
     uint8_t* col_c;          // (N, B) colour id by image column
     uint32_t* top_view;      // optional env.top_view UInt32 (H*pu, W*pu, B)  SR:302
     int32_t pu;              // pu_per_tu
+    int32_t top_rp;          // player_radius_pu = wu_to_pu(player_radius_wu, pu)  SR:469 (host-computed in T)
+    int32_t top_lds;         // 1: the write-once LDS bit-plane kernel fits this image; 0: in-place fallback
+    int32_t top_variant;     // development switches of the top view kernel (bit 0: neighbour de-duplication,
+                             // bit 1: wave-interleaved ray mapping, bit 2: plain instead of non-temporal stores)
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
     int32_t* status;         // per-agent sticky status
 };
@@ -73,6 +79,10 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
                            long long total_cols, const uint8_t* mask_dev, hipStream_t s);
 // update_top_view!(env) SR:446-483 for every (unmasked) agent; needs p.top_view
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
+// LDS bytes of the write-once top view kernel for this geometry, and the one-off preparation (raises the
+// kernel's dynamic LDS limit when the bit planes need more than 64 KiB); sets nothing on the device.
+size_t rcw_top_view_lds_bytes(const RcwDev& p);
+hipError_t rcw_prepare_top_view(const RcwDev& p);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos /* float2* or double2* */,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);

@@ -53,7 +53,7 @@ __device__ __forceinline__ void set_goal_bit(uint32_t* tm, int H, int i, int j, 
 }
 
 // ---- the reference's world-unit type T (SingleRoom(; T = ...) SR:259), compiled in: every
-// Float32 operation of the path is the same operation in T.  R (reward) is always Float32. ----
+// Float32 operation of the path is the same operation in T.  R (the reward type) is independent: store_reward. ----
 template <typename T> struct Real;
 template <> struct Real<float> {
     typedef float2 vec2;
@@ -136,6 +136,17 @@ __device__ __forceinline__ Collide player_colliding(const uint8_t* tb, int H, in
     return c;
 }
 
+// ---- world.reward::R (SR:33): zero(R) or goal_reward = one(R), stored in the handle's R -----------
+__device__ __forceinline__ void store_reward(const RcwDev& p, int a, bool goal)
+{
+    switch (p.reward_type) {
+    case RCW_REWARD_FLOAT64: static_cast<double*>(p.reward)[a] = goal ? p.goal_reward64 : 0.0; break;
+    case RCW_REWARD_INT32:   static_cast<int32_t*>(p.reward)[a] = goal ? (int32_t)p.goal_reward64 : 0; break;
+    case RCW_REWARD_INT64:   static_cast<int64_t*>(p.reward)[a] = goal ? (int64_t)p.goal_reward64 : 0; break;
+    default:                 static_cast<float*>(p.reward)[a] = goal ? p.goal_reward : 0.0f; break;
+    }
+}
+
 // ---- reset!(world)  SR:110-137 with the counter-based generator -------------------------
 // tm_a / tm_b: the agent's tile map words in up to two places (LDS copy and HBM).
 template <typename T> struct Pose { T x, y; int d; };
@@ -170,7 +181,7 @@ __device__ __forceinline__ Pose<T> reset_agent(const RcwDev& p, int a, uint32_t*
     o.d = (int)rcw_below(rcw_draw(key, n++), (uint64_t)p.nd);                  // SR:128
     Real<T>::pos(p)[a] = Real<T>::make(o.x, o.y);                             // SR:126
     p.dir[a] = o.d;                                                           // SR:129
-    p.reward[a] = 0.0f;                                                       // SR:131
+    store_reward(p, a, false);                                                // SR:131
     p.done[a] = 0;                                                            // SR:132
     p.episode[a] = ep + 1;
     return o;
@@ -302,8 +313,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         x = s_pose[0]; y = s_pose[1];
         d_new = s_pose_d;
     } else if (act != 0) {
-        float reward = 0.0f;
-        int done = 0;
+        int done = 0;                                                       // reward = done ? goal_reward : zero(R)
         bool oob = false;
         if (act <= 2) {                                                     // SR:150
             const T ix = Real<T>::inc(p) * dv.x, iy = Real<T>::inc(p) * dv.y;
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
             const T ny = act == 1 ? pos.y + iy : pos.y - iy;
             const Collide c = player_colliding<T>(tb, p.H, p.W, nx, ny, Real<T>::radius_sq(p), p.oob_empty);   // SR:162-163
             if (c.wall == 2 || c.goal == 2) oob = true;                     // BoundsError: no mutation
-            else if (c.goal) { reward = p.goal_reward; done = 1; }          // SR:166-168
+            else if (c.goal) { done = 1; }                                  // SR:166-168
             else if (c.wall) { }                                            // SR:170-171
             else { x = nx; y = ny; }                                        // SR:174
         }
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
             } else {
                 Real<T>::pos(p)[a] = Real<T>::make(x, y);                   // SR:174
                 p.dir[a] = d_new;                                           // SR:185
-                p.reward[a] = reward; p.done[a] = (uint8_t)done;            // SR:175-176, SR:186-187
+                store_reward(p, a, done != 0); p.done[a] = (uint8_t)done;   // SR:167-176, SR:186-187
             }
         }
     }
@@ -445,7 +455,7 @@ __global__ void rcw_init_tile_map_kernel(const RcwDev p)
             }
     p.goal[a] = make_int2(2, 2);
     p.episode[a] = 0;
-    p.reward[a] = 0.0f;
+    store_reward(p, a, false);
     p.done[a] = 0;
     p.status[a] = 0;
 }
@@ -476,7 +486,7 @@ __global__ void rcw_set_state_kernel(const RcwDev p, const int2* __restrict__ go
     set_goal_bit(tm, p.H, g.x, g.y, true);        // SR:122
     Real<T>::pos(p)[a] = pos[a];                  // SR:126
     p.dir[a] = dir[a];                            // SR:129
-    p.reward[a] = 0.0f;                           // SR:131
+    store_reward(p, a, false);                    // SR:131
     p.done[a] = 0;                                // SR:132
 }
 
@@ -511,10 +521,13 @@ __global__ __launch_bounds__(kBlock) void rcw_rays_kernel(const RcwDev p, int fi
 
 // ---- update_top_view!(env)  SR:446-483 (+ draw_tile_map! SR:342-372) ----------------------------
 // The reference's debug view: tile squares with a grid, one line per ray, the player circle.  Not
-// an observation and off by default (cfg.render_top_view).  One workgroup per agent, three phases
-// separated by barriers (a later phase overwrites pixels of an earlier one, as in the reference).
-// The line and circle rasterisers are SimpleDraw 0.3's (un-vendored): Bresenham and the midpoint
-// circle are ASSUMED — parity unpinned.
+// an observation and off by default (cfg.render_top_view).  The line and circle rasterisers are
+// SimpleDraw 0.3's (un-vendored): Bresenham and the midpoint circle are ASSUMED — parity unpinned.
+//
+// Two kernels.  rcw_top_view_kernel (below) is the one that runs whenever the image's bit planes fit
+// in LDS: it writes every pixel exactly once.  rcw_top_view_inplace_kernel (this one) is the fallback
+// for larger images: three phases separated by barriers, later phases overwriting pixels of
+// earlier ones in HBM exactly as the reference does.
 __device__ __forceinline__ void put_pixel(uint32_t* img, int Ht, int Wt, int i, int j, uint32_t c)
 {
     if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) img[(size_t)(i - 1) + (size_t)Ht * (j - 1)] = c;
@@ -532,7 +545,7 @@ __device__ __forceinline__ uint32_t top_view_tile_pixel(const uint8_t* tb, int H
 }
 
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(kBlock) void rcw_top_view_inplace_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int a = blockIdx.x;
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
 
     // ---- the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed) ----
     if (tid == 0) {
-        const int rp = wu_to_pu<T>(Real<T>::radius(p), pu);                  // SR:469
+        const int rp = p.top_rp;                                             // SR:469
         int x = 0, y = rp, dd = 1 - rp;
         while (x <= y) {
             put_pixel(img, Ht, Wt, ip + x, jp + y, 0x00c0c0c0u); put_pixel(img, Ht, Wt, ip - x, jp + y, 0x00c0c0c0u);
@@ -629,6 +642,230 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
             x += 1;
             if (dd < 0) dd += 2 * x + 1;
             else { y -= 1; dd += 2 * (x - y) + 1; }
+        }
+    }
+}
+
+
+// ---- the write-once top view -----------------------------------------------------------------------
+// One workgroup per agent, every pixel of the (H·pu, W·pu) image stored exactly once:
+//   1. the agent's tile map is staged in LDS (a byte per tile) and two bit planes are cleared:
+//      `line` (one bit per pixel, bit index = the pixel's linear index (j-1)·Ht + (i-1)) and `circ`
+//      (the 2·rp+1 image columns around the player only);
+//   2. one lane per ray: cast (same DDA as the camera path), end point SR:476, then the line's
+//      pixels are OR-ed into `line` with LDS atomics.  All lines start at the player's pixel and
+//      neighbouring rays share most of their first pixels, so a lane whose left neighbour is on
+//      the same pixel at the same step skips its atomic (the neighbour, or its neighbour, sets it);
+//   3. lane 0 ORs the player circle into `circ`;
+//   4. one pass over the image, lanes along the contiguous axis (rows of a column), 16 bytes per
+//      lane: colour = circle > ray line > tile frame > tile fill — the reference's overwrite order
+//      (SR:362-367 fill then frame per tile, SR:473-477 lines, SR:480 circle) resolved per pixel.
+// Algorithmic bytes: 4·(H·pu)·(W·pu) per agent, the HBM write roofline bounds it like the camera fill.
+//
+// SD.Line (ASSUMED Bresenham, all octants, both end points, as in the in-place kernel above): with a = the longer and b = the shorter
+// extent, pixel k = 0..a of the line sits k steps along the major axis and floor((2·b·k + a) / (2·a))
+// steps along the minor axis — the closed form of the error recurrence `e2 = 2 err; if e2 >= dj ...;
+// if e2 <= di ...` (checked exhaustively against it on the CPU, tests/test_host_logic.py).  The loop
+// below carries the remainder of that division instead of the error term: 5 VALU instructions a pixel.
+struct TopLds {
+    uint8_t* tb;        // [H*W] tile bytes
+    uint32_t* line;     // [line_words]
+    uint32_t* circ;     // [circ_words]
+};
+__host__ __device__ __forceinline__ size_t top_line_words(const RcwDev& p)
+{
+    return (((size_t)p.H * p.pu * (size_t)p.W * p.pu + 31) / 32 + 3) & ~(size_t)3;     // multiple of 4 words
+}
+__host__ __device__ __forceinline__ size_t top_circ_words(const RcwDev& p)
+{
+    return (((size_t)(2 * p.top_rp + 1) * (size_t)p.H * p.pu + 31) / 32 + 3) & ~(size_t)3;
+}
+__host__ __device__ __forceinline__ size_t top_tile_bytes(const RcwDev& p) { return ((size_t)p.H * p.W + 15) & ~(size_t)15; }
+
+// n / d and n % d for 0 <= n < 2^23, 1 <= d <= 4096 without the integer-division sequence
+__device__ __forceinline__ int fast_div(int n, int d, float inv_d)
+{
+    int q = (int)((float)n * inv_d);
+    q -= (q * d > n) ? 1 : 0;
+    q += ((q + 1) * d <= n) ? 1 : 0;
+    return q;
+}
+
+// colour of pixel (ip0, jp0) (0-based) before lines and circle: draw_tile_map! SR:342-372
+__device__ __forceinline__ uint32_t tile_fill_colour(uint32_t bits)
+{
+    return (bits & 1u) ? 0x00FFFFFFu : ((bits & 2u) ? 0x00FF0000u : 0x00000000u);       // findfirst SR:355-360, colours SR:288
+}
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int a = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (mask != nullptr && mask[a] == 0) return;
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
+    const int line_words = (int)top_line_words(p), circ_words = (int)top_circ_words(p);
+    uint8_t* tb = reinterpret_cast<uint8_t*>(lds);
+    uint32_t* line = lds + top_tile_bytes(p) / 4;
+    uint32_t* circ = line + line_words;
+
+    // ---- 1. stage the tile map, clear the planes ----
+    stage_tile_bytes(tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kBlock);
+    {
+        u32x4* z = reinterpret_cast<u32x4*>(line);
+        const int nz = (line_words + circ_words) >> 2;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int k = tid; k < nz; k += kBlock) z[k] = zero;
+    }
+    const typename Real<T>::vec2 pos = Real<T>::pos(p)[a];
+    const int d = p.dir[a];
+    const int ip = wu_to_pu<T>(pos.x, pu), jp = wu_to_pu<T>(pos.y, pu);      // SR:468 (1-based)
+    __syncthreads();
+
+    // ---- 2. one line per ray from the player to the ray's stop point  SR:473-477 ----
+    const T* tab = Real<T>::ray_table(p) + (size_t)d * RCW_TABLE_ROWS * p.N;
+    const bool dedup = (p.top_variant & 1) != 0;
+    const bool interleave = (p.top_variant & 2) != 0 && (p.N % kBlock) == 0;
+    const bool start_inside = ip >= 1 && ip <= Ht && jp >= 1 && jp <= Wt;
+    for (int i0 = 0; i0 < p.N; i0 += kBlock) {
+        // ray of this lane: consecutive lanes take consecutive rays, or (interleaved) the four wavefronts
+        // take every fourth ray so that one wavefront's lines spread over the whole fan
+        const int i = interleave ? i0 + (tid & 63) * (kBlock / 64) + (tid >> 6) : i0 + tid;
+        int n = 0, acc = 0, a2 = 0, b2 = 0, addr = 0, step_maj = 0, step_both = 0;
+        bool checked = false;
+        int i2 = ip, j2 = jp;
+        if (i < p.N) {
+            const T dx = tab[i], dy = tab[p.N + i];
+            const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+                                                              tab[3 * p.N + i]);
+            const T dist = r.oob ? (T)0 : r.dist;
+            const T ox = dist * dx, oy = dist * dy;                          // ray_distance_wu * ray_direction_wu
+            const T ex = pos.x + ox, ey = pos.y + oy;
+            i2 = wu_to_pu<T>(ex, pu); j2 = wu_to_pu<T>(ey, pu);             // SR:476
+            const int di = abs(i2 - ip), dj = abs(j2 - jp);
+            const int si = ip < i2 ? 1 : -1, sj = jp < j2 ? Ht : -Ht;      // steps of the linear pixel index
+            const bool imaj = di >= dj;
+            const int la = imaj ? di : dj, lb = imaj ? dj : di;
+            n = la + 1;
+            a2 = 2 * la; b2 = 2 * lb; acc = la;
+            step_maj = imaj ? si : sj;
+            step_both = si + sj;
+            addr = (jp - 1) * Ht + (ip - 1);
+            // a line whose end points are both on the image stays on it; anything else takes the clipped walk
+            checked = !(start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt);
+            if (checked) n = 0;
+        }
+        // All lanes stay in the loop until the longest line of the wavefront is done (a lane past its own
+        // end offers -1 to its right neighbour), so the neighbour exchange below always reads a live lane.
+        for (int k = 0; __ballot(k < n) != 0ull; ++k) {
+            const int cur = k < n ? addr : -1;
+            bool draw = cur >= 0;
+            if (dedup) {
+                // left neighbour's pixel at this step; lane 0 has none
+                const int left = __builtin_amdgcn_update_dpp(-1, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                draw = draw && left != cur;
+            }
+            if (draw) __hip_atomic_fetch_or(line + (cur >> 5), 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            acc += b2;
+            const bool t = acc >= a2;
+            acc -= t ? a2 : 0;
+            addr += t ? step_both : step_maj;
+        }
+        if (__ballot(checked)) {
+            // clipped walk (SimpleDraw skips pixels off the image): the error-term loop as written
+            if (checked) {
+                int i1 = ip, j1 = jp;
+                const int di = abs(i2 - i1), dj = -abs(j2 - j1);
+                const int si = i1 < i2 ? 1 : -1, sj = j1 < j2 ? 1 : -1;
+                int err = di + dj;
+                for (long long guard = 0; guard <= (long long)di - dj; ++guard) {
+                    if (i1 >= 1 && i1 <= Ht && j1 >= 1 && j1 <= Wt) {
+                        const int q = (j1 - 1) * Ht + (i1 - 1);
+                        __hip_atomic_fetch_or(line + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (i1 == i2 && j1 == j2) break;
+                    const int e2 = 2 * err;
+                    if (e2 >= dj) { err += dj; i1 += si; }
+                    if (e2 <= di) { err += di; j1 += sj; }
+                }
+            }
+        }
+    }
+
+    // ---- 3. the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed) ----
+    const int jc0 = jp - rp;                                                 // first image column of the circle plane (1-based)
+    if (tid == 0) {
+        int x = 0, y = rp, dd = 1 - rp;
+        auto put = [&](int i, int j) {
+            if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) {
+                const int q = (j - jc0) * Ht + (i - 1);
+                circ[q >> 5] |= 1u << (q & 31);
+            }
+        };
+        while (x <= y) {
+            put(ip + x, jp + y); put(ip - x, jp + y); put(ip + x, jp - y); put(ip - x, jp - y);
+            put(ip + y, jp + x); put(ip - y, jp + x); put(ip + y, jp - x); put(ip - y, jp - x);
+            x += 1;
+            if (dd < 0) dd += 2 * x + 1;
+            else { y -= 1; dd += 2 * (x - y) + 1; }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. every pixel once ----
+    uint32_t* img = p.top_view + (size_t)a * Ht * Wt;
+    const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
+    const float inv_pu = 1.0f / (float)pu;
+    const bool plain = (p.top_variant & 4) != 0;
+    if ((Ht & 3) == 0) {
+        // lanes along the rows of a column, four pixels per lane (they never straddle a column)
+        const int vpc = Ht >> 2, total = vpc * Wt;
+        const int qstep = kBlock / vpc, rstep = kBlock - qstep * vpc;
+        int jp0 = tid / vpc, rem = tid - jp0 * vpc;                          // column, vector within the column
+        u32x4* out = reinterpret_cast<u32x4*>(img);
+        const int box = 2 * rp;
+        for (int v = tid; v < total; v += kBlock) {
+            const int ip0 = rem * 4;
+            const int tj = fast_div(jp0, pu, inv_pu), rj = jp0 - tj * pu;
+            const bool frame_col = rj == 0 || rj == pu - 1;                  // SR:366-367
+            uint32_t px[4];
+            const int ti0 = fast_div(ip0, pu, inv_pu);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int ti = ti0, ri = ip0 + e - ti0 * pu;
+                if (ri >= pu) { const int t2 = fast_div(ip0 + e, pu, inv_pu); ti = t2; ri = ip0 + e - t2 * pu; }
+                const uint32_t fill = tile_fill_colour(tb[ti + p.H * tj]);
+                px[e] = (frame_col || ri == 0 || ri == pu - 1) ? grid_c : fill;   // SR:364-365
+            }
+            const int lin = jp0 * Ht + ip0;
+            const uint32_t lb = (line[lin >> 5] >> (lin & 31)) & 15u;
+            uint32_t cb = 0u;
+            const int cj = jp0 + 1 - jc0;
+            if ((unsigned)cj <= (unsigned)box) { const int q = cj * Ht + ip0; cb = (circ[q >> 5] >> (q & 31)) & 15u; }
+            u32x4 o;
+            o.x = (cb & 1u) ? player_c : ((lb & 1u) ? ray_c : px[0]);
+            o.y = (cb & 2u) ? player_c : ((lb & 2u) ? ray_c : px[1]);
+            o.z = (cb & 4u) ? player_c : ((lb & 4u) ? ray_c : px[2]);
+            o.w = (cb & 8u) ? player_c : ((lb & 8u) ? ray_c : px[3]);
+            if (plain) out[v] = o; else __builtin_nontemporal_store(o, out + v);
+            jp0 += qstep; rem += rstep;
+            if (rem >= vpc) { rem -= vpc; jp0 += 1; }
+        }
+    } else {
+        const int total = Ht * Wt;
+        const int qstep = kBlock / Ht, rstep = kBlock - qstep * Ht;
+        int jp0 = tid / Ht, ip0 = tid - jp0 * Ht;
+        for (int v = tid; v < total; v += kBlock) {
+            const int tj = fast_div(jp0, pu, inv_pu), rj = jp0 - tj * pu;
+            const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
+            uint32_t c = (rj == 0 || rj == pu - 1 || ri == 0 || ri == pu - 1) ? grid_c : tile_fill_colour(tb[ti + p.H * tj]);
+            if ((line[v >> 5] >> (v & 31)) & 1u) c = ray_c;
+            const int cj = jp0 + 1 - jc0;
+            if ((unsigned)cj <= (unsigned)(2 * rp)) { const int q = cj * Ht + ip0; if ((circ[q >> 5] >> (q & 31)) & 1u) c = player_c; }
+            img[v] = c;
+            jp0 += qstep; ip0 += rstep;
+            if (ip0 >= Ht) { ip0 -= Ht; jp0 += 1; }
         }
     }
 }
@@ -686,10 +923,32 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
     return hipGetLastError();
 }
 
+size_t rcw_top_view_lds_bytes(const RcwDev& p)
+{
+    return top_tile_bytes(p) + 4 * (top_line_words(p) + top_circ_words(p));
+}
+
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
-    RCW_DISPATCH(rcw_top_view_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), p, mask_dev);
+    if (p.top_lds) RCW_DISPATCH(rcw_top_view_kernel, dim3(p.B), dim3(kBlock), rcw_top_view_lds_bytes(p), p, mask_dev);
+    else           RCW_DISPATCH(rcw_top_view_inplace_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), p, mask_dev);
     return hipGetLastError();
+}
+
+// Above 64 KiB of dynamic LDS a kernel has to be told so once (the CU has 160 KiB).
+hipError_t rcw_prepare_top_view(const RcwDev& p)
+{
+    const size_t need = rcw_top_view_lds_bytes(p);
+    if (!p.top_lds || need <= 64 * 1024) return hipSuccess;
+    hipError_t e = hipSuccess;
+#define RCW_TOP_ATTR(TT, A, B_)                                                                                         \
+    if (e == hipSuccess)                                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rcw_top_view_kernel<TT, A, B_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)
+    if (p.real64) { RCW_TOP_ATTR(double, false, false); RCW_TOP_ATTR(double, false, true); RCW_TOP_ATTR(double, true, false); RCW_TOP_ATTR(double, true, true); }
+    else          { RCW_TOP_ATTR(float, false, false); RCW_TOP_ATTR(float, false, true); RCW_TOP_ATTR(float, true, false); RCW_TOP_ATTR(float, true, true); }
+#undef RCW_TOP_ATTR
+    return e;
 }
 
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)

@@ -49,6 +49,7 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self._owner = owner   # keeps the handle alive
         self._sync = sync
+        self._sync_on_export = True
 
     @property
     def nbytes(self) -> int:
@@ -56,7 +57,12 @@ class DeviceArray:
 
     @property
     def __cuda_array_interface__(self):
-        self._sync()
+        # One host synchronisation when the alias is made (what a casual `torch.as_tensor(env.camera_view)`
+        # needs to read valid data).  After that the alias is NOT re-synchronised: torch work on a stream other
+        # than the engine's must `wait_stream(env.torch_stream())` (or share one stream via `env.set_stream`)
+        # before reading frames a later step writes — INTEGRATION.md "Streams".
+        if self._sync_on_export:
+            self._sync()
         return {
             "shape": self.shape,
             "typestr": self.dtype.str,
@@ -65,12 +71,16 @@ class DeviceArray:
             "strides": None,
         }
 
-    def torch(self):
-        """Zero-copy torch tensor on the handle's device (int32 view for uint32 data)."""
+    def torch(self, sync: bool = True):
+        """Zero-copy torch tensor on the handle's device.  `sync=False` skips the host synchronisation: for
+        callers that order their work on the engine's stream themselves (the observation gather does)."""
         import torch
 
-        t = torch.as_tensor(self, device=f"cuda:{self._owner.device}")
-        return t
+        self._sync_on_export = bool(sync)
+        try:
+            return torch.as_tensor(self, device=f"cuda:{self._owner.device}")
+        finally:
+            self._sync_on_export = True
 
     def numpy(self) -> np.ndarray:
         """Copy to host."""
@@ -117,12 +127,12 @@ class SingleRoomWorld:
         return self._env.cfg.semi_field_of_view_wu
 
     @property
-    def goal_reward(self) -> np.float32:
-        return np.float32(self._env.cfg.goal_reward)
+    def goal_reward(self):                             # SR:34-35, one(R) SR:82
+        return self._env.R(1)
 
     @property
-    def reward(self) -> np.ndarray:                    # SR:33
-        return self._get(self._env._lib.rcw_reward, np.float32, (self._env.batch,))
+    def reward(self) -> np.ndarray:                    # SR:33, in R
+        return self._get(self._env._lib.rcw_reward_typed, self._env.R, (self._env.batch,))
 
     @property
     def done(self) -> np.ndarray:                      # SR:35
@@ -190,8 +200,9 @@ class SingleRoom:
     """`SingleRoom(; kwargs...)` (SR:258-324) for `batch` independent agents on one MI355X.
 
     Keyword arguments and defaults are the reference's (SR:258-272). `T` is "Float32" (default)
-    or "Float64"; `R` is Float32; a caller-supplied Julia `rng` is replaced by `seed`, which
-    keys the device generator. `device` is the HIP device index.
+    or "Float64"; `R` (the reward type, SR:266) is "Float32" (default), "Float64", "Int32" or "Int64";
+    a caller-supplied Julia `rng` is replaced by `seed`, which keys the device generator. `device` is
+    the HIP device index.
     """
 
     def __init__(
@@ -224,9 +235,15 @@ class SingleRoom:
         f64_names = ("Float64", "float64", "<class 'numpy.float64'>", "<class 'float'>")
         if str(T) not in f32_names + f64_names:
             raise NotImplementedError(f"world-unit type T = {T!r}: only Float32 and Float64 are built")
-        if str(R) not in f32_names:
-            raise NotImplementedError("only R = Float32 rewards are built")
+        r_names = {**{n: (np.float32, _capi.RCW_REWARD_FLOAT32) for n in f32_names},
+                   **{n: (np.float64, _capi.RCW_REWARD_FLOAT64) for n in f64_names},
+                   **{n: (np.int32, _capi.RCW_REWARD_INT32) for n in ("Int32", "int32", "<class 'numpy.int32'>")},
+                   **{n: (np.int64, _capi.RCW_REWARD_INT64) for n in ("Int64", "Int", "int64", "<class 'numpy.int64'>",
+                                                                     "<class 'int'>")}}
+        if str(R) not in r_names:
+            raise NotImplementedError(f"reward type R = {R!r}: Float32, Float64, Int32 and Int64 are built")
         self.T = np.float64 if str(T) in f64_names else np.float32
+        self.R, reward_type = r_names[str(R)]
         self._lib = _capi.load()
         cfg = _capi.default_config()
         cfg.height_tile_map_tu = height_tile_map_tu
@@ -246,6 +263,9 @@ class SingleRoom:
         cfg.normalize_mode = normalize_mode
         cfg.out_of_bounds = out_of_bounds
         cfg.render_top_view = 1 if render_top_view else 0
+        cfg.reward_type = reward_type                 # R, with goal_reward = one(R) SR:82
+        cfg.goal_reward = 1.0
+        cfg.goal_reward_f64 = 1.0
         # convert(T, .) of the caller's values (SR:263-270): for T = Float64 the Float64 value itself
         cfg.world_unit_bits = 64 if self.T is np.float64 else 32
         cfg.player_radius_wu_f64 = float(player_radius_wu)
@@ -352,9 +372,11 @@ class SingleRoom:
         return (DeviceArray(hp.value, shape, np.int32, self, self._sync),
                 DeviceArray(cp.value, shape, np.uint8, self, self._sync))
 
-    def expand_columns(self, height_line_pu, colour_id):
+    def expand_columns(self, height_line_pu, colour_id, out=None):
         """Descriptors (CUDA tensors (n, N) int32 / uint8, e.g. gathered from other GPUs) ->
-        frames (n, N, H_cam) as a torch CUDA tensor, with this engine's colours (rcw_expand_columns)."""
+        frames (n, N, H_cam) as a torch CUDA tensor, with this engine's colours (rcw_expand_columns).
+        Stream-ordered on the engine's stream behind the producer of the descriptors (torch's current
+        stream); no host synchronisation.  Consumers on another stream wait for `env.torch_stream()`."""
         import torch
 
         n = int(height_line_pu.shape[0])
@@ -364,18 +386,32 @@ class SingleRoom:
             raise ValueError("descriptors must be int32 / uint8")
         h = height_line_pu.contiguous()
         c = colour_id.contiguous()
-        out = torch.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=torch.uint32,
-                          device=f"cuda:{self.device}")
-        torch.cuda.current_stream(self.device).synchronize()   # inputs may come from another stream
+        if out is None:
+            out = torch.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=torch.uint32,
+                              device=f"cuda:{self.device}")
+        self._order_behind_torch(h, c, out)
         _capi.check(self._lib.rcw_expand_columns(self._h, C.c_void_p(h.data_ptr()), C.c_void_p(c.data_ptr()), n,
                                                  C.c_void_p(out.data_ptr())))
-        self._sync()
         return out
+
+    def _order_behind_torch(self, *tensors):
+        """Make the engine's stream wait for torch's current stream (the producer of `tensors`) and tell
+        torch's caching allocator that the engine's stream uses them: without the record a tensor the caller
+        drops right after the call could be handed out again — and overwritten — before the engine has read it."""
+        import torch
+
+        producer = torch.cuda.current_stream(self.device)
+        if producer.cuda_stream == self.stream_ptr():
+            return
+        es = self.torch_stream()
+        es.wait_stream(producer)
+        for t in tensors:
+            t.record_stream(es)
 
     def reward_device(self) -> DeviceArray:
         p = C.c_void_p()
         _capi.check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
-        return DeviceArray(p.value, (self.batch,), np.float32, self, self._sync)
+        return DeviceArray(p.value, (self.batch,), self.R, self, self._sync)
 
     def done_device(self) -> DeviceArray:
         p = C.c_void_p()
@@ -434,10 +470,10 @@ class SingleRoom:
         _capi.check(self._lib.rcw_profile(self._h, 1 if enable else 0))
 
     def profile_read(self):
-        """(mean cast kernel ms, mean fill kernel ms, steps recorded)."""
-        c, f, n = C.c_float(), C.c_float(), C.c_int32()
-        _capi.check(self._lib.rcw_profile_read(self._h, C.byref(c), C.byref(f), C.byref(n)))
-        return float(c.value), float(f.value), int(n.value)
+        """(mean cast kernel ms, mean top view kernel ms (0 without it), mean fill kernel ms, steps recorded)."""
+        c, t, f, n = C.c_float(), C.c_float(), C.c_float(), C.c_int32()
+        _capi.check(self._lib.rcw_profile_read(self._h, C.byref(c), C.byref(t), C.byref(f), C.byref(n)))
+        return float(c.value), float(t.value), float(f.value), int(n.value)
 
     def timer_start(self):
         _capi.check(self._lib.rcw_timer_start(self._h))
@@ -503,10 +539,9 @@ def act_(env: SingleRoom, action) -> None:
             if action.dtype != torch.uint8 or action.numel() != env.batch or not action.is_contiguous():
                 raise ValueError("device actions must be a contiguous uint8 tensor of length batch")
             # The actions were produced on torch's current stream; unless the engine runs on that very
-            # stream, make the engine's stream wait for them (an event record + wait, no host sync).
-            producer = torch.cuda.current_stream(action.device)
-            if producer.cuda_stream != env.stream_ptr():
-                env.torch_stream().wait_stream(producer)
+            # stream, make the engine's stream wait for them (an event record + wait, no host sync) and
+            # keep the caching allocator from recycling the tensor before the cast kernel has read it.
+            env._order_behind_torch(action)
             _capi.check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
             return None
     a = host_actions(env.batch, action)
@@ -515,20 +550,22 @@ def act_(env: SingleRoom, action) -> None:
 
 
 def cast_rays_(env: SingleRoom, first: int = 0, count: Optional[int] = None):
-    """`RCW.cast_rays!(world)` SR:195-231: returns the ray buffers for agents [first, first+count)."""
+    """`RCW.cast_rays!(world)` SR:195-231: recasts every agent's rays from the current state (rcw_cast_rays:
+    the compact column descriptors are refreshed, no pixel is written) and returns the ray buffers
+    (stop tile, hit dimension, distance, direction) of agents [first, first+count)."""
+    _capi.check(env._lib.rcw_cast_rays(env._h))
     return env.world.rays(first, count)
 
 
 def update_camera_view_(env: SingleRoom) -> None:
-    """`RCW.update_camera_view!(env)` SR:374-444.  The engine renders as part of every
-    reset/act/set_state, so the view is always current; this only waits for the GPU."""
-    env.sync()
+    """`RCW.update_camera_view!(env)` SR:374-444: refills `camera_view` from the stored ray results without
+    casting, as the reference's does (rcw_update_camera_view: the fill kernel alone)."""
+    _capi.check(env._lib.rcw_update_camera_view(env._h))
 
 
 def update_top_view_(env: SingleRoom) -> None:
-    """`RCW.update_top_view!(env)` SR:446-483: rendered with every reset/act/set_state when the env
-    was built with render_top_view=True; this only waits for the GPU."""
-    env.sync()
+    """`RCW.update_top_view!(env)` SR:446-483 (env built with render_top_view=True): redraws `top_view`."""
+    _capi.check(env._lib.rcw_update_top_view(env._h))
 
 
 def get_action_names(env: SingleRoom):

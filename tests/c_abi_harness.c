@@ -66,6 +66,29 @@ int main(int argc, char** argv)
     CHECK(rcw_device_name(h, name, sizeof name));
     printf("device=%s steps=%d terminal_events=%d checksum=%016llx pos0=%.9g,%.9g dir0=%d\n", name, STEPS, finished,
            (unsigned long long)sum, pos[0], pos[1], dir[0]);
+    /* the observation gather through the ABI alone (RCCL inside the library), world of one rank:
+     * what julia/BatchedSingleRoom.jl's gather_observations does */
+    {
+        unsigned char uid[RCW_UNIQUE_ID_BYTES];
+        int32_t rank = -1, world = -1;
+        void* all = NULL;
+        uint32_t* back = (uint32_t*)malloc(npix * sizeof(uint32_t));
+        CHECK(rcw_comm_unique_id(uid));
+        CHECK(rcw_comm_init(h, uid, 0, 1));
+        CHECK(rcw_comm_info(h, &rank, &world));
+        if (rank != 0 || world != 1) { fprintf(stderr, "rcw_comm_info: %d/%d\n", rank, world); return 1; }
+        CHECK(rcw_device_malloc(h, npix * sizeof(uint32_t), &all));
+        for (int mode = RCW_GATHER_COLUMNS; mode <= RCW_GATHER_FRAMES; ++mode) {
+            memset(back, 0, npix * sizeof(uint32_t));
+            CHECK(rcw_gather_observations(h, mode, all));
+            CHECK(rcw_memcpy_to_host(h, back, all, npix * sizeof(uint32_t)));
+            if (memcmp(back, frames, npix * sizeof(uint32_t)) != 0) { fprintf(stderr, "gather mode %d differs from camera_view\n", mode); return 1; }
+        }
+        CHECK(rcw_device_free(h, all));
+        CHECK(rcw_comm_destroy(h));
+        free(back);
+        printf("gather=ok\n");
+    }
     free(frames);
     CHECK(rcw_destroy(h));
     return 0;

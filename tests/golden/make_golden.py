@@ -22,8 +22,10 @@ from oracle import oracle as O  # noqa: E402
 CASES = {
     # name: (config overrides, agents, steps, seed)
     "cfg1_8x8_n64": (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64), 4, 200, 11),
+    "cfg2_8x8_n256": (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256), 4, 80, 15),
     "default_8x16_n512": (dict(), 2, 60, 12),
     "cfg3_16x16_n512": (dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=512), 2, 40, 13),
+    "cfg4_16x16_n256": (dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=256), 4, 60, 16),
     "cfg5_32x32_n1024": (dict(height_tile_map_tu=32, width_tile_map_tu=32, num_rays=1024), 2, 24, 14),
 }
 
@@ -61,5 +63,6 @@ def make(name):
 
 
 if __name__ == "__main__":
-    for n in CASES:
+    # `make_golden.py name...` rewrites only those cases; without arguments, all of them
+    for n in (sys.argv[1:] or CASES):
         make(n)

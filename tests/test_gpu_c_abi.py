@@ -46,3 +46,5 @@ def test_plain_c_caller(oracle, tmp_path):
     assert m.group(2) == f"{h:016x}"
     assert np.float32(m.group(3)) == orc.position[0, 0] and np.float32(m.group(4)) == orc.position[0, 1]
     assert int(m.group(5)) == orc.direction[0]
+    # rcw_comm_init / rcw_gather_observations (both modes) with a world of one rank, RCCL called by the library
+    assert "gather=ok" in res.stdout, res.stdout

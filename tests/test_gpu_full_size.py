@@ -1,4 +1,5 @@
-"""Parity at BASELINE.json's FULL sizes (cfg-2 4096 x 256, cfg-3 16384 x 512, cfg-5 8192 x 1024),
+"""Parity at BASELINE.json's FULL sizes (cfg-2 4096 x 256, cfg-3 16384 x 512, cfg-4's per-GPU shard 8192 x 256 of
+the 65536-agent batch, cfg-5 8192 x 1024),
 where stepping the rendering oracle would take minutes:
 
 * per-agent state and per-column descriptors (height_line_pu, colour id) of EVERY agent against
@@ -12,7 +13,7 @@ where stepping the rendering oracle would take minutes:
 import numpy as np
 import pytest
 
-from helpers import CFG1, CFG2, CFG3, CFG5
+from helpers import CFG1, CFG2, CFG3, CFG4, CFG5
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -39,8 +40,8 @@ def check_frames_against_descriptors(env, chunk=512):
         assert torch.equal(got, want), f"frames of agents {a0}..{a0 + chunk} differ from their descriptors"
 
 
-@pytest.mark.parametrize("cfg,batch,steps", [(CFG2, 4096, 24), (CFG3, 16384, 6), (CFG5, 8192, 4)],
-                         ids=["cfg2_4096x256", "cfg3_16384x512", "cfg5_8192x1024"])
+@pytest.mark.parametrize("cfg,batch,steps", [(CFG2, 4096, 24), (CFG3, 16384, 6), (CFG4, 8192, 6), (CFG5, 8192, 4)],
+                         ids=["cfg2_4096x256", "cfg3_16384x512", "cfg4_shard_8192x256", "cfg5_8192x1024"])
 def test_full_size_parity(rcw, oracle, cfg, batch, steps):
     env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=2024, out_of_bounds=1, **cfg)
     orc = oracle.OracleBatch(batch, seed=2024, render=False, out_of_bounds=1, **cfg)

@@ -438,3 +438,138 @@ def test_device_actions_are_ordered_behind_their_producer(rcw, oracle):
         orc.step(actions.cpu().numpy())
     assert_state_equal(env, orc, frames=False, where="ordered behind the producer")
     env.close()
+
+
+def test_reward_types(rcw, oracle):
+    """R of SingleRoom(; R = ...) SR:266: world.reward / goal_reward = one(R) (SR:81-82) in Float64, Int32 and
+    Int64 as well as the default Float32 — element type, values and the device alias."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(8)
+    for name, dt, rt in (("Float32", np.float32, 0), ("Float64", np.float64, 1), ("Int32", np.int32, 2),
+                         ("Int64", np.int64, 3)):
+        env = rcw.SingleRoomModule.SingleRoom(batch=512, seed=41, R=name, auto_reset=True, out_of_bounds=1, **CFG1)
+        orc = oracle.OracleBatch(512, seed=41, reward_type=rt, auto_reset=1, out_of_bounds=1, **CFG1)
+        assert env.world.goal_reward == dt(1) and type(env.world.goal_reward) is dt
+        total = 0
+        for s in range(300):
+            a = rng.integers(1, 5, 512).astype(np.uint8)
+            rcw.act_(env, a)
+            orc.step(a)
+            r = env.world.reward
+            assert r.dtype == dt and orc.reward.dtype == dt
+            np.testing.assert_array_equal(r, orc.reward, err_msg=f"R = {name}, step {s}")
+            # test/runtests.jl:30-34: non-zero exactly on terminal steps, and then exactly one(R)
+            np.testing.assert_array_equal(r != 0, env.world.done)
+            assert set(np.unique(r).tolist()) <= {0, 1}
+            total += int((r != 0).sum())
+        assert total > 0, "no agent reached the goal in 300 steps"
+        alias = env.reward_device().torch()
+        assert alias.dtype == {np.float32: torch.float32, np.float64: torch.float64, np.int32: torch.int32,
+                               np.int64: torch.int64}[dt]
+        np.testing.assert_array_equal(alias.cpu().numpy(), env.world.reward)
+        assert_state_equal(env, orc, frames=False, where=f"R = {name}")
+        if rt != 0:                                            # the Float32 getter refuses the other types, loudly
+            import ctypes as C
+            from raycastworlds_jl_amd import _capi
+            buf = np.zeros(512, np.float32)
+            assert env._lib.rcw_reward(env._h, buf.ctypes.data_as(C.c_void_p)) == _capi.RCW_ERR_UNSUPPORTED
+        env.close()
+    with pytest.raises(NotImplementedError):
+        rcw.SingleRoomModule.SingleRoom(batch=2, R="Float16", **CFG1)
+
+
+def test_frame_dump_of_engine_frames(rcw, oracle, tmp_path):
+    """f4 (headless stand-in for play! / copy_image_to_frame_buffer! utils.jl:64-73): the PPM written from an
+    ENGINE frame equals, byte for byte, the PPM written from the oracle's frame of the same state."""
+    env, orc = _make(rcw, oracle, 6, seed=77, **CFG2)
+    rng = np.random.default_rng(5)
+    for s in range(25):
+        a = rng.integers(1, 5, 6).astype(np.uint8)
+        rcw.act_(env, a)
+        orc.step(a)
+    for agent in range(6):
+        pe, po = tmp_path / f"engine_{agent}.ppm", tmp_path / f"oracle_{agent}.ppm"
+        rcw.save_agent_ppm(env, agent, str(pe))
+        rcw.save_ppm(orc.camera_view[agent], str(po))
+        data = pe.read_bytes()
+        assert data == po.read_bytes()
+        assert data.startswith(b"P6\n256 256\n255\n") and len(data) == 15 + 256 * 256 * 3
+        # the blit's transpose: image row r, column k  <-  camera_view[k][r]  (utils.jl:68-70)
+        rgb = np.frombuffer(data[15:], dtype=np.uint8).reshape(256, 256, 3)
+        frame = env.camera_view_host(agent, 1)[0]
+        for (r, k) in ((0, 0), (128, 17), (255, 255), (40, 200)):
+            px = int(frame[k, r])
+            assert tuple(rgb[r, k]) == ((px >> 16) & 255, (px >> 8) & 255, px & 255)
+    env.close()
+
+
+def test_device_actions_may_be_dropped_right_after_act(rcw, oracle):
+    """The engine runs on its own stream; a temporary action tensor handed to act_ and dropped at once must
+    not be recycled by torch's caching allocator before the cast kernel has read it (record_stream in act_).
+    No host synchronisation anywhere in the loop; each step allocates same-sized tensors that would reuse
+    the freed block immediately."""
+    torch = pytest.importorskip("torch")
+    B = 4096
+    env, orc = _make(rcw, oracle, B, seed=29, out_of_bounds=1, **CFG1)
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    all_actions = torch.randint(1, 5, (40, B), dtype=torch.uint8, device="cuda", generator=g)
+    host = all_actions.cpu().numpy()
+    big = torch.randn(2048, 2048, device="cuda")
+    torch.cuda.synchronize()
+    for s in range(40):
+        big = big @ big * 1e-3                       # keeps torch's stream busy so it runs BEHIND the host
+        rcw.act_(env, all_actions[s].clone())        # a temporary: freed as soon as act_ returns
+        junk = torch.full((B,), 7, dtype=torch.uint8, device="cuda")   # same size: takes the freed block if allowed to
+        del junk
+    for s in range(40):
+        orc.step(host[s])
+    env.sync()
+    assert (env.world.status == 0).all(), "an agent saw a corrupted (invalid) action"
+    assert_state_equal(env, orc, frames=False, where="temporaries dropped right after act_")
+    env.close()
+
+
+def test_render_entry_points(rcw, oracle):
+    """cast_rays! / update_camera_view! / update_top_view! as separate calls (RayCastWorlds.jl:9-14):
+    update_camera_view! refills the frames from the stored ray results without casting, as the reference's does."""
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 8, seed=13, render_top_view=1, **CFG1)
+    rng = np.random.default_rng(2)
+    for s in range(10):
+        a = rng.integers(1, 5, 8).astype(np.uint8)
+        rcw.act_(env, a); orc.step(a)
+    want, want_top = env.camera_view_host().copy(), env.top_view_host().copy()
+    cam, top = env.camera_view.torch(), env.top_view.torch()
+    cam.view(torch.int32).zero_(); top.view(torch.int32).zero_()
+    torch.cuda.synchronize()
+    assert not env.camera_view_host().any()
+    rcw.update_camera_view_(env)
+    np.testing.assert_array_equal(env.camera_view_host(), want)
+    assert not env.top_view_host().any()                         # update_camera_view! leaves the top view alone
+    rcw.update_top_view_(env)
+    np.testing.assert_array_equal(env.top_view_host(), want_top)
+    np.testing.assert_array_equal(want_top, orc.top_view)
+    stop, dim, dist, dirs = rcw.cast_rays_(env)
+    np.testing.assert_array_equal(stop, orc.ray_stop)
+    np.testing.assert_array_equal(dist.view(np.uint32), orc.ray_dist.view(np.uint32))
+    assert_state_equal(env, orc, where="after the separate render calls")
+    env.close()
+
+
+def test_top_view_in_place_fallback(rcw, oracle):
+    """Images whose bit plane does not fit in LDS (here 1600 x 1280 px) take the in-place kernel; a 1024 x 1024
+    image is the largest write-once case (128 KiB of LDS, raised limit)."""
+    rng = np.random.default_rng(17)
+    for kw, batch in ((dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), 3),
+                      (dict(pu_per_tu=32, **CFG5), 3)):
+        env, orc = _make(rcw, oracle, batch, seed=3, render_top_view=1, **kw)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
+        for s in range(6):
+            a = rng.integers(1, 5, batch).astype(np.uint8)
+            rcw.act_(env, a); orc.step(a)
+        try:
+            env.sync()
+        except IndexError:
+            env.clear_error(); orc.clear_status()
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after steps {kw}")
+        env.close()

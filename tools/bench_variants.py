@@ -26,6 +26,6 @@ for name, kw in (("Float32", {}), ("Float64", dict(T="Float64")), ("Float32 + to
         RCW.act_(env, a[s])
     env.sync()
     dt = (time.perf_counter() - t0) / 100
-    c, f, n = env.profile_read()
+    c, _t, f, n = env.profile_read()
     print(f"{name:32s} {dt * 1e6:8.1f} us/step  cast(+top view) {c * 1e3:7.1f} us  fill {f * 1e3:7.1f} us  {B / dt / 1e6:6.2f} M env-steps/s")
     env.close()
