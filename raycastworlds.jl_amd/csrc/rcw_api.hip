@@ -523,11 +523,19 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // player_radius_pu = wu_to_pu(player_radius_wu, pu_per_tu) SR:469 = floor(Int, r * pu) + 1 in T (UT:6)
     d.top_rp = h->real64 ? (int32_t)std::floor(cfg->player_radius_wu_f64 * (double)cfg->pu_per_tu) + 1
                          : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
-    // the write-once kernel needs the image's bit plane in LDS (160 KiB per CU; leave room for a second workgroup
-    // only where that is possible); larger images take the in-place kernel
-    d.top_lds = cfg->render_top_view && rcw_top_view_lds_bytes(d) <= 150 * 1024 ? 1 : 0;
-    d.top_variant = 1;
-    if (const char* v = std::getenv("RCW_TOP_VARIANT")) d.top_variant = std::atoi(v);
+    // the write-once kernel keeps two agents' bit planes in LDS (160 KiB per CU); larger images take the in-place kernel
+    // (1: two buffers, drawing overlapped with storing; 2: one buffer, no overlap; 0: in-place kernel)
+    d.top_lds = 1;
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 2;
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;
+    if (!cfg->render_top_view) d.top_lds = 0;
+    {   // persistent grid: as many 8-wavefront workgroups per CU as waves (32) and LDS allow
+        const size_t lds = rcw_top_view_lds_bytes(d);
+        int per_cu = lds ? (int)((160 * 1024) / lds) : 4;
+        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        d.top_grid = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    }
+    if (const char* v = std::getenv("RCW_TOP_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_grid = g; }
     if (const char* v = std::getenv("RCW_TOP_INPLACE")) { if (std::atoi(v)) d.top_lds = 0; }
     d.status = (int32_t*)h->d_status;
     d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;

@@ -54,9 +54,8 @@ struct RcwDev {
     uint32_t* top_view;      // optional env.top_view UInt32 (H*pu, W*pu, B)  SR:302
     int32_t pu;              // pu_per_tu
     int32_t top_rp;          // player_radius_pu = wu_to_pu(player_radius_wu, pu)  SR:469 (host-computed in T)
-    int32_t top_lds;         // 1: the write-once LDS bit-plane kernel fits this image; 0: in-place fallback
-    int32_t top_variant;     // development switches of the top view kernel (bit 0: neighbour de-duplication,
-                             // bit 1: wave-interleaved ray mapping, bit 2: plain instead of non-temporal stores)
+    int32_t top_lds;         // write-once LDS bit-plane kernel: 1 two buffers (overlapped), 2 one buffer; 0: in-place fallback
+    int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
     int32_t* status;         // per-agent sticky status
 };

@@ -648,30 +648,31 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_inplace_kernel(const RcwD
 
 
 // ---- the write-once top view -----------------------------------------------------------------------
-// One workgroup per agent, every pixel of the (H·pu, W·pu) image stored exactly once:
-//   1. the agent's tile map is staged in LDS (a byte per tile) and two bit planes are cleared:
-//      `line` (one bit per pixel, bit index = the pixel's linear index (j-1)·Ht + (i-1)) and `circ`
-//      (the 2·rp+1 image columns around the player only);
-//   2. one lane per ray: cast (same DDA as the camera path), end point SR:476, then the line's
-//      pixels are OR-ed into `line` with LDS atomics.  All lines start at the player's pixel and
-//      neighbouring rays share most of their first pixels, so a lane whose left neighbour is on
-//      the same pixel at the same step skips its atomic (the neighbour, or its neighbour, sets it);
-//   3. lane 0 ORs the player circle into `circ`;
-//   4. one pass over the image, lanes along the contiguous axis (rows of a column), 16 bytes per
-//      lane: colour = circle > ray line > tile frame > tile fill — the reference's overwrite order
-//      (SR:362-367 fill then frame per tile, SR:473-477 lines, SR:480 circle) resolved per pixel.
+// Every pixel of the (H·pu, W·pu) image is stored exactly once, and drawing overlaps with storing:
+// a workgroup has 8 wavefronts in two groups of four and walks through its agents in slots.  In slot s
+//   * the DRAW group rasterises agent s into one of two LDS buffers: the agent's tile map (a byte per
+//     tile), a `line` bit plane (one bit per pixel, bit index = the pixel's linear index (j-1)·Ht + (i-1))
+//     and a `circ` plane for the 2·rp+1 image columns around the player.  One lane per ray: cast (the same
+//     DDA as the camera path), end point SR:476, then the line's pixels are OR-ed into `line` with LDS
+//     atomics.  All lines start at the player's pixel and neighbouring rays share most of their first
+//     pixels, so a lane whose left neighbour is on the same pixel at the same step leaves the bit to it;
+//   * the STORE group streams agent s-1 out of the other buffer: lanes along the contiguous axis (rows of a
+//     column), 16 bytes per lane, colour = circle > ray line > tile frame > tile fill — the reference's
+//     overwrite order (SR:362-367 fill then frame per tile, SR:473-477 lines, SR:480 circle) per pixel.
+// Two workgroup barriers per slot (LDS only: stores stay in flight across them).  The drawing is VALU/LDS
+// work, the storing is HBM work; run one after the other they add up (measured: 239 µs at 4096 x 256² px),
+// overlapped the kernel approaches the store time.  The grid is persistent (4 workgroups per CU).
 // Algorithmic bytes: 4·(H·pu)·(W·pu) per agent, the HBM write roofline bounds it like the camera fill.
 //
-// SD.Line (ASSUMED Bresenham, all octants, both end points, as in the in-place kernel above): with a = the longer and b = the shorter
-// extent, pixel k = 0..a of the line sits k steps along the major axis and floor((2·b·k + a) / (2·a))
-// steps along the minor axis — the closed form of the error recurrence `e2 = 2 err; if e2 >= dj ...;
-// if e2 <= di ...` (checked exhaustively against it on the CPU, tests/test_host_logic.py).  The loop
-// below carries the remainder of that division instead of the error term: 5 VALU instructions a pixel.
-struct TopLds {
-    uint8_t* tb;        // [H*W] tile bytes
-    uint32_t* line;     // [line_words]
-    uint32_t* circ;     // [circ_words]
-};
+// SD.Line (ASSUMED Bresenham, all octants, both end points, as in the in-place kernel above): with a = the
+// longer and b = the shorter extent, pixel k = 0..a of the line sits k steps along the major axis and
+// floor((2·b·k + a) / (2·a)) steps along the minor axis — the closed form of the error recurrence
+// `e2 = 2 err; if e2 >= dj ...; if e2 <= di ...` (checked exhaustively against it on the CPU,
+// tests/test_host_logic.py).  The loop carries the remainder of that division instead of the error term.
+constexpr int kTopBlock = 512;          // 4 draw + 4 store wavefronts
+constexpr int kTopGroup = 256;
+constexpr int kTopDummyWords = 64;      // where lanes with nothing to draw aim their (harmless) atomic
+
 __host__ __device__ __forceinline__ size_t top_line_words(const RcwDev& p)
 {
     return (((size_t)p.H * p.pu * (size_t)p.W * p.pu + 31) / 32 + 3) & ~(size_t)3;     // multiple of 4 words
@@ -680,9 +681,35 @@ __host__ __device__ __forceinline__ size_t top_circ_words(const RcwDev& p)
 {
     return (((size_t)(2 * p.top_rp + 1) * (size_t)p.H * p.pu + 31) / 32 + 3) & ~(size_t)3;
 }
-__host__ __device__ __forceinline__ size_t top_tile_bytes(const RcwDev& p) { return ((size_t)p.H * p.W + 15) & ~(size_t)15; }
+__host__ __device__ __forceinline__ size_t top_tile_words(const RcwDev& p) { return (((size_t)p.H * p.W + 15) & ~(size_t)15) / 4; }
+// one buffer: [header 4 words | tile bytes | line | circ | dummy]
+__host__ __device__ __forceinline__ size_t top_buf_words(const RcwDev& p)
+{
+    return 4 + top_tile_words(p) + top_line_words(p) + top_circ_words(p) + kTopDummyWords;
+}
 
-// n / d and n % d for 0 <= n < 2^23, 1 <= d <= 4096 without the integer-division sequence
+struct TopBuf {
+    int* hdr;           // [0] ip, [1] jp: the player's pixel (1-based)  SR:468
+    uint8_t* tb;        // [H*W] tile bytes
+    uint32_t* line;
+    uint32_t* circ;
+    uint32_t* dummy;
+};
+__device__ __forceinline__ TopBuf top_buf(const RcwDev& p, uint32_t* base)
+{
+    TopBuf b;
+    b.hdr = reinterpret_cast<int*>(base);
+    b.tb = reinterpret_cast<uint8_t*>(base + 4);
+    b.line = base + 4 + top_tile_words(p);
+    b.circ = b.line + top_line_words(p);
+    b.dummy = b.circ + top_circ_words(p);
+    return b;
+}
+
+// LDS-only workgroup barrier: waits for this wavefront's LDS operations, not for its global stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// n / d for 0 <= n < 2^23, 1 <= d <= 4096 without the integer-division sequence
 __device__ __forceinline__ int fast_div(int n, int d, float inv_d)
 {
     int q = (int)((float)n * inv_d);
@@ -691,53 +718,41 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d)
     return q;
 }
 
-// colour of pixel (ip0, jp0) (0-based) before lines and circle: draw_tile_map! SR:342-372
 __device__ __forceinline__ uint32_t tile_fill_colour(uint32_t bits)
 {
     return (bits & 1u) ? 0x00FFFFFFu : ((bits & 2u) ? 0x00FF0000u : 0x00000000u);       // findfirst SR:355-360, colours SR:288
 }
 
-template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+// draw group, first half of a slot: stage the agent's tile map, clear the planes
+__device__ __forceinline__ void top_prepare(const RcwDev& p, int a, const TopBuf& b, int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int a = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (mask != nullptr && mask[a] == 0) return;
-    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
-    const int line_words = (int)top_line_words(p), circ_words = (int)top_circ_words(p);
-    uint8_t* tb = reinterpret_cast<uint8_t*>(lds);
-    uint32_t* line = lds + top_tile_bytes(p) / 4;
-    uint32_t* circ = line + line_words;
+    stage_tile_bytes(b.tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kTopGroup);
+    u32x4* z = reinterpret_cast<u32x4*>(b.line);
+    const int nz = (int)((top_line_words(p) + top_circ_words(p)) >> 2);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int k = tid; k < nz; k += kTopGroup) z[k] = zero;
+}
 
-    // ---- 1. stage the tile map, clear the planes ----
-    stage_tile_bytes(tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kBlock);
-    {
-        u32x4* z = reinterpret_cast<u32x4*>(line);
-        const int nz = (line_words + circ_words) >> 2;
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        for (int k = tid; k < nz; k += kBlock) z[k] = zero;
-    }
+// draw group, second half: one line per ray from the player to the ray's stop point (SR:473-477) and the player
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b, int tid)
+{
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     const typename Real<T>::vec2 pos = Real<T>::pos(p)[a];
     const int d = p.dir[a];
     const int ip = wu_to_pu<T>(pos.x, pu), jp = wu_to_pu<T>(pos.y, pu);      // SR:468 (1-based)
-    __syncthreads();
-
-    // ---- 2. one line per ray from the player to the ray's stop point  SR:473-477 ----
+    if (tid == 0) { b.hdr[0] = ip; b.hdr[1] = jp; }
     const T* tab = Real<T>::ray_table(p) + (size_t)d * RCW_TABLE_ROWS * p.N;
-    const bool dedup = (p.top_variant & 1) != 0;
-    const bool interleave = (p.top_variant & 2) != 0 && (p.N % kBlock) == 0;
     const bool start_inside = ip >= 1 && ip <= Ht && jp >= 1 && jp <= Wt;
-    for (int i0 = 0; i0 < p.N; i0 += kBlock) {
-        // ray of this lane: consecutive lanes take consecutive rays, or (interleaved) the four wavefronts
-        // take every fourth ray so that one wavefront's lines spread over the whole fan
-        const int i = interleave ? i0 + (tid & 63) * (kBlock / 64) + (tid >> 6) : i0 + tid;
+    uint32_t* const dummy = b.dummy + (tid & 63);
+    for (int i0 = 0; i0 < p.N; i0 += kTopGroup) {
+        const int i = i0 + tid;
         int n = 0, acc = 0, a2 = 0, b2 = 0, addr = 0, step_maj = 0, step_both = 0;
         bool checked = false;
         int i2 = ip, j2 = jp;
         if (i < p.N) {
             const T dx = tab[i], dy = tab[p.N + i];
-            const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
+            const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(b.tb, p.H, p.W, pos.x, pos.y, dx, dy, tab[2 * p.N + i],
                                                               tab[3 * p.N + i]);
             const T dist = r.oob ? (T)0 : r.dist;
             const T ox = dist * dx, oy = dist * dy;                          // ray_distance_wu * ray_direction_wu
@@ -756,17 +771,15 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
             checked = !(start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt);
             if (checked) n = 0;
         }
-        // All lanes stay in the loop until the longest line of the wavefront is done (a lane past its own
-        // end offers -1 to its right neighbour), so the neighbour exchange below always reads a live lane.
+        // All lanes stay in the loop until the longest line of the wavefront is done (a lane past its own end
+        // offers -1 to its right neighbour), so the neighbour exchange always reads a live lane.  No branch in
+        // the body: a lane with nothing to draw ORs its bit into a private dummy word.
         for (int k = 0; __ballot(k < n) != 0ull; ++k) {
             const int cur = k < n ? addr : -1;
-            bool draw = cur >= 0;
-            if (dedup) {
-                // left neighbour's pixel at this step; lane 0 has none
-                const int left = __builtin_amdgcn_update_dpp(-1, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                draw = draw && left != cur;
-            }
-            if (draw) __hip_atomic_fetch_or(line + (cur >> 5), 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int left = __builtin_amdgcn_update_dpp(-1, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0: -1
+            const bool draw = cur >= 0 && left != cur;
+            uint32_t* const w = draw ? b.line + (cur >> 5) : dummy;
+            __hip_atomic_fetch_or(w, 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             acc += b2;
             const bool t = acc >= a2;
             acc -= t ? a2 : 0;
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
                 for (long long guard = 0; guard <= (long long)di - dj; ++guard) {
                     if (i1 >= 1 && i1 <= Ht && j1 >= 1 && j1 <= Wt) {
                         const int q = (j1 - 1) * Ht + (i1 - 1);
-                        __hip_atomic_fetch_or(line + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(b.line + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     if (i1 == i2 && j1 == j2) break;
                     const int e2 = 2 * err;
@@ -792,15 +805,15 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
             }
         }
     }
-
-    // ---- 3. the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed) ----
-    const int jc0 = jp - rp;                                                 // first image column of the circle plane (1-based)
-    if (tid == 0) {
+    // the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed).  Its plane is
+    // separate from the lines', so one lane of the LAST wavefront draws it while the others finish their lines.
+    if (tid == kTopGroup - 1) {
+        const int jc0 = jp - rp;                                             // first image column of the circle plane (1-based)
         int x = 0, y = rp, dd = 1 - rp;
         auto put = [&](int i, int j) {
             if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) {
                 const int q = (j - jc0) * Ht + (i - 1);
-                circ[q >> 5] |= 1u << (q & 31);
+                b.circ[q >> 5] |= 1u << (q & 31);
             }
         };
         while (x <= y) {
@@ -811,62 +824,137 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_kernel(const RcwDev p, co
             else { y -= 1; dd += 2 * (x - y) + 1; }
         }
     }
-    __syncthreads();
+}
 
-    // ---- 4. every pixel once ----
+// store group: half `part` (0 / 1) of agent a's image, every pixel once
+__device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& b, int tid, int part)
+{
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     uint32_t* img = p.top_view + (size_t)a * Ht * Wt;
     const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
     const float inv_pu = 1.0f / (float)pu;
-    const bool plain = (p.top_variant & 4) != 0;
-    if ((Ht & 3) == 0) {
-        // lanes along the rows of a column, four pixels per lane (they never straddle a column)
-        const int vpc = Ht >> 2, total = vpc * Wt;
-        const int qstep = kBlock / vpc, rstep = kBlock - qstep * vpc;
-        int jp0 = tid / vpc, rem = tid - jp0 * vpc;                          // column, vector within the column
+    const int jc0 = b.hdr[1] - rp;
+    const int box = 2 * rp;
+    const int half = Wt >> 1;                                               // part 0: columns [0, half), part 1: the rest
+    const int c_lo = part == 0 ? 0 : half, c_hi = part == 0 ? half : Wt;
+    if ((Ht & 255) == 0 && (pu & 3) == 0) {
+        // One wavefront per image column (256 rows per pass), lanes along the contiguous rows, four pixels a lane:
+        // they never straddle a tile, and everything that depends on the column only is wave-uniform.
+        const int wave = tid >> 6, lane = tid & 63;
         u32x4* out = reinterpret_cast<u32x4*>(img);
-        const int box = 2 * rp;
-        for (int v = tid; v < total; v += kBlock) {
+        const int vpc = Ht >> 2;
+        for (int jp0 = c_lo + wave; jp0 < c_hi; jp0 += kTopGroup / 64) {
+            const int tj = jp0 / pu, rj = jp0 - tj * pu;                    // wave-uniform: scalar unit
+            const bool frame_col = rj == 0 || rj == pu - 1;                  // SR:366-367
+            const int cj = jp0 + 1 - jc0;
+            const bool in_box = (unsigned)cj <= (unsigned)box;
+            for (int ip0 = lane * 4; ip0 < Ht; ip0 += 256) {
+                const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
+                const uint32_t fill = tile_fill_colour(b.tb[ti + p.H * tj]);
+                const uint32_t inner = frame_col ? grid_c : fill;
+                const int lin = jp0 * Ht + ip0;
+                const uint32_t lb = b.line[lin >> 5] >> (lin & 31);
+                uint32_t cb = 0u;
+                if (in_box) { const int q = cj * Ht + ip0; cb = b.circ[q >> 5] >> (q & 31); }
+                const uint32_t ov = lb | cb;                                 // any overlay on these four pixels?
+                u32x4 o;
+                o.x = ri == 0 ? grid_c : inner;                              // SR:364: first row of the tile
+                o.y = inner;
+                o.z = inner;
+                o.w = ri + 3 == pu - 1 ? grid_c : inner;                     // SR:365: last row of the tile
+                if (ov & 15u) {
+                    o.x = (cb & 1u) ? player_c : ((lb & 1u) ? ray_c : o.x);
+                    o.y = (cb & 2u) ? player_c : ((lb & 2u) ? ray_c : o.y);
+                    o.z = (cb & 4u) ? player_c : ((lb & 4u) ? ray_c : o.z);
+                    o.w = (cb & 8u) ? player_c : ((lb & 8u) ? ray_c : o.w);
+                }
+                __builtin_nontemporal_store(o, out + (size_t)jp0 * vpc + (ip0 >> 2));
+            }
+        }
+    } else if ((Ht & 3) == 0) {
+        // any pu, Ht % 4 == 0: four pixels per lane (they never straddle a column), tiles looked up per pixel
+        const int vpc = Ht >> 2, v_lo = c_lo * vpc, v_hi = c_hi * vpc;
+        const int qstep = kTopGroup / vpc, rstep = kTopGroup - qstep * vpc;
+        int jp0 = (v_lo + tid) / vpc, rem = (v_lo + tid) - jp0 * vpc;        // column, vector within the column
+        u32x4* out = reinterpret_cast<u32x4*>(img);
+        for (int v = v_lo + tid; v < v_hi; v += kTopGroup) {
             const int ip0 = rem * 4;
             const int tj = fast_div(jp0, pu, inv_pu), rj = jp0 - tj * pu;
-            const bool frame_col = rj == 0 || rj == pu - 1;                  // SR:366-367
+            const bool frame_col = rj == 0 || rj == pu - 1;
             uint32_t px[4];
-            const int ti0 = fast_div(ip0, pu, inv_pu);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int ti = ti0, ri = ip0 + e - ti0 * pu;
-                if (ri >= pu) { const int t2 = fast_div(ip0 + e, pu, inv_pu); ti = t2; ri = ip0 + e - t2 * pu; }
-                const uint32_t fill = tile_fill_colour(tb[ti + p.H * tj]);
-                px[e] = (frame_col || ri == 0 || ri == pu - 1) ? grid_c : fill;   // SR:364-365
+                const int ti = fast_div(ip0 + e, pu, inv_pu), ri = ip0 + e - ti * pu;
+                px[e] = (frame_col || ri == 0 || ri == pu - 1) ? grid_c : tile_fill_colour(b.tb[ti + p.H * tj]);
             }
             const int lin = jp0 * Ht + ip0;
-            const uint32_t lb = (line[lin >> 5] >> (lin & 31)) & 15u;
+            const uint32_t lb = b.line[lin >> 5] >> (lin & 31);
             uint32_t cb = 0u;
             const int cj = jp0 + 1 - jc0;
-            if ((unsigned)cj <= (unsigned)box) { const int q = cj * Ht + ip0; cb = (circ[q >> 5] >> (q & 31)) & 15u; }
+            if ((unsigned)cj <= (unsigned)box) { const int q = cj * Ht + ip0; cb = b.circ[q >> 5] >> (q & 31); }
             u32x4 o;
             o.x = (cb & 1u) ? player_c : ((lb & 1u) ? ray_c : px[0]);
             o.y = (cb & 2u) ? player_c : ((lb & 2u) ? ray_c : px[1]);
             o.z = (cb & 4u) ? player_c : ((lb & 4u) ? ray_c : px[2]);
             o.w = (cb & 8u) ? player_c : ((lb & 8u) ? ray_c : px[3]);
-            if (plain) out[v] = o; else __builtin_nontemporal_store(o, out + v);
+            __builtin_nontemporal_store(o, out + v);
             jp0 += qstep; rem += rstep;
             if (rem >= vpc) { rem -= vpc; jp0 += 1; }
         }
     } else {
-        const int total = Ht * Wt;
-        const int qstep = kBlock / Ht, rstep = kBlock - qstep * Ht;
-        int jp0 = tid / Ht, ip0 = tid - jp0 * Ht;
-        for (int v = tid; v < total; v += kBlock) {
+        const int v_lo = c_lo * Ht, v_hi = c_hi * Ht;
+        const int qstep = kTopGroup / Ht, rstep = kTopGroup - qstep * Ht;
+        int jp0 = (v_lo + tid) / Ht, ip0 = (v_lo + tid) - jp0 * Ht;
+        for (int v = v_lo + tid; v < v_hi; v += kTopGroup) {
             const int tj = fast_div(jp0, pu, inv_pu), rj = jp0 - tj * pu;
             const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
-            uint32_t c = (rj == 0 || rj == pu - 1 || ri == 0 || ri == pu - 1) ? grid_c : tile_fill_colour(tb[ti + p.H * tj]);
-            if ((line[v >> 5] >> (v & 31)) & 1u) c = ray_c;
+            uint32_t c = (rj == 0 || rj == pu - 1 || ri == 0 || ri == pu - 1) ? grid_c : tile_fill_colour(b.tb[ti + p.H * tj]);
+            if ((b.line[v >> 5] >> (v & 31)) & 1u) c = ray_c;
             const int cj = jp0 + 1 - jc0;
-            if ((unsigned)cj <= (unsigned)(2 * rp)) { const int q = cj * Ht + ip0; if ((circ[q >> 5] >> (q & 31)) & 1u) c = player_c; }
+            if ((unsigned)cj <= (unsigned)box) { const int q = cj * Ht + ip0; if ((b.circ[q >> 5] >> (q & 31)) & 1u) c = player_c; }
             img[v] = c;
             jp0 += qstep; ip0 += rstep;
             if (ip0 >= Ht) { ip0 -= Ht; jp0 += 1; }
         }
+    }
+}
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kTopBlock, 8) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int role = threadIdx.x >> 8;        // 0: draw group, 1: store group (wave-uniform)
+    const int tid = threadIdx.x & (kTopGroup - 1);
+    const int G = gridDim.x;
+    const int n = (p.B - (int)blockIdx.x + G - 1) / G;                      // agents of this workgroup: blockIdx.x + k*G
+    const size_t bw = top_buf_words(p);
+    // The schedule, one workgroup barrier per step.  Overlapped (two LDS buffers): step h = 2 s + part; the draw
+    // group prepares (part 0) then draws (part 1) agent s while the store group stores the two halves of agent
+    // s - 1.  Serial (image too large for two buffers): step h = 3 s + phase; prepare, draw, then both groups
+    // store one half each.
+    const bool serial = p.top_lds == 2;
+    const int steps = serial ? 3 * n : 2 * (n + 1);
+    enum { NONE, PREPARE, DRAW, STORE };
+    for (int h = 0; h < steps; ++h) {
+        int what = NONE, agent = 0, buf = 0, part = 0;
+        if (serial) {
+            const int s = h / 3, ph = h - 3 * s;
+            agent = s;
+            if (ph == 2) { what = STORE; part = role; }
+            else if (role == 0) what = ph == 0 ? PREPARE : DRAW;
+        } else {
+            const int s = h >> 1;
+            part = h & 1;
+            if (role == 0) { agent = s; buf = s & 1; what = s < n ? (part == 0 ? PREPARE : DRAW) : NONE; }
+            else           { agent = s - 1; buf = (s + 1) & 1; what = s >= 1 ? STORE : NONE; }
+        }
+        const int a = blockIdx.x + agent * G;
+        if (what != NONE && mask != nullptr && mask[a] == 0) what = NONE;
+        const TopBuf b = top_buf(p, lds + (size_t)buf * bw);
+        if (what == PREPARE) top_prepare(p, a, b, tid);
+        else if (what == DRAW) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
+        else if (what == STORE) top_store(p, a, b, tid, part);
+        lds_barrier();
     }
 }
 
@@ -925,13 +1013,17 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
 
 size_t rcw_top_view_lds_bytes(const RcwDev& p)
 {
-    return top_tile_bytes(p) + 4 * (top_line_words(p) + top_circ_words(p));
+    return (p.top_lds == 2 ? 1 : 2) * 4 * top_buf_words(p);      // two buffers: one being drawn, one being stored
 }
 
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
-    if (p.top_lds) RCW_DISPATCH(rcw_top_view_kernel, dim3(p.B), dim3(kBlock), rcw_top_view_lds_bytes(p), p, mask_dev);
-    else           RCW_DISPATCH(rcw_top_view_inplace_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), p, mask_dev);
+    if (p.top_lds) {
+        const int grid = p.B < p.top_grid ? p.B : p.top_grid;              // persistent: 4 workgroups of 8 wavefronts per CU
+        RCW_DISPATCH(rcw_top_view_kernel, dim3(grid), dim3(kTopBlock), rcw_top_view_lds_bytes(p), p, mask_dev);
+    } else {
+        RCW_DISPATCH(rcw_top_view_inplace_kernel, dim3(p.B), dim3(kBlock), rcw_step_lds_bytes(p), p, mask_dev);
+    }
     return hipGetLastError();
 }
 

@@ -205,10 +205,12 @@ class ShardedSingleRoom:
         dev = f"cuda:{env.device}"
         gh = torch.empty((self.global_batch, env.cfg.num_rays), dtype=torch.int32, device=dev)
         gc = torch.empty((self.global_batch, env.cfg.num_rays), dtype=torch.uint8, device=dev)
-        env._order_behind_torch(gh, gc)
+        cross = env._order_behind_torch()
         from . import _capi
 
         _capi.check(env._lib.rcw_gather_columns(env._h, C.c_void_p(gh.data_ptr()), C.c_void_p(gc.data_ptr())))
+        if cross:
+            env._release_after_use(gh, gc)
         return gh, gc
 
     def gather_observations_abi(self, mode: str = "columns", out=None):
@@ -226,8 +228,10 @@ class ShardedSingleRoom:
         if out is None:
             out = torch.empty((self.global_batch, env.cfg.num_rays, env.cfg.height_camera_view_pu), dtype=torch.uint32,
                               device=f"cuda:{env.device}")
-        env._order_behind_torch(out)
+        cross = env._order_behind_torch()
         _capi.check(env._lib.rcw_gather_observations(env._h, modes[mode], C.c_void_p(out.data_ptr())))
+        if cross:
+            env._release_after_use(out)
         return out
 
     def close(self):

@@ -292,8 +292,9 @@ class SingleRoom:
     # ---- lifetime -------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.rcw_destroy(self._h)
+            self._lib.rcw_destroy(self._h)       # waits for the handle's stream
             self._h = C.c_void_p()
+            self.__dict__.pop("_held", None)
 
     def __del__(self):
         try:
@@ -389,24 +390,42 @@ class SingleRoom:
         if out is None:
             out = torch.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=torch.uint32,
                               device=f"cuda:{self.device}")
-        self._order_behind_torch(h, c, out)
+        cross = self._order_behind_torch()
         _capi.check(self._lib.rcw_expand_columns(self._h, C.c_void_p(h.data_ptr()), C.c_void_p(c.data_ptr()), n,
                                                  C.c_void_p(out.data_ptr())))
+        if cross:
+            self._release_after_use(h, c, out)
         return out
 
     def _order_behind_torch(self, *tensors):
-        """Make the engine's stream wait for torch's current stream (the producer of `tensors`) and tell
-        torch's caching allocator that the engine's stream uses them: without the record a tensor the caller
-        drops right after the call could be handed out again — and overwritten — before the engine has read it."""
+        """Make the engine's stream wait for torch's current stream (the producer of `tensors`), and keep the
+        tensors alive until the engine has consumed them: `_release_after_use` must follow the launch.  Without
+        the hold, a tensor the caller drops right after the call goes back to torch's caching allocator, which
+        may hand the block out again — to be overwritten on torch's stream — before the engine has read it."""
         import torch
 
         producer = torch.cuda.current_stream(self.device)
         if producer.cuda_stream == self.stream_ptr():
-            return
-        es = self.torch_stream()
-        es.wait_stream(producer)
-        for t in tensors:
-            t.record_stream(es)
+            return False
+        self.torch_stream().wait_stream(producer)
+        return True
+
+    def _release_after_use(self, *tensors):
+        """Hold references to `tensors` until an event recorded NOW on the engine's stream has completed (a
+        ring of 16 reusable events; the host only ever blocks when it runs 16 launches ahead of the GPU)."""
+        import torch
+
+        ring = self.__dict__.setdefault("_held", [])
+        free = self.__dict__.setdefault("_free_events", [])
+        while ring and ring[0][0].query():
+            free.append(ring.pop(0)[0])
+        if len(ring) >= 16:
+            ev, _ = ring.pop(0)
+            ev.synchronize()
+            free.append(ev)
+        ev = free.pop() if free else torch.cuda.Event()
+        ev.record(self.torch_stream())
+        ring.append((ev, tensors))
 
     def reward_device(self) -> DeviceArray:
         p = C.c_void_p()
@@ -540,9 +559,11 @@ def act_(env: SingleRoom, action) -> None:
                 raise ValueError("device actions must be a contiguous uint8 tensor of length batch")
             # The actions were produced on torch's current stream; unless the engine runs on that very
             # stream, make the engine's stream wait for them (an event record + wait, no host sync) and
-            # keep the caching allocator from recycling the tensor before the cast kernel has read it.
-            env._order_behind_torch(action)
+            # hold the tensor until the cast kernel has read it (the caller may drop a temporary at once).
+            cross = env._order_behind_torch()
             _capi.check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
+            if cross:
+                env._release_after_use(action)
             return None
     a = host_actions(env.batch, action)
     _capi.check(env._lib.rcw_step(env._h, _as_ptr(a)))

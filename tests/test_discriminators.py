@@ -1,0 +1,81 @@
+"""The parity-pin kit's discriminating inputs (tests/golden/discriminators.json, made by
+tests/golden/make_discriminators.py): poses where the two readings of an UNPINNED switch (include/rcw.h:
+dda_tie_break, dda_distance, normalize_mode) give DIFFERENT reference-visible outputs.
+
+CPU: the oracle reproduces both recorded candidates and they really differ.
+GPU (`-m gpu`): the HIP path reproduces both candidates under the matching switch, through the C ABI.
+
+Which candidate the real RayCastWorlds.jl produces is what `julia julia/make_reference_fixtures.jl` settles
+(tests/test_reference_fixtures.py reads its output); until someone runs it, parity is unpinned.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "discriminators.json")) as f:
+    DISC = json.load(f)
+CASES = DISC["cases"]
+
+
+def _check(case, value, got):
+    want = case["candidates"][str(value)]
+    for key, arr in got.items():
+        np.testing.assert_array_equal(np.asarray(arr).reshape(-1), np.asarray(want[key]),
+                                      err_msg=f"{case['name']} {case['switch']}={value}: {key}")
+
+
+def test_kit_covers_every_switch():
+    assert {c["switch"] for c in CASES} == set(DISC["switches"]) == {"dda_tie_break", "dda_distance", "normalize_mode"}
+    for sw in DISC["switches"]:
+        frame = [c for c in CASES if c["switch"] == sw and ({"height_line_pu", "colour_id"} & set(c["differs_in"]))]
+        assert frame, f"no case where {sw} changes camera_view"
+    for c in CASES:
+        a, b = c["candidates"]["0"], c["candidates"]["1"]
+        assert sorted(k for k in a if a[k] != b[k]) == sorted(c["differs_in"]) and c["differs_in"]
+    # the inputs the Julia script reads are the same cases
+    tsv = [l.split("\t") for l in open(os.path.join(os.path.dirname(HERE), "julia", "discriminator_cases.tsv"))
+           if not l.startswith("#")]
+    assert [r[0] for r in tsv] == [c["name"] for c in CASES]
+    for r, c in zip(tsv, CASES):
+        x, y = np.array([int(r[6]), int(r[7])], dtype=np.uint32).view(np.float32)
+        assert [float(x), float(y)] == c["position"] and int(r[8]) == c["direction"]
+        assert [int(r[4]), int(r[5])] == c["goal"] and int(r[3]) == c["config"]["num_rays"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_reproduces_both_candidates(oracle, case):
+    for value in (0, 1):
+        orc = oracle.OracleBatch(1, out_of_bounds=1, **case["config"], **{case["switch"]: value})
+        orc.set_state([case["goal"]], [case["position"]], [case["direction"]])
+        _check(case, value, dict(
+            ray_hit_dimension=orc.ray_dim[0], ray_stop_position_tu=orc.ray_stop[0],
+            ray_distance_bits=orc.ray_dist[0].view(np.uint32), ray_direction_bits=orc.ray_dirs[0].view(np.uint32),
+            height_line_pu=orc.col_height[0], colour_id=orc.col_colour[0]))
+        orc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_hip_reproduces_both_candidates(rcw, case):
+    """No oracle in the loop: the engine against the committed candidates, frames included (a frame is a pure
+    function of its column descriptors, SR:431-440 — rebuilt here from the recorded candidate)."""
+    colours = np.array([0x808080, 0xC0C0C0, 0x800000, 0xC00000], dtype=np.uint32)
+    for value in (0, 1):
+        env = rcw.SingleRoomModule.SingleRoom(batch=1, out_of_bounds=1, **case["config"], **{case["switch"]: value})
+        env.set_state([case["goal"]], [case["position"]], [case["direction"]])
+        stop, dim, dist, dirs = env.world.rays()
+        h, c = env.columns()
+        _check(case, value, dict(
+            ray_hit_dimension=dim[0], ray_stop_position_tu=stop[0], ray_distance_bits=dist[0].view(np.uint32),
+            ray_direction_bits=dirs[0].view(np.uint32), height_line_pu=h[0], colour_id=c[0]))
+        want = case["candidates"][str(value)]
+        hh = np.asarray(want["height_line_pu"], dtype=np.int64)
+        pad = np.where(hh >= 255, 0, (256 - hh) // 2)[:, None]
+        rows = np.arange(256)[None, :]
+        frame = np.where(rows < pad, 0xFFFFFF, np.where(rows < 256 - pad, colours[np.asarray(want["colour_id"])][:, None],
+                                                        0x404040)).astype(np.uint32)
+        np.testing.assert_array_equal(env.camera_view_host()[0], frame, err_msg=f"{case['name']} camera_view")
+        env.close()

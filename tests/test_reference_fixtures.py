@@ -1,0 +1,161 @@
+"""Pins the oracle (and, with `-m gpu`, the HIP path) to the REAL RayCastWorlds.jl — as soon as someone has run
+
+    julia --project=<env with RayCastWorlds> julia/make_reference_fixtures.jl
+
+which writes tests/golden/reference/ (the package's own outputs on the discriminating inputs of
+tests/golden/discriminators.json).  No Julia toolchain exists in this pipeline, so that directory is absent here and
+the two pinning tests SKIP, saying so: parity stays "unpinned".  What does run everywhere is the self-test of the
+kit: files in the same format, written from the CPU oracle under a known non-default switch setting, must be read
+back and judged correctly (exactly that setting — and no other — reproduces them).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import reference_pin as RP
+from test_discriminators import CASES
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "golden", "reference")
+BY_NAME = {c["name"]: c for c in CASES}
+HAVE_REFERENCE = os.path.exists(os.path.join(REF_DIR, "manifest.tsv"))
+NEED = pytest.mark.skipif(not HAVE_REFERENCE, reason="parity unpinned: tests/golden/reference/ is absent — run "
+                          "`julia julia/make_reference_fixtures.jl` with the real RayCastWorlds.jl once")
+
+
+def _rollout(step, state, frames):
+    """64 LCG actions from the injected state; stops where the reference raises BoundsError."""
+    pos, dirs, rew, done, error_step = [], [], [], [], 0
+    for k, a in enumerate(RP.lcg_actions(64), start=1):
+        if step(a) != 0:
+            error_step = k
+            break
+        p, d, r, dn = state()
+        pos += np.asarray(p, dtype=np.float32).view(np.uint32).tolist()
+        dirs.append(int(d)); rew.append(int(np.float32(r).view(np.uint32))); done.append(int(dn))
+    return dict(error_step=error_step, position_bits=np.array(pos, dtype=np.int64), direction_au=np.array(dirs, dtype=np.int64),
+                reward_bits=np.array(rew, dtype=np.int64), done=np.array(done, dtype=np.int64), camera_view=frames())
+
+
+def oracle_run(O):
+    def run(case, sw, directions):
+        orc = O.OracleBatch(1, render_top_view=1, **case["config"], **sw)
+        if directions is not None:
+            orc.set_direction_table(directions)
+        orc.set_state([case["goal"]], [case["position"]], [case["direction"]])
+        out = dict(ray_direction_bits=orc.ray_dirs[0].view(np.uint32).copy(), ray_stop_position_tu=orc.ray_stop[0].copy(),
+                   ray_hit_dimension=orc.ray_dim[0].copy(), ray_distance_bits=orc.ray_dist[0].view(np.uint32).copy(),
+                   camera_view=orc.camera_view[0].copy(), top_view=orc.top_view[0].copy())
+
+        def step(a):
+            rc = orc.step([a])
+            return rc if rc else int(orc.status[0])
+        out["rollout"] = _rollout(step, lambda: (orc.position[0], orc.direction[0], orc.reward[0], orc.done[0]),
+                                  lambda: orc.camera_view[0].copy())
+        orc.close()
+        return out
+    return run
+
+
+def hip_run(rcw):
+    def run(case, sw, directions):
+        env = rcw.SingleRoomModule.SingleRoom(batch=1, render_top_view=True, **case["config"], **sw)
+        if directions is not None:
+            env.set_direction_table(directions)
+        env.set_state([case["goal"]], [case["position"]], [case["direction"]])
+        stop, dim, dist, dirs = env.world.rays()
+        out = dict(ray_direction_bits=dirs[0].view(np.uint32), ray_stop_position_tu=stop[0], ray_hit_dimension=dim[0],
+                   ray_distance_bits=dist[0].view(np.uint32), camera_view=env.camera_view_host()[0],
+                   top_view=env.top_view_host()[0])
+
+        def step(a):
+            rcw.act_(env, a)
+            try:
+                env.sync()
+                return 0
+            except IndexError:
+                env.clear_error()
+                return -5
+        w = env.world
+        out["rollout"] = _rollout(step, lambda: (w.player_position_wu[0], w.player_direction_au[0], w.reward[0], w.done[0]),
+                                  lambda: env.camera_view_host()[0])
+        env.close()
+        return out
+    return run
+
+
+def _report(table):
+    lines = []
+    for setting, failures in sorted(table.items()):
+        tag = dict(zip(RP.SWITCHES, setting))
+        lines.append(f"{tag}: " + ("REPRODUCES THE REFERENCE" if not failures else f"{len(failures)} case(s) differ, e.g. {failures[:2]}"))
+    return "\n".join(lines)
+
+
+# ---- the pinning tests proper (need the Julia-made files) ---------------------------------------------------
+@NEED
+def test_reference_pins_the_oracle(oracle):
+    refs = RP.read_manifest(REF_DIR)
+    assert [r["name"] for r in refs] == [c["name"] for c in CASES], "fixtures are stale: re-run make_reference_fixtures.jl"
+    table = RP.judge(refs, BY_NAME, oracle_run(oracle))
+    matching = [s for s, f in table.items() if not f]
+    assert matching, "no switch setting reproduces RayCastWorlds.jl:\n" + _report(table)
+    assert (0, 0, 0) in matching, ("the library's DEFAULT switches do not reproduce RayCastWorlds.jl; the setting(s) that do: "
+                                   f"{matching} — change rcw_config_default (include/rcw.h) accordingly\n" + _report(table))
+    # cos/sin: Julia's directions_wu against the C library's (SR:65-69)
+    ours = oracle.direction_table(refs[0]["nd"])
+    theirs = RP.directions_from_bits(refs[0])
+    assert np.array_equal(ours.view(np.uint32), theirs.view(np.uint32)), \
+        "Julia's cos/sin table differs from the C library's in the last bit: hand it over with rcw_set_direction_table"
+
+
+@NEED
+@pytest.mark.gpu
+def test_reference_pins_the_hip_path(rcw):
+    refs = RP.read_manifest(REF_DIR)
+    table = RP.judge(refs, BY_NAME, hip_run(rcw))
+    assert not table[(0, 0, 0)], "HIP path vs RayCastWorlds.jl:\n" + _report(table)
+
+
+# ---- self-test of the kit (runs everywhere): same file format, written from the oracle under a known setting ----
+def _write_like_the_julia_script(directory, case, out, nd, directions):
+    """Emulates make_reference_fixtures.jl's output format from a backend's outputs — for the self-test only; the
+    real files come from Julia."""
+    name = case["name"]
+    cfg = case["config"]
+    j = lambda a: " ".join(str(int(v)) for v in np.asarray(a).reshape(-1))      # noqa: E731
+    r = out["rollout"]
+    with open(os.path.join(directory, name + ".txt"), "w") as f:
+        f.write(f"name {name}\nversions self-test (CPU oracle, not Julia)\n")
+        f.write(f"shape {cfg['height_tile_map_tu']} {cfg['width_tile_map_tu']} {cfg['num_rays']} {nd} 256 "
+                f"{cfg['height_tile_map_tu'] * 32} {cfg['width_tile_map_tu'] * 32}\n")
+        f.write("directions_wu_bits " + j(directions.view(np.uint32)) + "\n")
+        for k in RP.RAY_FIELDS:
+            f.write(f"{k} {j(out[k])}\n")
+        f.write("rollout_actions " + j(RP.lcg_actions(64)) + "\n")
+        f.write(f"rollout_error_step {r['error_step']}\n")
+        f.write("rollout_position_bits " + j(r["position_bits"]) + "\n")
+        f.write("rollout_direction_au " + j(r["direction_au"]) + "\n")
+        f.write("rollout_reward_bits " + j(r["reward_bits"]) + "\n")
+        f.write("rollout_done " + j(r["done"]) + "\n")
+    out["camera_view"].astype("<u4").tofile(os.path.join(directory, name + ".camera_view.u32"))
+    out["top_view"].astype("<u4").tofile(os.path.join(directory, name + ".top_view.u32"))
+    r["camera_view"].astype("<u4").tofile(os.path.join(directory, name + ".camera_view_after_rollout.u32"))
+
+
+@pytest.mark.parametrize("truth", [(1, 0, 1), (0, 1, 0)], ids=["tie_le+divide", "pre_increment"])
+def test_kit_identifies_a_known_setting(oracle, tmp_path, truth):
+    run = oracle_run(oracle)
+    sw = dict(zip(RP.SWITCHES, truth))
+    directions = oracle.direction_table(128)
+    with open(tmp_path / "manifest.tsv", "w") as mf:
+        mf.write("# self-test\n")
+        for case in CASES:
+            _write_like_the_julia_script(str(tmp_path), case, run(case, sw, None), 128, directions)
+            mf.write(case["name"] + "\n")
+    refs = RP.read_manifest(str(tmp_path))
+    assert len(refs) == len(CASES)
+    table = RP.judge(refs, BY_NAME, run)
+    matching = [s for s, f in table.items() if not f]
+    assert matching == [truth], _report(table)          # the discriminators leave exactly one setting standing

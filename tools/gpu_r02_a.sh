@@ -4,10 +4,10 @@ set -o pipefail
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/a_pytest.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/a_pytest.log 2>&1
 rc=$?
 tail -5 gpurun_out/a_pytest.log
-if [ $rc -ge 124 ]; then echo "pytest killed ($rc): stopping"; exit $rc; fi
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out ($rc): stopping"; exit $rc; fi
 for v in 0 1 2 3 5; do
   echo "== RCW_TOP_VARIANT=$v"
   RCW_TOP_VARIANT=$v timeout -k 10 120 python bench.py --top-view --steps 60 --warmup 5 --no-cpu-baseline > gpurun_out/a_top_v$v.json 2> gpurun_out/a_top_v$v.err || { echo "variant $v failed"; tail -3 gpurun_out/a_top_v$v.err; exit 1; }
