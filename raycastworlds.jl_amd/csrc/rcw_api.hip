@@ -535,6 +535,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
         per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         d.top_grid = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     }
+    d.top_debug = 0;
+    if (const char* v = std::getenv("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
     if (const char* v = std::getenv("RCW_TOP_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_grid = g; }
     if (const char* v = std::getenv("RCW_TOP_INPLACE")) { if (std::atoi(v)) d.top_lds = 0; }
     d.status = (int32_t*)h->d_status;

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_view_inplace_kernel(const RcwD
 // Every pixel of the (H·pu, W·pu) image is stored exactly once, and drawing overlaps with storing:
 // a workgroup has 8 wavefronts in two groups of four and walks through its agents in slots.  In slot s
 //   * the DRAW group rasterises agent s into one of two LDS buffers: the agent's tile map (a byte per
-//     tile), a `line` bit plane (one bit per pixel, bit index = the pixel's linear index (j-1)·Ht + (i-1))
+//     tile), a `line` bit plane (one bit per pixel, bit index (j-1)·top_col_bits + (i-1))
 //     and a `circ` plane for the 2·rp+1 image columns around the player.  One lane per ray: cast (the same
 //     DDA as the camera path), end point SR:476, then the line's pixels are OR-ed into `line` with LDS
 //     atomics.  All lines start at the player's pixel and neighbouring rays share most of their first
@@ -673,13 +673,22 @@ constexpr int kTopBlock = 512;          // 4 draw + 4 store wavefronts
 constexpr int kTopGroup = 256;
 constexpr int kTopDummyWords = 64;      // where lanes with nothing to draw aim their (harmless) atomic
 
+// A plane stores image column j (Ht pixels, contiguous in the image) at bit offset j * top_col_bits: the column
+// stride is padded to an ODD number of words, so that the pixels of one wavefront step — which lie on an arc across
+// neighbouring columns when the agent looks along the rows — fall into different LDS banks (an unpadded 256-pixel
+// column is 8 words: neighbouring columns would share only 4 banks).
+__host__ __device__ __forceinline__ int top_col_bits(const RcwDev& p)
+{
+    const int words = (p.H * p.pu + 31) / 32;
+    return 32 * (words | 1);
+}
 __host__ __device__ __forceinline__ size_t top_line_words(const RcwDev& p)
 {
-    return (((size_t)p.H * p.pu * (size_t)p.W * p.pu + 31) / 32 + 3) & ~(size_t)3;     // multiple of 4 words
+    return ((size_t)p.W * p.pu * (top_col_bits(p) / 32) + 3) & ~(size_t)3;     // multiple of 4 words
 }
 __host__ __device__ __forceinline__ size_t top_circ_words(const RcwDev& p)
 {
-    return (((size_t)(2 * p.top_rp + 1) * (size_t)p.H * p.pu + 31) / 32 + 3) & ~(size_t)3;
+    return ((size_t)(2 * p.top_rp + 1) * (top_col_bits(p) / 32) + 3) & ~(size_t)3;
 }
 __host__ __device__ __forceinline__ size_t top_tile_words(const RcwDev& p) { return (((size_t)p.H * p.W + 15) & ~(size_t)15) / 4; }
 // one buffer: [header 4 words | tile bytes | line | circ | dummy]
@@ -744,6 +753,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     if (tid == 0) { b.hdr[0] = ip; b.hdr[1] = jp; }
     const T* tab = Real<T>::ray_table(p) + (size_t)d * RCW_TABLE_ROWS * p.N;
     const bool start_inside = ip >= 1 && ip <= Ht && jp >= 1 && jp <= Wt;
+    const int cb_ = top_col_bits(p);
     uint32_t* const dummy = b.dummy + (tid & 63);
     for (int i0 = 0; i0 < p.N; i0 += kTopGroup) {
         const int i = i0 + tid;
@@ -759,14 +769,14 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
             const T ex = pos.x + ox, ey = pos.y + oy;
             i2 = wu_to_pu<T>(ex, pu); j2 = wu_to_pu<T>(ey, pu);             // SR:476
             const int di = abs(i2 - ip), dj = abs(j2 - jp);
-            const int si = ip < i2 ? 1 : -1, sj = jp < j2 ? Ht : -Ht;      // steps of the linear pixel index
+            const int si = ip < i2 ? 1 : -1, sj = jp < j2 ? cb_ : -cb_;    // steps of the plane's bit index
             const bool imaj = di >= dj;
             const int la = imaj ? di : dj, lb = imaj ? dj : di;
             n = la + 1;
             a2 = 2 * la; b2 = 2 * lb; acc = la;
             step_maj = imaj ? si : sj;
             step_both = si + sj;
-            addr = (jp - 1) * Ht + (ip - 1);
+            addr = (jp - 1) * cb_ + (ip - 1);
             // a line whose end points are both on the image stays on it; anything else takes the clipped walk
             checked = !(start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt);
             if (checked) n = 0;
@@ -794,7 +804,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
                 int err = di + dj;
                 for (long long guard = 0; guard <= (long long)di - dj; ++guard) {
                     if (i1 >= 1 && i1 <= Ht && j1 >= 1 && j1 <= Wt) {
-                        const int q = (j1 - 1) * Ht + (i1 - 1);
+                        const int q = (j1 - 1) * cb_ + (i1 - 1);
                         __hip_atomic_fetch_or(b.line + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     if (i1 == i2 && j1 == j2) break;
@@ -812,7 +822,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
         int x = 0, y = rp, dd = 1 - rp;
         auto put = [&](int i, int j) {
             if (i >= 1 && i <= Ht && j >= 1 && j <= Wt) {
-                const int q = (j - jc0) * Ht + (i - 1);
+                const int q = (j - jc0) * cb_ + (i - 1);
                 b.circ[q >> 5] |= 1u << (q & 31);
             }
         };
@@ -826,7 +836,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     }
 }
 
-// store group: half `part` (0 / 1) of agent a's image, every pixel once
+// store group: agent a's image, every pixel once.  part 0 / 1: the first / second half of the columns, 2: all of it
 __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& b, int tid, int part)
 {
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
@@ -835,40 +845,49 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
     const float inv_pu = 1.0f / (float)pu;
     const int jc0 = b.hdr[1] - rp;
     const int box = 2 * rp;
-    const int half = Wt >> 1;                                               // part 0: columns [0, half), part 1: the rest
-    const int c_lo = part == 0 ? 0 : half, c_hi = part == 0 ? half : Wt;
+    const int cbits = top_col_bits(p);
+    const int half = Wt >> 1;
+    const int c_lo = part == 1 ? half : 0, c_hi = part == 0 ? half : Wt;
     if ((Ht & 255) == 0 && (pu & 3) == 0) {
         // One wavefront per image column (256 rows per pass), lanes along the contiguous rows, four pixels a lane:
-        // they never straddle a tile, and everything that depends on the column only is wave-uniform.
-        const int wave = tid >> 6, lane = tid & 63;
+        // they never straddle a tile.  What depends on the rows only (tile row, frame rows) is computed once per
+        // row block; what depends on the column only is wave-uniform (scalar unit).
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         u32x4* out = reinterpret_cast<u32x4*>(img);
         const int vpc = Ht >> 2;
-        for (int jp0 = c_lo + wave; jp0 < c_hi; jp0 += kTopGroup / 64) {
-            const int tj = jp0 / pu, rj = jp0 - tj * pu;                    // wave-uniform: scalar unit
-            const bool frame_col = rj == 0 || rj == pu - 1;                  // SR:366-367
-            const int cj = jp0 + 1 - jc0;
-            const bool in_box = (unsigned)cj <= (unsigned)box;
-            for (int ip0 = lane * 4; ip0 < Ht; ip0 += 256) {
-                const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
-                const uint32_t fill = tile_fill_colour(b.tb[ti + p.H * tj]);
+        for (int r0 = 0; r0 < Ht; r0 += 256) {
+            const int ip0 = r0 + lane * 4;
+            const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
+            const bool first_row = ri == 0, last_row = ri + 3 == pu - 1;    // SR:364-365: the tile's frame rows
+            const uint8_t* const tile_row = b.tb + ti;
+            const int word0 = ip0 >> 5, sh = ip0 & 31;
+            const int wpc = top_col_bits(p) >> 5;                           // plane words per (padded) column
+            int tj = c_lo / pu, rj = c_lo - tj * pu;                        // tile column / offset of column c_lo
+            tj = __builtin_amdgcn_readfirstlane(tj); rj = __builtin_amdgcn_readfirstlane(rj);
+            // this wavefront's columns: c_lo + wave, + 4, + 8, ...
+            rj += wave; while (rj >= pu) { rj -= pu; tj += 1; }
+            for (int jp0 = c_lo + wave; jp0 < c_hi; jp0 += kTopGroup / 64) {
+                const bool frame_col = rj == 0 || rj == pu - 1;              // SR:366-367
+                const uint32_t fill = tile_fill_colour(tile_row[p.H * tj]);
                 const uint32_t inner = frame_col ? grid_c : fill;
-                const int lin = jp0 * Ht + ip0;
-                const uint32_t lb = b.line[lin >> 5] >> (lin & 31);
+                const uint32_t lb = b.line[jp0 * wpc + word0] >> sh;
+                const int cj = jp0 + 1 - jc0;
                 uint32_t cb = 0u;
-                if (in_box) { const int q = cj * Ht + ip0; cb = b.circ[q >> 5] >> (q & 31); }
-                const uint32_t ov = lb | cb;                                 // any overlay on these four pixels?
+                if ((unsigned)cj <= (unsigned)box) cb = b.circ[cj * wpc + word0] >> sh;   // wave-uniform branch
                 u32x4 o;
-                o.x = ri == 0 ? grid_c : inner;                              // SR:364: first row of the tile
+                o.x = first_row ? grid_c : inner;
                 o.y = inner;
                 o.z = inner;
-                o.w = ri + 3 == pu - 1 ? grid_c : inner;                     // SR:365: last row of the tile
-                if (ov & 15u) {
+                o.w = last_row ? grid_c : inner;
+                if ((lb | cb) & 15u) {
                     o.x = (cb & 1u) ? player_c : ((lb & 1u) ? ray_c : o.x);
                     o.y = (cb & 2u) ? player_c : ((lb & 2u) ? ray_c : o.y);
                     o.z = (cb & 4u) ? player_c : ((lb & 4u) ? ray_c : o.z);
                     o.w = (cb & 8u) ? player_c : ((lb & 8u) ? ray_c : o.w);
                 }
-                __builtin_nontemporal_store(o, out + (size_t)jp0 * vpc + (ip0 >> 2));
+                u32x4* dst = out + (size_t)jp0 * vpc + (ip0 >> 2);
+                __builtin_nontemporal_store(o, dst);
+                rj += kTopGroup / 64; while (rj >= pu) { rj -= pu; tj += 1; }
             }
         }
     } else if ((Ht & 3) == 0) {
@@ -887,11 +906,11 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
                 const int ti = fast_div(ip0 + e, pu, inv_pu), ri = ip0 + e - ti * pu;
                 px[e] = (frame_col || ri == 0 || ri == pu - 1) ? grid_c : tile_fill_colour(b.tb[ti + p.H * tj]);
             }
-            const int lin = jp0 * Ht + ip0;
+            const int lin = jp0 * cbits + ip0;
             const uint32_t lb = b.line[lin >> 5] >> (lin & 31);
             uint32_t cb = 0u;
             const int cj = jp0 + 1 - jc0;
-            if ((unsigned)cj <= (unsigned)box) { const int q = cj * Ht + ip0; cb = b.circ[q >> 5] >> (q & 31); }
+            if ((unsigned)cj <= (unsigned)box) { const int q = cj * cbits + ip0; cb = b.circ[q >> 5] >> (q & 31); }
             u32x4 o;
             o.x = (cb & 1u) ? player_c : ((lb & 1u) ? ray_c : px[0]);
             o.y = (cb & 2u) ? player_c : ((lb & 2u) ? ray_c : px[1]);
@@ -909,14 +928,25 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
             const int tj = fast_div(jp0, pu, inv_pu), rj = jp0 - tj * pu;
             const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
             uint32_t c = (rj == 0 || rj == pu - 1 || ri == 0 || ri == pu - 1) ? grid_c : tile_fill_colour(b.tb[ti + p.H * tj]);
-            if ((b.line[v >> 5] >> (v & 31)) & 1u) c = ray_c;
+            const int lin = jp0 * cbits + ip0;
+            if ((b.line[lin >> 5] >> (lin & 31)) & 1u) c = ray_c;
             const int cj = jp0 + 1 - jc0;
-            if ((unsigned)cj <= (unsigned)box) { const int q = cj * Ht + ip0; if ((b.circ[q >> 5] >> (q & 31)) & 1u) c = player_c; }
+            if ((unsigned)cj <= (unsigned)box) { const int q = cj * cbits + ip0; if ((b.circ[q >> 5] >> (q & 31)) & 1u) c = player_c; }
             img[v] = c;
             jp0 += qstep; ip0 += rstep;
             if (ip0 >= Ht) { ip0 -= Ht; jp0 += 1; }
         }
     }
+}
+
+// Sync among the four wavefronts of the draw group only (the store group must not be held up): a counter in LDS
+// that only ever grows; each wavefront adds one when its LDS writes are done and waits for the group's total.
+__device__ __forceinline__ void draw_group_sync(int* counter, int target)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
 }
 
 template <typename T, bool TIE_LE, bool DIST_PRE>
@@ -928,32 +958,38 @@ __global__ __launch_bounds__(kTopBlock, 8) void rcw_top_view_kernel(const RcwDev
     const int G = gridDim.x;
     const int n = (p.B - (int)blockIdx.x + G - 1) / G;                      // agents of this workgroup: blockIdx.x + k*G
     const size_t bw = top_buf_words(p);
-    // The schedule, one workgroup barrier per step.  Overlapped (two LDS buffers): step h = 2 s + part; the draw
-    // group prepares (part 0) then draws (part 1) agent s while the store group stores the two halves of agent
-    // s - 1.  Serial (image too large for two buffers): step h = 3 s + phase; prepare, draw, then both groups
-    // store one half each.
+    int* const counter = reinterpret_cast<int*>(lds);                       // lds[0..3]: the draw group's counter
+    uint32_t* const bufs = lds + 4;
+    if (threadIdx.x == 0) *counter = 0;
+    lds_barrier();
+    // The schedule, one workgroup barrier per step.  Overlapped (two LDS buffers): in step s the draw group prepares
+    // and draws agent s while the store group stores agent s - 1.  Serial (image too large for two buffers): step
+    // h = 2 s + phase; the draw group draws, then both groups store one half each.
     const bool serial = p.top_lds == 2;
-    const int steps = serial ? 3 * n : 2 * (n + 1);
-    enum { NONE, PREPARE, DRAW, STORE };
+    const int steps = serial ? 2 * n : n + 1;
+    enum { NONE, DRAW, STORE };
+    int drawn = 0;
     for (int h = 0; h < steps; ++h) {
-        int what = NONE, agent = 0, buf = 0, part = 0;
+        int what = NONE, agent = 0, buf = 0, part = 2;
         if (serial) {
-            const int s = h / 3, ph = h - 3 * s;
-            agent = s;
-            if (ph == 2) { what = STORE; part = role; }
-            else if (role == 0) what = ph == 0 ? PREPARE : DRAW;
+            agent = h >> 1;
+            if (h & 1) { what = STORE; part = role; }
+            else if (role == 0) what = DRAW;
         } else {
-            const int s = h >> 1;
-            part = h & 1;
-            if (role == 0) { agent = s; buf = s & 1; what = s < n ? (part == 0 ? PREPARE : DRAW) : NONE; }
-            else           { agent = s - 1; buf = (s + 1) & 1; what = s >= 1 ? STORE : NONE; }
+            if (role == 0) { agent = h; buf = h & 1; what = h < n ? DRAW : NONE; }
+            else           { agent = h - 1; buf = (h + 1) & 1; what = h >= 1 ? STORE : NONE; }
         }
         const int a = blockIdx.x + agent * G;
         if (what != NONE && mask != nullptr && mask[a] == 0) what = NONE;
-        const TopBuf b = top_buf(p, lds + (size_t)buf * bw);
-        if (what == PREPARE) top_prepare(p, a, b, tid);
-        else if (what == DRAW) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
-        else if (what == STORE) top_store(p, a, b, tid, part);
+        const TopBuf b = top_buf(p, bufs + (size_t)buf * bw);
+        if (what == DRAW) {
+            top_prepare(p, a, b, tid);
+            drawn += 1;
+            draw_group_sync(counter, 4 * drawn);
+            if (!(p.top_debug & 1)) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
+        } else if (what == STORE && !(p.top_debug & 2)) {
+            top_store(p, a, b, tid, part);
+        }
         lds_barrier();
     }
 }
@@ -1013,7 +1049,7 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
 
 size_t rcw_top_view_lds_bytes(const RcwDev& p)
 {
-    return (p.top_lds == 2 ? 1 : 2) * 4 * top_buf_words(p);      // two buffers: one being drawn, one being stored
+    return 16 + (p.top_lds == 2 ? 1 : 2) * 4 * top_buf_words(p);      // counter + two buffers: one being drawn, one being stored
 }
 
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)

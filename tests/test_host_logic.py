@@ -97,3 +97,45 @@ def test_frame_dump_matches_the_reference_blit(rcw, oracle, tmp_path):
     rcw.save_ppm(frame, str(p))
     data = p.read_bytes()
     assert data.startswith(b"P6\n64 256\n255\n") and len(data) == len(b"P6\n64 256\n255\n") + 64 * 256 * 3
+
+
+def test_line_closed_form_equals_the_error_term_walk():
+    """The write-once top view kernel (rcw_kernels.hip, top_draw) steps a line with the remainder of
+    floor((2 b k + a) / (2 a)) instead of the error term of SD.Line as the oracle restates it (sd_line in
+    oracle/rcw_oracle.c).  Exhaustive check that both visit the same pixels, for every end point within +-48 px."""
+    def error_term_walk(i2, j2):
+        i1 = j1 = 0
+        di, dj = abs(i2), -abs(j2)
+        si, sj = (1 if i1 < i2 else -1), (1 if j1 < j2 else -1)
+        err, out = di + dj, []
+        while True:
+            out.append((i1, j1))
+            if i1 == i2 and j1 == j2:
+                return out
+            e2 = 2 * err
+            if e2 >= dj:
+                err += dj; i1 += si
+            if e2 <= di:
+                err += di; j1 += sj
+
+    def remainder_walk(i2, j2):
+        di, dj = abs(i2), abs(j2)
+        si, sj = (1 if 0 < i2 else -1), (1 if 0 < j2 else -1)
+        imaj = di >= dj
+        a, b = (di, dj) if imaj else (dj, di)
+        acc, i, j, out = a, 0, 0, []
+        for _ in range(a + 1):
+            out.append((i, j))
+            acc += 2 * b
+            t = acc >= 2 * a
+            if t:
+                acc -= 2 * a
+            if imaj:
+                i += si; j += sj if t else 0
+            else:
+                j += sj; i += si if t else 0
+        return out
+
+    for i2 in range(-48, 49):
+        for j2 in range(-48, 49):
+            assert error_term_walk(i2, j2) == remainder_walk(i2, j2), (i2, j2)

@@ -1,0 +1,20 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests -m gpu -q -k "top_view or render_entry or float64" > gpurun_out/c_pytest.log 2>&1
+rc=$?
+tail -3 gpurun_out/c_pytest.log
+if [ $rc -ne 0 ]; then echo "tests failed ($rc): not timing"; exit $rc; fi
+for dbg in 0 8 2 1 4; do
+ for g in 1024; do
+  echo "== RCW_TOP_DEBUG=$dbg RCW_TOP_GRID=$g"
+  RCW_TOP_DEBUG=$dbg RCW_TOP_GRID=$g timeout -k 10 120 python bench.py --top-view --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/c_top.json 2> gpurun_out/c_top.err || { echo "failed"; tail -3 gpurun_out/c_top.err; exit 1; }
+  python3 -c "import json,sys; d=json.load(open('gpurun_out/c_top.json')); t=d['top_view']; print('top_view us', round(t['launch_ms']*1e3,1), 'GB/s', round(t['achieved']), 'frac', round(t['frac'],3))"
+ done
+done
+for g in 2048; do
+  echo "== RCW_TOP_GRID=$g"
+  RCW_TOP_GRID=$g timeout -k 10 120 python bench.py --top-view --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/c_top.json 2> gpurun_out/c_top.err || { echo "failed"; tail -3 gpurun_out/c_top.err; exit 1; }
+  python3 -c "import json,sys; d=json.load(open('gpurun_out/c_top.json')); t=d['top_view']; print('top_view us', round(t['launch_ms']*1e3,1), 'GB/s', round(t['achieved']), 'frac', round(t['frac'],3))"
+done
