@@ -1,13 +1,14 @@
-# BatchedSingleRoom.jl — the reference-side binding of librcw_hip (include/rcw.h).
+# BatchedSingleRoom.jl — the reference-side binding of librcw_hip (include/rcw.h, ABI version 3).
 #
 # This is what a RayCastWorlds.jl maintainer would add to keep the package's API
-# (`RCW.reset!`, `RCW.act!`, `RCW.RLBaseEnv` with `state` / `reward` / `is_terminated`) while the
-# SingleRoom step/render path runs on an MI355X for a whole batch of agents.
+# (`RCW.reset!`, `RCW.act!`, `RCW.cast_rays!`, `RCW.update_camera_view!`, `RCW.update_top_view!`,
+# `RCW.RLBaseEnv` with `state` / `reward` / `is_terminated`) while the SingleRoom step/render path runs on an
+# MI355X for a whole batch of agents.  EVERY export of include/rcw.h is bound here; tests/test_julia_binding.py
+# checks each `ccall` below against the prototypes in the header (name, arity, pointer/scalar kind, width).
 #
-# NOT EXECUTED IN THIS PIPELINE: neither the build container nor the GPU box has a Julia
-# toolchain (SURVEY.md §0), so this file is written against the C ABI and checked by reading
-# only; the same calls are exercised by the Python/ctypes host layer in
-# raycastworlds.jl_amd/ and by tests/.
+# NOT EXECUTED IN THIS PIPELINE: neither the build container nor the GPU box has a Julia toolchain
+# (SURVEY.md §0), so this file is written against the C ABI and checked mechanically; the same calls are
+# exercised by the Python/ctypes host layer in raycastworlds.jl_amd/ and by tests/c_abi_harness.c.
 #
 # Usage (inside the RayCastWorlds module tree, next to single_room.jl):
 #
@@ -17,8 +18,15 @@
 #     RCW.reset!(env)
 #     RCW.act!(env, rand(UInt8(1):UInt8(4), 4096))
 #     rl = RCW.RLBaseEnv(env)
-#     obs = RLBase.state(rl)        # Array{UInt32,3}(H_cam, N, B) copied from the device
+#     obs = RLBase.state(rl)        # the SAME Array{UInt32,3}(H_cam, N, B) every call (SR:576), refreshed lazily
 #     RLBase.reward(rl); RLBase.is_terminated(rl)
+#
+# Observations.  The reference returns `camera_view` itself from `RLBase.state` (single_room.jl:576): one array,
+# mutated in place by the next `act!`.  Here the frames live in HBM.  `RLBase.state` returns one host mirror —
+# the same `Array` object on every call — and copies the batch off the device only when a step / reset has made
+# the mirror stale, so calling it repeatedly costs nothing.  A device-side consumer skips the copy altogether:
+# `camera_view_device_ptr(env)` is stable for the handle's lifetime, e.g. with AMDGPU.jl
+# `unsafe_wrap(ROCArray{UInt32,3}, Ptr{UInt32}(ptr), (H_cam, N, B))`.
 
 module BatchedSingleRoomModule
 
@@ -27,11 +35,17 @@ import ReinforcementLearningBase as RLBase
 
 const librcw = get(ENV, "LIBRCW_HIP", "librcw_hip.so")
 
+const RCW_ABI_VERSION = 3
 const NUM_ACTIONS = 4   # src/single_room.jl:19
+const RCW_UNIQUE_ID_BYTES = 128
+const RCW_GATHER_COLUMNS = Int32(0)
+const RCW_GATHER_FRAMES = Int32(1)
+# R of SingleRoom(; R = ...) single_room.jl:266  <->  rcw_config.reward_type
+const REWARD_TYPES = (Float32, Float64, Int32, Int64)
 
 # struct rcw_config (include/rcw.h) — field order and types must match exactly (160 bytes)
 Base.@kwdef mutable struct RcwConfig
-    abi_version::Int32 = 2
+    abi_version::Int32 = RCW_ABI_VERSION
     height_tile_map_tu::Int32 = 8
     width_tile_map_tu::Int32 = 16
     num_directions::Int32 = 128
@@ -54,7 +68,7 @@ Base.@kwdef mutable struct RcwConfig
     normalize_mode::Int32 = 0
     auto_reset::Int32 = 0
     agent_id_offset::Int64 = 0
-    write_columns::Int32 = 1
+    reward_type::Int32 = 0
     out_of_bounds::Int32 = 0
     render_top_view::Int32 = 0
     world_unit_bits::Int32 = 32
@@ -62,7 +76,8 @@ Base.@kwdef mutable struct RcwConfig
     position_increment_wu_f64::Float64 = 1 / 8
     semi_field_of_view_wu_f64::Float64 = 2 / 3
     camera_height_tile_wu_f64::Float64 = 1
-    reserved::NTuple{4, Int32} = (0, 0, 0, 0)
+    goal_reward_f64::Float64 = 1
+    reserved::NTuple{2, Int32} = (0, 0)
 end
 
 struct RcwError <: Exception
@@ -70,40 +85,74 @@ struct RcwError <: Exception
     msg::String
 end
 
+last_error() = unsafe_string(ccall((:rcw_last_error, librcw), Cstring, ()))
+abi_version() = ccall((:rcw_abi_version, librcw), Cint, ())
+
 function check(rc::Cint)
     rc == 0 && return nothing
-    msg = unsafe_string(ccall((:rcw_last_error, librcw), Cstring, ()))
+    msg = last_error()
     rc == -2 && throw(AssertionError(msg))            # @assert action in 1:4, single_room.jl:140
     rc == -5 && throw(BoundsError())                   # collision_detection.jl:35
     rc == -1 && throw(ArgumentError(msg))
+    rc == -4 && throw(OutOfMemoryError())
     throw(RcwError(rc, msg))
 end
 
-mutable struct BatchedSingleRoom <: RCW.AbstractGame
+# The library's own defaults (the reference's kwargs, single_room.jl:258-272, 288-296): equals RcwConfig()
+function config_default()
+    cfg = RcwConfig()
+    check(ccall((:rcw_config_default, librcw), Cint, (Ref{RcwConfig},), cfg))
+    return cfg
+end
+
+mutable struct BatchedSingleRoom{T, R} <: RCW.AbstractGame
     handle::Ptr{Cvoid}
     batch::Int
     config::RcwConfig
-    camera_view::Array{UInt32, 3}     # (H_cam, N, B) host mirror, refreshed by state()
+    camera_view::Array{UInt32, 3}     # (H_cam, N, B) host mirror: THE array RLBase.state returns, every call
+    stale::Bool                       # the mirror is older than the device frames
     seed::UInt64
+    gather_buffer::Ptr{Cvoid}         # device memory for gather_observations (allocated on first use)
+    gather_frames::Int                # agents the gather buffer holds
 
-    function BatchedSingleRoom(batch::Integer; device::Integer = 0, seed::Integer = 0, kwargs...)
+    # SingleRoom(; T, R, kwargs...) single_room.jl:258-272 for `batch` agents on HIP device `device`
+    function BatchedSingleRoom(batch::Integer; T::Type = Float32, R::Type = Float32, device::Integer = 0,
+                               seed::Integer = 0, kwargs...)
+        T in (Float32, Float64) || throw(ArgumentError("T must be Float32 or Float64"))
+        R in REWARD_TYPES || throw(ArgumentError("R must be one of $(REWARD_TYPES)"))
         cfg = RcwConfig(; kwargs...)
-        # Julia's own cos/sin for directions_wu (single_room.jl:65-69) can be handed over with
-        # rcw_set_direction_table; the library's default is the same formula in C.
+        cfg.world_unit_bits = T === Float64 ? 64 : 32
+        cfg.reward_type = Int32(findfirst(==(R), REWARD_TYPES) - 1)
+        cfg.goal_reward = one(Float32); cfg.goal_reward_f64 = 1.0      # one(R) single_room.jl:82
         handle = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:rcw_create, librcw), Cint, (Ref{RcwConfig}, Int32, Int32, UInt64, Ref{Ptr{Cvoid}}),
                     cfg, batch, device, seed, handle))
         view = Array{UInt32, 3}(undef, cfg.height_camera_view_pu, cfg.num_rays, batch)
-        env = new(handle[], batch, cfg, view, seed)
-        finalizer(e -> ccall((:rcw_destroy, librcw), Cint, (Ptr{Cvoid},), e.handle), env)
+        env = new{T, R}(handle[], batch, cfg, view, true, seed, C_NULL, 0)
+        finalizer(destroy!, env)
         return env
     end
 end
 
-# RCW.reset!(env)  — single_room.jl:326-331
-function RCW.reset!(env::BatchedSingleRoom; mask::Union{Nothing, Vector{UInt8}} = nothing)
+function destroy!(env::BatchedSingleRoom)
+    env.handle == C_NULL && return nothing
+    env.gather_buffer != C_NULL && ccall((:rcw_device_free, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), env.handle, env.gather_buffer)
+    ccall((:rcw_destroy, librcw), Cint, (Ptr{Cvoid},), env.handle)
+    env.handle = C_NULL
+    env.gather_buffer = C_NULL
+    return nothing
+end
+
+#####
+##### the generic functions of RayCastWorlds.jl:7-14 on the path
+#####
+
+# RCW.reset!(env)  — single_room.jl:326-331 (all agents, or those whose mask byte is non-zero)
+function RCW.reset!(env::BatchedSingleRoom; mask::Union{Nothing, Vector{UInt8}} = nothing, seed::Integer = env.seed)
+    env.seed = seed
     check(ccall((:rcw_reset, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}, UInt64),
                 env.handle, mask === nothing ? C_NULL : pointer(mask), env.seed))
+    env.stale = true
     return nothing
 end
 
@@ -111,22 +160,82 @@ end
 function RCW.act!(env::BatchedSingleRoom, actions::Vector{UInt8})
     length(actions) == env.batch || throw(DimensionMismatch("expected $(env.batch) actions"))
     check(ccall((:rcw_step, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}), env.handle, actions))
+    env.stale = true
     return nothing
 end
 RCW.act!(env::BatchedSingleRoom, action::Integer) = RCW.act!(env, fill(UInt8(action), env.batch))
 
+# The same with actions already in device memory (a policy that runs on the GPU): stream-ordered, no host round trip
+function act_device!(env::BatchedSingleRoom, actions_device::Ptr{UInt8})
+    check(ccall((:rcw_step_device, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}), env.handle, actions_device))
+    env.stale = true
+    return nothing
+end
+
 RCW.get_action_names(env::BatchedSingleRoom) = (:MOVE_FORWARD, :MOVE_BACKWARD, :TURN_LEFT, :TURN_RIGHT)
+
+# RCW.cast_rays!(world) single_room.jl:195-231, RCW.update_camera_view!(env) :374-444, RCW.update_top_view!(env) :446-483
+function RCW.cast_rays!(env::BatchedSingleRoom)
+    check(ccall((:rcw_cast_rays, librcw), Cint, (Ptr{Cvoid},), env.handle))
+    return nothing
+end
+function RCW.update_camera_view!(env::BatchedSingleRoom)
+    check(ccall((:rcw_update_camera_view, librcw), Cint, (Ptr{Cvoid},), env.handle))
+    env.stale = true
+    return nothing
+end
+function RCW.update_top_view!(env::BatchedSingleRoom)
+    check(ccall((:rcw_update_top_view, librcw), Cint, (Ptr{Cvoid},), env.handle))
+    return nothing
+end
+
+sync(env::BatchedSingleRoom) = check(ccall((:rcw_sync, librcw), Cint, (Ptr{Cvoid},), env.handle))
+clear_error!(env::BatchedSingleRoom) = check(ccall((:rcw_clear_error, librcw), Cint, (Ptr{Cvoid},), env.handle))
 
 # Inject the state reset!(world) would have produced (single_room.jl:118-132) — how "identical
 # seeds" is realised against the CPU reference (SURVEY.md §8c).
-function set_state!(env::BatchedSingleRoom, goal_ij::Matrix{Int32}, position_wu::Matrix{Float32},
-                    direction_au::Vector{Int32})
+function set_state!(env::BatchedSingleRoom{Float32}, goal_ij::Matrix{Int32}, position_wu::Matrix{Float32},
+                    direction_au::Vector{Int32}; mask::Union{Nothing, Vector{UInt8}} = nothing)
     check(ccall((:rcw_set_state, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Int32}, Ptr{UInt8}),
-                env.handle, goal_ij, position_wu, direction_au, C_NULL))
+                env.handle, goal_ij, position_wu, direction_au, mask === nothing ? C_NULL : pointer(mask)))
+    env.stale = true
+    return nothing
+end
+function set_state!(env::BatchedSingleRoom{Float64}, goal_ij::Matrix{Int32}, position_wu::Matrix{Float64},
+                    direction_au::Vector{Int32}; mask::Union{Nothing, Vector{UInt8}} = nothing)
+    check(ccall((:rcw_set_state64, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{UInt8}),
+                env.handle, goal_ij, position_wu, direction_au, mask === nothing ? C_NULL : pointer(mask)))
+    env.stale = true
+    return nothing
 end
 
-# world fields (single_room.jl:21-40)
-function reward(env::BatchedSingleRoom)
+# Julia's own directions_wu (single_room.jl:65-69: Julia's cos / sin) instead of the C library's
+function set_direction_table!(env::BatchedSingleRoom{Float32}, directions_wu::Matrix{Float32})
+    check(ccall((:rcw_set_direction_table, librcw), Cint, (Ptr{Cvoid}, Ptr{Float32}), env.handle, directions_wu))
+    env.stale = true
+end
+function set_direction_table!(env::BatchedSingleRoom{Float64}, directions_wu::Matrix{Float64})
+    check(ccall((:rcw_set_direction_table64, librcw), Cint, (Ptr{Cvoid}, Ptr{Float64}), env.handle, directions_wu))
+    env.stale = true
+end
+function julia_direction_table(::Type{T}, num_directions) where {T}
+    out = Matrix{T}(undef, 2, num_directions)
+    for i in 1:num_directions
+        theta_wu = (i - 1) * 2 * pi / num_directions                     # single_room.jl:66
+        out[1, i] = convert(T, cos(theta_wu)); out[2, i] = convert(T, sin(theta_wu))
+    end
+    return out
+end
+
+#####
+##### world fields (single_room.jl:21-40)
+#####
+
+function reward(env::BatchedSingleRoom{T, R}) where {T, R}
+    out = Vector{R}(undef, env.batch)
+    check(ccall((:rcw_reward_typed, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), env.handle, out)); out
+end
+function reward_float32(env::BatchedSingleRoom{T, Float32}) where {T}
     out = Vector{Float32}(undef, env.batch)
     check(ccall((:rcw_reward, librcw), Cint, (Ptr{Cvoid}, Ptr{Float32}), env.handle, out)); out
 end
@@ -134,13 +243,31 @@ function done(env::BatchedSingleRoom)
     out = Vector{UInt8}(undef, env.batch)
     check(ccall((:rcw_done, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}), env.handle, out)); out .!= 0
 end
-function player_position_wu(env::BatchedSingleRoom)
+function player_position_wu(env::BatchedSingleRoom{Float32})
     out = Matrix{Float32}(undef, 2, env.batch)
     check(ccall((:rcw_position, librcw), Cint, (Ptr{Cvoid}, Ptr{Float32}), env.handle, out)); out
+end
+function player_position_wu(env::BatchedSingleRoom{Float64})
+    out = Matrix{Float64}(undef, 2, env.batch)
+    check(ccall((:rcw_position64, librcw), Cint, (Ptr{Cvoid}, Ptr{Float64}), env.handle, out)); out
 end
 function player_direction_au(env::BatchedSingleRoom)
     out = Vector{Int32}(undef, env.batch)
     check(ccall((:rcw_direction, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}), env.handle, out)); out
+end
+function goal_position(env::BatchedSingleRoom)
+    out = Matrix{Int32}(undef, 2, env.batch)
+    check(ccall((:rcw_goal, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}), env.handle, out))
+    return [CartesianIndex(Int(out[1, b]), Int(out[2, b])) for b in 1:env.batch]
+end
+function episode(env::BatchedSingleRoom)
+    out = Vector{UInt32}(undef, env.batch)
+    check(ccall((:rcw_episode, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt32}), env.handle, out)); out
+end
+# per-agent sticky status: 0, -5 where the reference would have raised BoundsError, -2 for an invalid device action
+function status(env::BatchedSingleRoom)
+    out = Vector{Int32}(undef, env.batch)
+    check(ccall((:rcw_status, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}), env.handle, out)); out
 end
 # tile_map as B BitArray{3}(2, H, W): the library hands back `.chunks` verbatim
 function tile_maps(env::BatchedSingleRoom)
@@ -156,11 +283,187 @@ function tile_maps(env::BatchedSingleRoom)
     end
 end
 
+# world.ray_stop_position_tu / ray_hit_dimension / ray_distance_wu / ray_directions_wu (single_room.jl:29-31,39)
+# of agents first+1 : first+count (0-based `first`, as in the C ABI)
+function rays(env::BatchedSingleRoom{Float32}; first::Integer = 0, count::Integer = env.batch - first)
+    N = Int(env.config.num_rays)
+    stop = Array{Int64, 3}(undef, 2, N, count); dim = Matrix{Int64}(undef, N, count)
+    dist = Matrix{Float32}(undef, N, count); dirs = Array{Float32, 3}(undef, 2, N, count)
+    check(ccall((:rcw_rays, librcw), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Float32}, Ptr{Float32}),
+                env.handle, first, count, stop, dim, dist, dirs))
+    return (ray_stop_position_tu = stop, ray_hit_dimension = dim, ray_distance_wu = dist, ray_directions_wu = dirs)
+end
+function rays(env::BatchedSingleRoom{Float64}; first::Integer = 0, count::Integer = env.batch - first)
+    N = Int(env.config.num_rays)
+    stop = Array{Int64, 3}(undef, 2, N, count); dim = Matrix{Int64}(undef, N, count)
+    dist = Matrix{Float64}(undef, N, count); dirs = Array{Float64, 3}(undef, 2, N, count)
+    check(ccall((:rcw_rays64, librcw), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+                env.handle, first, count, stop, dim, dist, dirs))
+    return (ray_stop_position_tu = stop, ray_hit_dimension = dim, ray_distance_wu = dist, ray_directions_wu = dirs)
+end
+
+# directions_wu (single_room.jl:28) and the (direction, ray) table the kernels use: (N, 5, nd)
+function directions_wu(env::BatchedSingleRoom{Float32})
+    out = Matrix{Float32}(undef, 2, env.config.num_directions)
+    check(ccall((:rcw_direction_table, librcw), Cint, (Ptr{Cvoid}, Ptr{Float32}), env.handle, out)); out
+end
+function directions_wu(env::BatchedSingleRoom{Float64})
+    out = Matrix{Float64}(undef, 2, env.config.num_directions)
+    check(ccall((:rcw_direction_table64, librcw), Cint, (Ptr{Cvoid}, Ptr{Float64}), env.handle, out)); out
+end
+function ray_table(env::BatchedSingleRoom{Float32})
+    out = Array{Float32, 3}(undef, env.config.num_rays, 5, env.config.num_directions)
+    check(ccall((:rcw_ray_table, librcw), Cint, (Ptr{Cvoid}, Ptr{Float32}), env.handle, out)); out
+end
+function ray_table(env::BatchedSingleRoom{Float64})
+    out = Array{Float64, 3}(undef, env.config.num_rays, 5, env.config.num_directions)
+    check(ccall((:rcw_ray_table64, librcw), Cint, (Ptr{Cvoid}, Ptr{Float64}), env.handle, out)); out
+end
+
+#####
+##### images
+#####
+
 # Device pointer of the observation batch (aliased, stable): for AMDGPU.jl users
 #   unsafe_wrap(ROCArray{UInt32,3}, Ptr{UInt32}(ptr), (H_cam, N, B))
 function camera_view_device_ptr(env::BatchedSingleRoom)
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:rcw_obs_device_ptr, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), env.handle, p)); p[]
+end
+# The host mirror, refreshed only if a step / reset happened since the last refresh (the SAME array every call)
+function camera_view(env::BatchedSingleRoom)
+    if env.stale
+        check(ccall((:rcw_obs_copy, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt32}, Int32, Int32),
+                    env.handle, env.camera_view, 0, env.batch))
+        env.stale = false
+    end
+    return env.camera_view
+end
+# Render into caller-owned device memory instead (double-buffered observations); C_NULL restores the library's buffer
+bind_obs!(env::BatchedSingleRoom, device_ptr::Ptr{Cvoid}) =
+    check(ccall((:rcw_bind_obs, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), env.handle, device_ptr))
+
+# env.top_view (single_room.jl:302; build with render_top_view = 1): (H*pu, W*pu, count) copied to host
+function top_view(env::BatchedSingleRoom; first::Integer = 0, count::Integer = env.batch - first)
+    c = env.config
+    out = Array{UInt32, 3}(undef, c.height_tile_map_tu * c.pu_per_tu, c.width_tile_map_tu * c.pu_per_tu, count)
+    check(ccall((:rcw_top_view_copy, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt32}, Int32, Int32), env.handle, out, first, count)); out
+end
+function top_view_device_ptr(env::BatchedSingleRoom)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rcw_top_view_device_ptr, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), env.handle, p)); p[]
+end
+function reward_device_ptr(env::BatchedSingleRoom)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rcw_reward_device_ptr, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), env.handle, p)); p[]
+end
+function done_device_ptr(env::BatchedSingleRoom)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rcw_done_device_ptr, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), env.handle, p)); p[]
+end
+
+# The compact per-column descriptor of the frames: height_line_pu (single_room.jl:408-411) and colour id by image column
+function columns(env::BatchedSingleRoom; first::Integer = 0, count::Integer = env.batch - first)
+    N = Int(env.config.num_rays)
+    h = Matrix{Int32}(undef, N, count); c = Matrix{UInt8}(undef, N, count)
+    check(ccall((:rcw_columns, librcw), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{UInt8}), env.handle, first, count, h, c))
+    return (height_line_pu = h, colour_id = c)
+end
+function columns_device_ptr(env::BatchedSingleRoom)
+    h = Ref{Ptr{Cvoid}}(C_NULL); c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rcw_columns_device_ptr, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}), env.handle, h, c))
+    return (h[], c[])
+end
+# descriptors (device pointers) -> frames (device pointer), with this handle's colours: the receiving side of a gather
+expand_columns!(env::BatchedSingleRoom, height_line_pu_device::Ptr{Int32}, colour_id_device::Ptr{UInt8}, count::Integer,
+                frames_device::Ptr{Cvoid}) =
+    check(ccall((:rcw_expand_columns, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+                env.handle, height_line_pu_device, colour_id_device, count, frames_device))
+
+#####
+##### streams, device memory, timing, introspection
+#####
+
+set_stream!(env::BatchedSingleRoom, hip_stream::Ptr{Cvoid}) =
+    check(ccall((:rcw_set_stream, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), env.handle, hip_stream))
+function get_stream(env::BatchedSingleRoom)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rcw_get_stream, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), env.handle, p)); p[]
+end
+function device_malloc(env::BatchedSingleRoom, bytes::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rcw_device_malloc, librcw), Cint, (Ptr{Cvoid}, UInt64, Ref{Ptr{Cvoid}}), env.handle, bytes, p)); p[]
+end
+device_free(env::BatchedSingleRoom, p::Ptr{Cvoid}) =
+    check(ccall((:rcw_device_free, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), env.handle, p))
+memcpy_to_host!(env::BatchedSingleRoom, dst::Array, src_device::Ptr{Cvoid}) =
+    check(ccall((:rcw_memcpy_to_host, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, UInt64),
+                env.handle, dst, src_device, sizeof(dst)))
+
+timer_start(env::BatchedSingleRoom) = check(ccall((:rcw_timer_start, librcw), Cint, (Ptr{Cvoid},), env.handle))
+function timer_stop(env::BatchedSingleRoom)
+    ms = Ref{Float32}(0)
+    check(ccall((:rcw_timer_stop, librcw), Cint, (Ptr{Cvoid}, Ref{Float32}), env.handle, ms)); ms[]
+end
+profile!(env::BatchedSingleRoom, enable::Bool) =
+    check(ccall((:rcw_profile, librcw), Cint, (Ptr{Cvoid}, Int32), env.handle, enable ? 1 : 0))
+function profile_read(env::BatchedSingleRoom)
+    c = Ref{Float32}(0); t = Ref{Float32}(0); f = Ref{Float32}(0); n = Ref{Int32}(0)
+    check(ccall((:rcw_profile_read, librcw), Cint, (Ptr{Cvoid}, Ref{Float32}, Ref{Float32}, Ref{Float32}, Ref{Int32}),
+                env.handle, c, t, f, n))
+    return (cast_ms = c[], top_view_ms = t[], fill_ms = f[], steps = n[])
+end
+function batch(env::BatchedSingleRoom)
+    n = Ref{Int32}(0)
+    check(ccall((:rcw_batch, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, n)); Int(n[])
+end
+function get_config(env::BatchedSingleRoom)
+    cfg = RcwConfig()
+    check(ccall((:rcw_get_config, librcw), Cint, (Ptr{Cvoid}, Ref{RcwConfig}), env.handle, cfg)); cfg
+end
+function device_name(env::BatchedSingleRoom)
+    buf = Vector{UInt8}(undef, 256)
+    check(ccall((:rcw_device_name, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32), env.handle, buf, length(buf)))
+    return unsafe_string(pointer(buf))
+end
+
+#####
+##### multi-GPU: one process (or task) per GPU, agents sharded by rank; the observation gather over RCCL
+#####
+# rank 0 makes the id and ships its 128 bytes to the other ranks (Distributed.jl, MPI.jl, a file — caller's choice)
+function comm_unique_id()
+    id = Vector{UInt8}(undef, RCW_UNIQUE_ID_BYTES)
+    check(ccall((:rcw_comm_unique_id, librcw), Cint, (Ptr{Cvoid},), id)); id
+end
+comm_init!(env::BatchedSingleRoom, unique_id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(ccall((:rcw_comm_init, librcw), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32), env.handle, unique_id, rank, world))
+comm_destroy!(env::BatchedSingleRoom) = check(ccall((:rcw_comm_destroy, librcw), Cint, (Ptr{Cvoid},), env.handle))
+function comm_info(env::BatchedSingleRoom)
+    r = Ref{Int32}(0); w = Ref{Int32}(0)
+    check(ccall((:rcw_comm_info, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), env.handle, r, w))
+    return (rank = Int(r[]), world = Int(w[]))
+end
+# all-gather of the compact descriptors into caller-owned device memory (B*world columns each)
+gather_columns!(env::BatchedSingleRoom, height_line_pu_all_device::Ptr{Int32}, colour_id_all_device::Ptr{UInt8}) =
+    check(ccall((:rcw_gather_columns, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{UInt8}),
+                env.handle, height_line_pu_all_device, colour_id_all_device))
+# the GLOBAL observation batch (H_cam, N, B*world) into caller-owned device memory
+gather_observations!(env::BatchedSingleRoom, frames_all_device::Ptr{Cvoid}; mode::Int32 = RCW_GATHER_COLUMNS) =
+    check(ccall((:rcw_gather_observations, librcw), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}), env.handle, mode, frames_all_device))
+# ... and as a host Array, through a device buffer the binding keeps (what a learner on rank 0 would read)
+function gather_observations(env::BatchedSingleRoom; mode::Int32 = RCW_GATHER_COLUMNS)
+    world = comm_info(env).world
+    world >= 1 || throw(ArgumentError("comm_init! first"))
+    c = env.config
+    out = Array{UInt32, 3}(undef, c.height_camera_view_pu, c.num_rays, env.batch * world)
+    if env.gather_frames != env.batch * world
+        env.gather_buffer != C_NULL && device_free(env, env.gather_buffer)
+        env.gather_buffer = device_malloc(env, sizeof(out))
+        env.gather_frames = env.batch * world
+    end
+    gather_observations!(env, env.gather_buffer; mode = mode)
+    memcpy_to_host!(env, out, env.gather_buffer)
+    return out
 end
 
 #####
@@ -169,12 +472,7 @@ end
 
 RLBase.StateStyle(env::RCW.RLBaseEnv{E}) where {E <: BatchedSingleRoom} = RLBase.Observation{Any}()
 RLBase.state_space(env::RCW.RLBaseEnv{E}, ::RLBase.Observation) where {E <: BatchedSingleRoom} = nothing
-function RLBase.state(env::RCW.RLBaseEnv{E}, ::RLBase.Observation) where {E <: BatchedSingleRoom}
-    e = env.env
-    check(ccall((:rcw_obs_copy, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt32}, Int32, Int32),
-                e.handle, e.camera_view, 0, e.batch))
-    return e.camera_view            # the same Array every call, as in the reference (aliasing)
-end
+RLBase.state(env::RCW.RLBaseEnv{E}, ::RLBase.Observation) where {E <: BatchedSingleRoom} = camera_view(env.env)
 RLBase.reset!(env::RCW.RLBaseEnv{E}) where {E <: BatchedSingleRoom} = RCW.reset!(env.env)
 RLBase.action_space(env::RCW.RLBaseEnv{E}) where {E <: BatchedSingleRoom} = Base.OneTo(NUM_ACTIONS)
 (env::RCW.RLBaseEnv{E})(action) where {E <: BatchedSingleRoom} = RCW.act!(env.env, action)
