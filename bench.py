@@ -52,13 +52,9 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(kw, batch_hint, target_seconds=12.0):
-    """Time the CPU oracle (OpenMP over agents on the usable host cores) on a bounded sample."""
-    from oracle import oracle as O
-
-    threads = usable_cores()
+def _time_oracle(O, kw, agents, threads, target_seconds):
+    """env-steps/s of the CPU oracle with `threads` OpenMP threads on `agents` agents, for about target_seconds."""
     O.set_num_threads(threads)
-    agents = min(batch_hint, 32 * threads)
     orc = O.OracleBatch(agents, seed=0, auto_reset=1, out_of_bounds=0, **kw)
     rng = np.random.default_rng(0)
     acts = rng.integers(1, 5, (64, agents)).astype(np.uint8)
@@ -74,13 +70,28 @@ def cpu_baseline(kw, batch_hint, target_seconds=12.0):
         orc.step(acts[s & 63])
     dt = time.perf_counter() - t0
     orc.close()
+    return agents * steps / dt, steps, dt
+
+
+def cpu_baseline(kw, batch_hint, target_seconds=10.0):
+    """Time the CPU oracle on a bounded sample of the same workload: (i) ONE thread — what the single-threaded
+    reference's own loop corresponds to — and (ii) OpenMP over agents on all usable host cores."""
+    from oracle import oracle as O
+
+    threads = usable_cores()
+    one, steps1, dt1 = _time_oracle(O, kw, min(batch_hint, 32), 1, 0.6 * target_seconds)
+    agents = min(batch_hint, 32 * threads)
+    allc, steps, dt = _time_oracle(O, kw, agents, threads, target_seconds)
     return {
-        "value": agents * steps / dt,
+        "value": allc,
         "unit": "env-steps/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{agents} agents x {steps} steps of the same workload (C restatement of the reference "
-                  f"camera path incl. the frame fill, OpenMP over agents, {dt:.1f} s)",
+        "single_thread": one,
+        "all_cores": allc,
+        "sample": f"all cores: {agents} agents x {steps} steps ({dt:.1f} s, OpenMP over agents, {threads} threads); "
+                  f"single thread: {min(batch_hint, 32)} agents x {steps1} steps ({dt1:.1f} s); same workload, C restatement "
+                  f"of the reference camera path incl. the frame fill",
     }
 
 
@@ -245,6 +256,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": ("profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE of the fill kernel from separate "
+                                   "rocprofv3 --pmc passes of this command, committed; not re-measured in this run"
+                                   if traffic is not None else None),
                 "kernel": "rcw_fill256_kernel" if Hc == 256 else "rcw_fill_any_kernel",
                 "bytes_per_launch": bytes_per_launch,
                 "launch_ms": fill_ms,

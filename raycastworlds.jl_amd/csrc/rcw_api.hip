@@ -546,6 +546,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // cast kernel: two view columns per lane (measured best at 4096 x 256), 64..256 threads per agent
     { const int lanes = (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
     if (const char* v = std::getenv("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
+    d.cast_ballot = 0;
+    if (const char* v = std::getenv("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
     // tuning knobs for development runs only
     if (const char* v = std::getenv("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
     if (const char* v = std::getenv("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;

@@ -236,6 +236,54 @@ __device__ __forceinline__ RayHit<T> cast_ray(const uint8_t* tb, int H, int W, T
     return r;
 }
 
+// The march north_star words literally: a wave-uniform loop bound resolved by ballot.  Every lane of the wavefront
+// iterates until the LAST ray of the wavefront has hit (`__ballot(still marching) != 0`), finished lanes carrying their
+// state through selects, so there is no divergent branch at all.  Same results as cast_ray, bit for bit; kept as a
+// measured alternative (cfg.-independent development switch RCW_CAST_MARCH=ballot, profiles/r02_cast_march_cfg5.txt):
+// the exec-masked `break` of cast_ray runs the same number of iterations (the wavefront's longest ray) with fewer
+// instructions per iteration, because the hardware's exec mask does for free what the selects do explicitly.
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__device__ __forceinline__ RayHit<T> cast_ray_ballot(const uint8_t* tb, int H, int W, T x, T y, T dx, T dy, T ddx, T ddy)
+{
+    const int i0 = (int)rfloor(x) + 1;
+    const int j0 = (int)rfloor(y) + 1;
+    const bool neg_x = dx < (T)0, neg_y = dy < (T)0;
+    const int si = neg_x ? -1 : 1;
+    const int tj = neg_y ? -H : H;
+    const T fx = neg_x ? x - (T)(i0 - 1) : (T)i0 - x;
+    const T fy = neg_y ? y - (T)(j0 - 1) : (T)j0 - y;
+    T sx = fx * ddx, sy = fy * ddy;
+    int t = (i0 - 1) + H * (j0 - 1);
+    const unsigned last = (unsigned)(H * W - 1);
+    const int cap = H + W;
+    RayHit<T> r;
+    r.dim = 0; r.dist = (T)0; r.bits = 0u;
+    int n = 0;
+    bool marching = true;
+    while (__ballot(marching) != 0ull) {
+        const unsigned tc = (unsigned)t < last ? (unsigned)t : last;
+        const uint32_t bits = tb[tc];
+        const bool stop = bits != 0u || n >= cap;
+        if (marching) r.bits = bits;
+        marching = marching && !stop;
+        n += marching ? 1 : 0;
+        const bool xf = TIE_LE ? (sx <= sy) : (sx < sy);
+        const T nx = sx + ddx, ny = sy + ddy;
+        if (DIST_PRE) r.dist = marching ? (xf ? sx : sy) : r.dist;
+        sx = (marching && xf) ? nx : sx;
+        sy = (marching && !xf) ? ny : sy;
+        t += marching ? (xf ? si : tj) : 0;
+        r.dim = marching ? (xf ? 1 : 2) : r.dim;
+    }
+    r.oob = r.bits == 0u || (unsigned)t > last;
+    if (!DIST_PRE) {
+        const T d1 = sx - ddx, d2 = sy - ddy;
+        r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : (T)0);
+    }
+    r.t = t;
+    return r;
+}
+
 // ---- column height  SR:404-411 ------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ int height_line_pu(const RcwDev& p, T dist, T dot)
@@ -345,7 +393,8 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         const T dx = tab[i], dy = tab[p.N + i];
         const T ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
         const T dot = tab[4 * p.N + i];
-        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+        const RayHit<T> r = p.cast_ballot ? cast_ray_ballot<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy)
+                                          : cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu<T>(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension

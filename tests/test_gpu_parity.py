@@ -573,3 +573,22 @@ def test_top_view_in_place_fallback(rcw, oracle):
             env.clear_error(); orc.clear_status()
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after steps {kw}")
         env.close()
+
+
+def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
+    """The ballot-bounded march (the form north_star words; development switch RCW_CAST_MARCH=ballot, measured against
+    the shipped exec-masked march in profiles/) is the same function: bit-exact at the deep-march config and under
+    every unpinned switch."""
+    monkeypatch.setenv("RCW_CAST_MARCH", "ballot")
+    rng = np.random.default_rng(12)
+    env, orc = _make(rcw, oracle, 16, seed=9, **CFG5)
+    _rollout(rcw, env, orc, 30, rng, check_every=10, rays_every=10)
+    env.close()
+    for tie in (0, 1):
+        for dist in (0, 1):
+            env, orc = _make(rcw, oracle, 16, seed=5, dda_tie_break=tie, dda_distance=dist, **CFG1)
+            _rollout(rcw, env, orc, 30, rng, check_every=10, rays_every=10)
+            env.close()
+    env, orc = _make(rcw, oracle, 8, seed=3, T="Float64", **CFG2)
+    _rollout(rcw, env, orc, 20, rng, check_every=10, rays_every=10)
+    env.close()

@@ -1,21 +1,56 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun) at the end of a round: GPU tests, the bench line, and the rocprofv3
-# evidence for profiles/ (kernel stats + separate WRITE_SIZE / FETCH_SIZE passes).  Everything lands under
-# gpurun_out/<tag>_*; tools/collect_profiles.py then copies the summaries into profiles/.
-#   usage: tools/gpu_round.sh r02
+# evidence for profiles/ (kernel stats + separate WRITE_SIZE / FETCH_SIZE passes; top view; cast kernel at cfg-5).
+# Everything lands under gpurun_out/<tag>_*; tools/collect_profiles.py then copies the summaries into profiles/.
+#   usage: tools/gpu_round.sh r02 [notests]
 set -o pipefail
 tag=${1:-rXX}
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -2 gpurun_out/${tag}_pytest_gpu.log
-timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; cut -c1-160 gpurun_out/${tag}_bench.json
-rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch
+stop_if_killed() { if [ "$1" -eq 124 ] || [ "$1" -eq 137 ]; then echo "step '$2' timed out ($1): stopping"; exit "$1"; fi; }
+
+if [ "$2" != "notests" ]; then
+  timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?; tail -2 gpurun_out/${tag}_pytest_gpu.log; stop_if_killed $rc pytest
+fi
+timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; rc=$?; cut -c1-160 gpurun_out/${tag}_bench.json; stop_if_killed $rc bench
+rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_top_stats gpurun_out/${tag}_top_pmc_write gpurun_out/${tag}_cfg5_*
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_stats.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc_write -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1
+prof() {  # prof <outdir> <log> <rocprof args...> -- <bench args...>
+  local out=$1 log=$2; shift 2
+  local pre=() ; while [ "$1" != "--" ]; do pre+=("$1"); shift; done; shift
+  timeout -k 10 300 rocprofv3 "${pre[@]}" --output-format csv -d $R/gpurun_out/$out -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/$log 2>&1
+  local rc=$?; stop_if_killed $rc "$out"; return $rc
+}
+# --- headline workload (cfg2): kernel stats + HBM traffic passes
+prof ${tag}_stats ${tag}_stats.log --kernel-trace --stats --
+prof ${tag}_pmc_write ${tag}_pmc_write.log --pmc WRITE_SIZE --kernel-trace -- --steps 20 --warmup 2
+prof ${tag}_pmc_fetch ${tag}_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --steps 20 --warmup 2
+# --- top view kernel (opt-in): kernel stats + bytes written
+prof ${tag}_top_stats ${tag}_top_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
+prof ${tag}_top_pmc_write ${tag}_top_pmc_write.log --pmc WRITE_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
+prof ${tag}_top_pmc_sq ${tag}_top_pmc_sq.log --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -- --top-view --steps 20 --warmup 2
+# --- cast kernel at cfg-5 (32x32 map, 1024 columns: 60-step rays), exec-masked march vs ballot-bounded march
+for march in exec ballot; do
+  export RCW_CAST_MARCH=$march
+  prof ${tag}_cfg5_${march}_stats ${tag}_cfg5_${march}_stats.log --kernel-trace --stats -- --workload cfg5 --steps 30 --warmup 3
+  prof ${tag}_cfg5_${march}_sq ${tag}_cfg5_${march}_sq.log --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- --workload cfg5 --steps 10 --warmup 2
+  prof ${tag}_cfg5_${march}_lanes ${tag}_cfg5_${march}_lanes.log --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU --kernel-trace -- --workload cfg5 --steps 10 --warmup 2
+done
+unset RCW_CAST_MARCH
 cd $R
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_write.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_fetch FETCH_SIZE | tee gpurun_out/${tag}_fetch.txt
+python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_top_write.txt
 cp gpurun_out/${tag}_stats/*/*_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
+cp gpurun_out/${tag}_top_stats/*/*_kernel_stats.csv gpurun_out/${tag}_top_kernel_stats.csv
+for march in exec ballot; do cp gpurun_out/${tag}_cfg5_${march}_stats/*/*_kernel_stats.csv gpurun_out/${tag}_cfg5_${march}_kernel_stats.csv; done
+: > gpurun_out/${tag}_top_sq.txt
+for c in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT; do python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_sq $c rcw_top >> gpurun_out/${tag}_top_sq.txt; done
+for march in exec ballot; do
+  : > gpurun_out/${tag}_cfg5_${march}_sq.txt
+  for c in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE; do python3 tools/pmc_summary.py gpurun_out/${tag}_cfg5_${march}_sq $c rcw_cast >> gpurun_out/${tag}_cfg5_${march}_sq.txt; done
+  for c in SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU; do python3 tools/pmc_summary.py gpurun_out/${tag}_cfg5_${march}_lanes $c rcw_cast >> gpurun_out/${tag}_cfg5_${march}_sq.txt; done
+done
+grep -h "rcw_" gpurun_out/${tag}_cfg5_*_kernel_stats.csv | cut -c1-200 | head -8
+echo "round script done"
