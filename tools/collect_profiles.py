@@ -27,5 +27,45 @@ json.dump({"workload": "cfg2", "batch": 4096, "kernel": "rcw_fill256_kernel", "w
            "fetch_bytes_per_launch_raw": int(F * 1024), "traffic_bytes_per_launch": int(W * 1024) + 2 * int(F * 1024),
            "note": "traffic = WRITE_SIZE + 2 x FETCH_SIZE (gfx950 FETCH correction, upper bound for narrow gathers)",
            "source": f"profiles/{tag}_pmc_summary.txt"}, open("profiles/pmc_traffic.json", "w"), indent=1)
+# ---- top view kernel (opt-in): kernel stats, bytes written, SQ counters
+import os
+if os.path.exists(f"gpurun_out/{tag}_top_kernel_stats.csv"):
+    rows = list(csv.reader(open(f"gpurun_out/{tag}_top_kernel_stats.csv")))
+    csv.writer(open(f"profiles/{tag}_top_view_kernel_stats.csv", "w")).writerows([rows[0]] + [[r[0][:160]] + r[1:] for r in rows[1:]])
+    tw = open(f"gpurun_out/{tag}_top_write.txt").read()
+    sq = open(f"gpurun_out/{tag}_top_sq.txt").read()
+    top = [r for r in rows[1:] if "rcw_top_view_kernel" in r[0]][0]
+    avg_us = float(top[3]) / 1e3
+    TW = float(re.search(r"rcw_top_view_kernel\s+WRITE_SIZE.*?mean=\s*([\d.]+)", tw).group(1))
+    open(f"profiles/{tag}_top_view_summary.txt", "w").write(
+        "rcw_top_view_kernel (update_top_view! SR:446-483, opt-in), cfg2 + pu_per_tu 32: 4096 agents x 256 x 256 px, 1 MI355X\n"
+        "commands: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --top-view --steps 60 --warmup 5\n"
+        "          rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --top-view --steps 20 --warmup 2\n"
+        "          rocprofv3 --pmc SQ_... --kernel-trace -- (same)\n\n"
+        f"kernel stats: avg {avg_us:.1f} us over {top[1]} dispatches (min {float(top[5]) / 1e3:.1f}, max {float(top[6]) / 1e3:.1f})\n"
+        f"algorithmic bytes per launch: 4 * 256 * 256 * 4096 = 1,073,741,824 B -> {1073741824 / avg_us / 1e6:.2f} TB/s = "
+        f"{1073741824 / avg_us / 1e6 / 8 * 100:.1f} % of the 8 TB/s HBM peak\n"
+        f"WRITE_SIZE per launch: {TW:,.1f} KiB vs algorithmic 1,048,576 KiB (+{(TW / 1048576 - 1) * 100:.2f} %): every pixel is written once\n\n" + tw + "\n" + sq)
+# ---- cast kernel at cfg-5: exec-masked march (shipped) vs ballot-bounded march (RCW_CAST_MARCH=ballot)
+if os.path.exists(f"gpurun_out/{tag}_cfg5_exec_sq.txt"):
+    out = ["rcw_cast_kernel at cfg-5 (SingleRoom 32x32, 1024 columns, 8192 agents: rays up to 60 tile steps), 1 MI355X\n"
+           "exec-masked march (shipped: per-lane `break`, the hardware exec mask retires finished lanes) vs ballot-bounded march\n"
+           "(RCW_CAST_MARCH=ballot: wave-uniform loop bound via __ballot, finished lanes carried through selects)\n"
+           "commands: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --workload cfg5 --steps 30 --warmup 3\n"
+           "          rocprofv3 --pmc <SQ counters> --kernel-trace -- python3 bench.py --no-cpu-baseline --workload cfg5 --steps 10 --warmup 2\n"
+           "per dispatch, summed over the 8 XCDs; SQ_*_CYCLES count quad-cycles\n"]
+    for march in ("exec", "ballot"):
+        rows = list(csv.reader(open(f"gpurun_out/{tag}_cfg5_{march}_kernel_stats.csv")))
+        cast = [r for r in rows[1:] if "rcw_cast_kernel" in r[0]][0]
+        sq = open(f"gpurun_out/{tag}_cfg5_{march}_sq.txt").read()
+        v = {m.group(1): float(m.group(2)) for m in re.finditer(r"rcw_cast_kernel\s+(\w+)\s+dispatches=.*?mean=\s*([\d.]+)", sq)}
+        lane = v.get("SQ_THREAD_CYCLES_VALU", 0) / max(v.get("SQ_ACTIVE_INST_VALU", 1) * 64, 1)
+        out.append(f"\n== {march}: kernel avg {float(cast[3]) / 1e3:.1f} us (min {float(cast[5]) / 1e3:.1f}, max {float(cast[6]) / 1e3:.1f}), "
+                   f"{v.get('SQ_INSTS_VALU', 0) / v.get('SQ_WAVES', 1):.0f} VALU instructions per wavefront, "
+                   f"waiting {v.get('SQ_WAIT_ANY', 0) / max(v.get('SQ_WAVE_CYCLES', 1), 1) * 100:.0f} % of wave cycles, "
+                   f"active lanes per VALU instruction {lane * 100:.1f} %\n" + sq)
+    open(f"profiles/{tag}_cast_march_cfg5.txt", "w").write("".join(out))
+if os.path.exists("gpurun_out/rccl_world1.json"):
+    shutil.copy("gpurun_out/rccl_world1.json", f"profiles/{tag}_rccl_world1.json")
 b = json.load(open(f"profiles/{tag}_bench.json"))
 print(tag, "value", round(b["value"]), "fill frac", round(b["roofline"]["frac"], 4), "step frac", round(b["roofline"]["whole_step"]["frac"], 4))
