@@ -529,10 +529,10 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 2;
     if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;
     if (!cfg->render_top_view) d.top_lds = 0;
-    {   // persistent grid: as many 8-wavefront workgroups per CU as waves (32) and LDS allow
+    {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
         const size_t lds = rcw_top_view_lds_bytes(d);
         int per_cu = lds ? (int)((160 * 1024) / lds) : 4;
-        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);   // 3 x 8 wavefronts: what the kernel's register use admits (4 measured no faster)
         d.top_grid = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     }
     d.top_debug = 0;

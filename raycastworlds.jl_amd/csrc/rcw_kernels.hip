@@ -833,10 +833,15 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
         // All lanes stay in the loop until the longest line of the wavefront is done (a lane past its own end
         // offers -1 to its right neighbour), so the neighbour exchange always reads a live lane.  No branch in
         // the body: a lane with nothing to draw ORs its bit into a private dummy word.
-        for (int k = 0; __ballot(k < n) != 0ull; ++k) {
+        // (the trip count is the wavefront's longest line: a scalar loop)
+        int nmax = n;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        for (int k = 0; k < nmax; ++k) {
             const int cur = k < n ? addr : -1;
             const int left = __builtin_amdgcn_update_dpp(-1, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0: -1
-            const bool draw = cur >= 0 && left != cur;
+            const bool draw = k < n && left != cur;
             uint32_t* const w = draw ? b.line + (cur >> 5) : dummy;
             __hip_atomic_fetch_or(w, 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             acc += b2;
@@ -900,43 +905,68 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
     if ((Ht & 255) == 0 && (pu & 3) == 0) {
         // One wavefront per image column (256 rows per pass), lanes along the contiguous rows, four pixels a lane:
         // they never straddle a tile.  What depends on the rows only (tile row, frame rows) is computed once per
-        // row block; what depends on the column only is wave-uniform (scalar unit).
+        // row block, what depends on the column's tile once per tile, the column itself is wave-uniform (scalar
+        // unit), and the overlay is skipped for a column none of whose 256 pixels carries a line or circle bit:
+        // per column and lane that leaves one LDS read, a bit-field extract, four selects and the store.
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         u32x4* out = reinterpret_cast<u32x4*>(img);
         const int vpc = Ht >> 2;
+        const int wpc = top_col_bits(p) >> 5;                               // plane words per (padded) column
+        const int step = kTopGroup / 64;                                    // columns between two of this wavefront's
+        const int ncols = (c_hi - c_lo - wave + step - 1) / step;           // wave-uniform trip count
+        auto overlay = [](uint32_t bits, int e, uint32_t colour, uint32_t under) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, e, 1);   // 0 or ~0
+            return (m & colour) | (~m & under);                             // v_bfi_b32
+        };
         for (int r0 = 0; r0 < Ht; r0 += 256) {
             const int ip0 = r0 + lane * 4;
             const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
             const bool first_row = ri == 0, last_row = ri + 3 == pu - 1;    // SR:364-365: the tile's frame rows
             const uint8_t* const tile_row = b.tb + ti;
-            const int word0 = ip0 >> 5, sh = ip0 & 31;
-            const int wpc = top_col_bits(p) >> 5;                           // plane words per (padded) column
-            int tj = c_lo / pu, rj = c_lo - tj * pu;                        // tile column / offset of column c_lo
-            tj = __builtin_amdgcn_readfirstlane(tj); rj = __builtin_amdgcn_readfirstlane(rj);
-            // this wavefront's columns: c_lo + wave, + 4, + 8, ...
-            rj += wave; while (rj >= pu) { rj -= pu; tj += 1; }
-            for (int jp0 = c_lo + wave; jp0 < c_hi; jp0 += kTopGroup / 64) {
-                const bool frame_col = rj == 0 || rj == pu - 1;              // SR:366-367
-                const uint32_t fill = tile_fill_colour(tile_row[p.H * tj]);
-                const uint32_t inner = frame_col ? grid_c : fill;
-                const uint32_t lb = b.line[jp0 * wpc + word0] >> sh;
-                const int cj = jp0 + 1 - jc0;
-                uint32_t cb = 0u;
-                if ((unsigned)cj <= (unsigned)box) cb = b.circ[cj * wpc + word0] >> sh;   // wave-uniform branch
-                u32x4 o;
-                o.x = first_row ? grid_c : inner;
-                o.y = inner;
-                o.z = inner;
-                o.w = last_row ? grid_c : inner;
-                if ((lb | cb) & 15u) {
-                    o.x = (cb & 1u) ? player_c : ((lb & 1u) ? ray_c : o.x);
-                    o.y = (cb & 2u) ? player_c : ((lb & 2u) ? ray_c : o.y);
-                    o.z = (cb & 4u) ? player_c : ((lb & 4u) ? ray_c : o.z);
-                    o.w = (cb & 8u) ? player_c : ((lb & 8u) ? ray_c : o.w);
+            const int sh = ip0 & 31;
+            int jp0 = c_lo + wave;
+            int tj = __builtin_amdgcn_readfirstlane(jp0 / pu);
+            int rj = jp0 - tj * pu;
+            const uint32_t* lp = b.line + jp0 * wpc + (ip0 >> 5);
+            u32x4* dst = out + (size_t)jp0 * vpc + (ip0 >> 2);
+            int tj_loaded = -1;
+            uint32_t fx = 0u, fy = 0u, fw = 0u;                             // the tile's pixels of this lane's four rows
+            // Four columns per trip: their plane words are read from LDS first, so that the stores that follow do
+            // not each wait for an LDS round trip (one dependent LDS read per store costs 6 % of the store rate).
+            constexpr int U = 4;
+            for (int c = 0; c < ncols; c += U) {
+                uint32_t words[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) words[u] = c + u < ncols ? lp[u * step * wpc] : 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c + u >= ncols) break;                               // wave-uniform
+                    if (tj != tj_loaded) {                                   // wave-uniform: a new tile column
+                        const uint32_t fill = tile_fill_colour(tile_row[p.H * tj]);
+                        fx = first_row ? grid_c : fill; fy = fill; fw = last_row ? grid_c : fill;
+                        tj_loaded = tj;
+                    }
+                    const bool frame_col = rj == 0 || rj == pu - 1;          // SR:366-367 (wave-uniform)
+                    u32x4 o;
+                    o.x = frame_col ? grid_c : fx;
+                    o.y = frame_col ? grid_c : fy;
+                    o.z = o.y;
+                    o.w = frame_col ? grid_c : fw;
+                    const uint32_t lb = __builtin_amdgcn_ubfe(words[u], sh, 4);
+                    if (__ballot(lb != 0u) != 0ull) {                        // some pixel of this column is on a ray line
+                        o.x = overlay(lb, 0, ray_c, o.x); o.y = overlay(lb, 1, ray_c, o.y);
+                        o.z = overlay(lb, 2, ray_c, o.z); o.w = overlay(lb, 3, ray_c, o.w);
+                    }
+                    if ((unsigned)(jp0 + 1 - jc0) <= (unsigned)box) {        // wave-uniform: a column of the circle's box
+                        const uint32_t cb = __builtin_amdgcn_ubfe(b.circ[(jp0 + 1 - jc0) * wpc + (ip0 >> 5)], sh, 4);
+                        o.x = overlay(cb, 0, player_c, o.x); o.y = overlay(cb, 1, player_c, o.y);
+                        o.z = overlay(cb, 2, player_c, o.z); o.w = overlay(cb, 3, player_c, o.w);
+                    }
+                    *dst = o;      // plain, not non-temporal: measured 224 vs 237 us for the kernel (the opposite of the camera fill)
+                    jp0 += step; dst += (size_t)step * vpc;
+                    rj += step; while (rj >= pu) { rj -= pu; tj += 1; }
                 }
-                u32x4* dst = out + (size_t)jp0 * vpc + (ip0 >> 2);
-                __builtin_nontemporal_store(o, dst);
-                rj += kTopGroup / 64; while (rj >= pu) { rj -= pu; tj += 1; }
+                lp += U * step * wpc;
             }
         }
     } else if ((Ht & 3) == 0) {
@@ -999,7 +1029,7 @@ __device__ __forceinline__ void draw_group_sync(int* counter, int target)
 }
 
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(kTopBlock, 8) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int role = threadIdx.x >> 8;        // 0: draw group, 1: store group (wave-uniform)
@@ -1011,35 +1041,36 @@ __global__ __launch_bounds__(kTopBlock, 8) void rcw_top_view_kernel(const RcwDev
     uint32_t* const bufs = lds + 4;
     if (threadIdx.x == 0) *counter = 0;
     lds_barrier();
-    // The schedule, one workgroup barrier per step.  Overlapped (two LDS buffers): in step s the draw group prepares
-    // and draws agent s while the store group stores agent s - 1.  Serial (image too large for two buffers): step
-    // h = 2 s + phase; the draw group draws, then both groups store one half each.
+    // The schedule, one workgroup barrier per step; the two groups run their own loops (separate code paths, so
+    // that the store group's instruction stream carries no wait for anything but its own LDS reads — in a shared
+    // loop the compiler's wait-count bookkeeping for the draw group's loads also drained the store group's stores
+    // once per agent).  Overlapped (two LDS buffers): in step h the draw group prepares and draws agent h while the
+    // store group stores agent h - 1.  Serial (image too large for two buffers): steps 2 s, 2 s + 1 draw, then store.
     const bool serial = p.top_lds == 2;
     const int steps = serial ? 2 * n : n + 1;
-    enum { NONE, DRAW, STORE };
-    int drawn = 0;
-    for (int h = 0; h < steps; ++h) {
-        int what = NONE, agent = 0, buf = 0, part = 2;
-        if (serial) {
-            agent = h >> 1;
-            if (h & 1) { what = STORE; part = role; }
-            else if (role == 0) what = DRAW;
-        } else {
-            if (role == 0) { agent = h; buf = h & 1; what = h < n ? DRAW : NONE; }
-            else           { agent = h - 1; buf = (h + 1) & 1; what = h >= 1 ? STORE : NONE; }
+    if (role == 0) {
+        int drawn = 0;
+        for (int h = 0; h < steps; ++h) {
+            const int agent = serial ? h >> 1 : h;
+            const int a = blockIdx.x + agent * G;
+            const bool on = agent < n && !(serial && (h & 1)) && (mask == nullptr || mask[a] != 0);
+            if (on) {
+                const TopBuf b = top_buf(p, bufs + (size_t)(serial ? 0 : agent & 1) * bw);
+                top_prepare(p, a, b, tid);
+                drawn += 1;
+                draw_group_sync(counter, 4 * drawn);
+                if (!(p.top_debug & 1)) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
+            }
+            lds_barrier();
         }
-        const int a = blockIdx.x + agent * G;
-        if (what != NONE && mask != nullptr && mask[a] == 0) what = NONE;
-        const TopBuf b = top_buf(p, bufs + (size_t)buf * bw);
-        if (what == DRAW) {
-            top_prepare(p, a, b, tid);
-            drawn += 1;
-            draw_group_sync(counter, 4 * drawn);
-            if (!(p.top_debug & 1)) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
-        } else if (what == STORE && !(p.top_debug & 2)) {
-            top_store(p, a, b, tid, part);
+    } else {
+        for (int h = 0; h < steps; ++h) {
+            const int agent = serial ? h >> 1 : h - 1;
+            const int a = blockIdx.x + agent * G;
+            const bool on = agent >= 0 && (!serial || (h & 1)) && (mask == nullptr || mask[a] != 0);
+            if (on && !(p.top_debug & 2)) top_store(p, a, top_buf(p, bufs + (size_t)(serial ? 0 : agent & 1) * bw), tid, 2);
+            lds_barrier();
         }
-        lds_barrier();
     }
 }
 

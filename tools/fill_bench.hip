@@ -70,6 +70,28 @@ __global__ __launch_bounds__(BLOCK) void fill_window(u32x4* out, size_t nvec, ui
     }
     for (; i < nvec; i += stride) { if (NT) __builtin_nontemporal_store(val, out + i); else out[i] = val; }
 }
+// G: the top view kernel's skeleton: persistent 512-thread WGs, threads 256..511 store frame after frame (wave w of
+// the group writes the 1 KiB columns w, w+4, ...), threads 0..255 only meet them at one barrier per frame
+template <bool NT, bool LDSREAD>
+__global__ __launch_bounds__(512) void fill_top_skeleton(u32x4* out, int vec_per_frame, int frames, uint32_t v)
+{
+    __shared__ uint32_t plane[2304];
+    const int role = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    if (LDSREAD) { for (int k = threadIdx.x; k < 2304; k += 512) plane[k] = v * k; __syncthreads(); }
+    for (int f = blockIdx.x; f < frames; f += gridDim.x) {
+        if (role == 1) {
+            u32x4* base = out + (size_t)f * vec_per_frame;
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int col = wave; col < vec_per_frame / 64; col += 4) {
+                u32x4 val = {v, v + 1, v + 2, v + 3};
+                if (LDSREAD) { const uint32_t w = plane[col * 9 + (lane >> 3)]; val.x ^= w; val.w += w >> 3; }
+                u32x4* dst = base + (size_t)col * 64 + lane;
+                if (NT) __builtin_nontemporal_store(val, dst); else *dst = val;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
 // Z: launch floor — a kernel that does nothing, at the cast kernel's grid shapes
 __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 12345) *p = 1; }
 // E: 1024-thread WG per frame
@@ -126,6 +148,15 @@ int main(int argc, char** argv)
         char nm[64];
         snprintf(nm, sizeof nm, "D persistent nt grid=%d", g);
         rep(nm, time_it([&](int i) { hipLaunchKernelGGL(fill_persistent<true>, dim3(g), dim3(256), 0, s, buf, vpf, frames, i); }, s, it));
+    }
+    for (int g : {768, 1024}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "G top skeleton nt grid=%d", g);
+        rep(nm, time_it([&](int i) { hipLaunchKernelGGL((fill_top_skeleton<true, false>), dim3(g), dim3(512), 0, s, buf, vpf, frames, i); }, s, it));
+        snprintf(nm, sizeof nm, "G top skeleton nt+lds grid=%d", g);
+        rep(nm, time_it([&](int i) { hipLaunchKernelGGL((fill_top_skeleton<true, true>), dim3(g), dim3(512), 0, s, buf, vpf, frames, i); }, s, it));
+        snprintf(nm, sizeof nm, "G top skeleton plain grid=%d", g);
+        rep(nm, time_it([&](int i) { hipLaunchKernelGGL((fill_top_skeleton<false, false>), dim3(g), dim3(512), 0, s, buf, vpf, frames, i); }, s, it));
     }
 #define RUNF(NT, BLOCK, UNROLL, G) { char nm[80]; snprintf(nm, sizeof nm, "F window %s block=%d unroll=%d grid=%d", NT ? "nt" : "plain", BLOCK, UNROLL, G); \
         rep(nm, time_it([&](int i) { hipLaunchKernelGGL((fill_window<NT, BLOCK, UNROLL>), dim3(G), dim3(BLOCK), 0, s, buf, nvec, i); }, s, it)); }

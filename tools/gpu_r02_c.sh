@@ -6,15 +6,10 @@ timeout -k 10 600 python -m pytest tests -m gpu -q -k "top_view or render_entry 
 rc=$?
 tail -3 gpurun_out/c_pytest.log
 if [ $rc -ne 0 ]; then echo "tests failed ($rc): not timing"; exit $rc; fi
-for dbg in 0 8 2 1 4; do
- for g in 1024; do
-  echo "== RCW_TOP_DEBUG=$dbg RCW_TOP_GRID=$g"
-  RCW_TOP_DEBUG=$dbg RCW_TOP_GRID=$g timeout -k 10 120 python bench.py --top-view --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/c_top.json 2> gpurun_out/c_top.err || { echo "failed"; tail -3 gpurun_out/c_top.err; exit 1; }
+run() {
+  timeout -k 10 120 python bench.py --top-view --steps 40 --warmup 5 --no-cpu-baseline "$@" > gpurun_out/c_top.json 2> gpurun_out/c_top.err || { echo "failed"; tail -3 gpurun_out/c_top.err; exit 1; }
   python3 -c "import json,sys; d=json.load(open('gpurun_out/c_top.json')); t=d['top_view']; print('top_view us', round(t['launch_ms']*1e3,1), 'GB/s', round(t['achieved']), 'frac', round(t['frac'],3))"
- done
-done
-for g in 2048; do
-  echo "== RCW_TOP_GRID=$g"
-  RCW_TOP_GRID=$g timeout -k 10 120 python bench.py --top-view --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/c_top.json 2> gpurun_out/c_top.err || { echo "failed"; tail -3 gpurun_out/c_top.err; exit 1; }
-  python3 -c "import json,sys; d=json.load(open('gpurun_out/c_top.json')); t=d['top_view']; print('top_view us', round(t['launch_ms']*1e3,1), 'GB/s', round(t['achieved']), 'frac', round(t['frac'],3))"
-done
+}
+for dbg in 0 1; do echo "== RCW_TOP_DEBUG=$dbg"; RCW_TOP_DEBUG=$dbg run; done
+for g in 768 896; do echo "== RCW_TOP_GRID=$g"; RCW_TOP_GRID=$g run; done
+echo "== cfg3"; run --workload cfg3 --steps 10
