@@ -934,6 +934,10 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
             // Four columns per trip: their plane words are read from LDS first, so that the stores that follow do
             // not each wait for an LDS round trip (one dependent LDS read per store costs 6 % of the store rate).
             constexpr int U = 4;
+            if (p.top_debug & 8) {      // development: the bare store stream of this path (no pixel logic, no LDS reads)
+                for (int c = 0; c < ncols; ++c) { const u32x4 o = {grid_c, grid_c, grid_c, grid_c}; *dst = o; dst += (size_t)step * vpc; }
+                continue;
+            }
             for (int c = 0; c < ncols; c += U) {
                 uint32_t words[U];
 #pragma unroll
