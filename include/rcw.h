@@ -73,7 +73,13 @@ extern "C" {
 
 /* The three choices inside the un-vendored dependencies that the reference's own tests
  * do not pin (DESIGN.md "parity unpinned").  They live here, in ONE
- * place, so a maintainer with a Julia toolchain can flip them without touching code. */
+ * place, so a maintainer with a Julia toolchain can flip them without touching code;
+ * tests/golden/discriminators.json holds poses where the two readings of each differ and
+ * julia/make_reference_fixtures.jl dumps what the real package computes for them.
+ * A fourth unpinned piece has no switch: the direction table (SR:65-69) is built with the C
+ * library's cos / sin, Julia uses its own implementations — both < 1 ulp in Float64, so a
+ * last-bit difference is possible (plausible for T = Float64, ~1e-8 per entry for Float32).
+ * rcw_set_direction_table[64] lets the caller hand over Julia's table. */
 #define RCW_DDA_TIE_X_FIRST_ON_LT 0  /* step in x when side_x <  side_y (default)          */
 #define RCW_DDA_TIE_X_FIRST_ON_LE 1  /* step in x when side_x <= side_y                    */
 #define RCW_DDA_DIST_SIDE_MINUS_DELTA 0 /* distance = side - delta after the step (default) */
