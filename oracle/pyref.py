@@ -95,8 +95,10 @@ class World:
     """SingleRoomWorld + the camera half of SingleRoom, one agent (SR:21-40, SR:241-256)."""
 
     def __init__(self, H=8, W=16, nd=128, radius=1 / 8, inc=1 / 8, fov=2 / 3, num_rays=512,
-                 camera_height=1.0, Hc=256, tie_le=False, dist_pre=False, normalize_divide=False, T=np.float32):
-        self.T = T                                   # the reference's world-unit type (SR:259); R stays Float32
+                 camera_height=1.0, Hc=256, tie_le=False, dist_pre=False, normalize_divide=False, T=np.float32,
+                 R=np.float32):
+        self.T = T                                   # the reference's world-unit type (SR:259)
+        self.R = R                                   # the reward type (SR:266): reward = zero(R), goal_reward = one(R) SR:81-82
         self.H, self.W, self.nd, self.N, self.Hc = H, W, nd, num_rays, Hc
         self.radius, self.inc, self.fov = self.T(radius), self.T(inc), self.T(fov)
         self.camh = self.T(camera_height)
@@ -118,7 +120,7 @@ class World:
         self.tile_map[GOAL][2][2] = True
         self.pos = (self.T(1.5), self.T(1.5))
         self.dir = 0
-        self.reward = np.float32(0)
+        self.reward = self.R(0)
         self.done = False
         self.camera_view = np.zeros((self.N, Hc), dtype=np.uint32)   # [k-1][row-1] == Julia [row, k]
 
@@ -129,7 +131,7 @@ class World:
         self.tile_map[GOAL][self.goal[0]][self.goal[1]] = True      # SR:122
         self.pos = (self.T(pos[0]), self.T(pos[1]))
         self.dir = int(d)
-        self.reward = np.float32(0)
+        self.reward = self.R(0)
         self.done = False
         self.cast_rays()
         self.update_camera_view()
@@ -148,15 +150,15 @@ class World:
             w = is_player_colliding(wall_map, new, self.radius, self.T)     # SR:163
             if g or w:
                 if g:
-                    self.reward, self.done = np.float32(1), True           # SR:166-168
+                    self.reward, self.done = self.R(1), True           # SR:166-168
                 else:
-                    self.reward, self.done = np.float32(0), False          # SR:170-171
+                    self.reward, self.done = self.R(0), False          # SR:170-171
             else:
                 self.pos = new                                      # SR:174
-                self.reward, self.done = np.float32(0), False
+                self.reward, self.done = self.R(0), False
         else:
             self.dir = turn_left(self.dir, self.nd) if action == 3 else turn_right(self.dir, self.nd)
-            self.reward, self.done = np.float32(0), False                  # SR:186-187
+            self.reward, self.done = self.R(0), False                  # SR:186-187
 
     def ray_fan(self):
         """SR:214-221: normalized ray directions for the current heading."""

@@ -525,9 +525,9 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
                          : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
     // the write-once kernel keeps two agents' bit planes in LDS (160 KiB per CU); larger images take the in-place kernel
     // (1: two buffers, drawing overlapped with storing; 2: one buffer, no overlap; 0: in-place kernel)
-    d.top_lds = 1;
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 2;
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;
+    d.top_lds = 1;                                             // try two buffers,
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 2; // then one,
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0; // then give up on LDS (the size depends on top_lds)
     if (!cfg->render_top_view) d.top_lds = 0;
     {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
         const size_t lds = rcw_top_view_lds_bytes(d);
@@ -986,6 +986,10 @@ int rcw_comm_destroy(rcw_handle* h)
     RCW_HIP(hipStreamSynchronize(h->stream));
     RCW_NCCL(g_rccl.CommDestroy((ncclComm_t)h->comm));
     h->comm = nullptr; h->comm_rank = 0; h->comm_world = 0;
+    // the gathered-descriptor scratch is sized by the world: a later rcw_comm_init may have another
+    if (h->d_gather_h) (void)hipFree(h->d_gather_h);
+    if (h->d_gather_c) (void)hipFree(h->d_gather_c);
+    h->d_gather_h = h->d_gather_c = nullptr;
     return RCW_OK;
 }
 

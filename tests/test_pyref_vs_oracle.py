@@ -182,3 +182,20 @@ def test_arbitrary_poses_two_restatements_agree(oracle, bits):
             np.testing.assert_array_equal(orc.camera_view[0], w.camera_view)
     finally:
         orc.close()
+
+
+@pytest.mark.parametrize("rt,R", [(1, np.float64), (2, np.int32), (3, np.int64)], ids=["Float64", "Int32", "Int64"])
+def test_reward_type_R(oracle, rt, R):
+    """R of SingleRoom(; R = ...) SR:266 in both restatements: reward = zero(R) / goal_reward = one(R) (SR:81-82),
+    element type included.  A walk into the goal, a turn, and back (the hand-derived dynamics case)."""
+    orc = oracle.OracleBatch(1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=16, reward_type=rt)
+    w = pyref.World(H=8, W=8, num_rays=16, R=R)
+    orc.set_state([[6, 5]], [[4.5, 4.5]], [0])
+    w.set_state((6, 5), (4.5, 4.5), 0)
+    seen = set()
+    for a in (1, 1, 1, 1, 3, 4, 1, 2, 1):
+        orc.step([a]); w.act(a)
+        assert orc.reward.dtype == R and type(w.reward) is R
+        assert orc.reward[0] == w.reward and bool(orc.done[0]) == w.done
+        seen.add((int(w.reward), w.done))
+    assert seen == {(0, False), (1, True)}
