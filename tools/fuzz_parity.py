@@ -3,7 +3,7 @@
 configurations (map size, columns, headings, field of view, radius, step, camera height, image
 height, world-unit type, the three unpinned switches, both BoundsError policies, auto-reset).
 
-    python tools/fuzz_parity.py [configs] [seed]
+    python tools/fuzz_parity.py [configs] [seed] [top]     # "top": every configuration renders the top view
 """
 import os
 import sys
@@ -18,6 +18,7 @@ from oracle import oracle as O
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+always_top = len(sys.argv) > 3 and sys.argv[3] == "top"
 fails = 0
 O.set_num_threads(8)
 for c in range(n_cfg):
@@ -34,18 +35,20 @@ for c in range(n_cfg):
               height_camera_view_pu=int(rng.choice([256, 64, 100, 37, 512])),
               dda_tie_break=int(rng.integers(0, 2)), dda_distance=int(rng.integers(0, 2)),
               normalize_mode=int(rng.integers(0, 2)), out_of_bounds=int(rng.integers(0, 2)),
-              auto_reset=bool(rng.integers(0, 2)), render_top_view=bool(rng.integers(0, 4) == 0),
-              pu_per_tu=int(rng.choice([4, 8, 13, 32])))
+              auto_reset=bool(rng.integers(0, 2)), render_top_view=bool(rng.integers(0, 4) == 0) or always_top,
+              pu_per_tu=int(rng.choice([4, 8, 13, 32, 40, 52] if always_top else [4, 8, 13, 32])))
+    R = str(rng.choice(["Float32", "Float64", "Int32", "Int64"]))
     B = int(rng.integers(1, 40))
     seed = int(rng.integers(0, 2**31))
     okw = {k: v for k, v in kw.items()}
     okw["auto_reset"] = int(kw["auto_reset"]); okw["render_top_view"] = int(kw["render_top_view"])
+    okw["reward_type"] = ["Float32", "Float64", "Int32", "Int64"].index(R)
     if T64:
         okw["world_unit_bits"] = 64
         for k in ("player_radius_wu", "position_increment_wu", "semi_field_of_view_wu", "camera_height_tile_wu"):
             okw[k + "_f64"] = float(kw[k])
     try:
-        env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, T="Float64" if T64 else "Float32", **kw)
+        env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, T="Float64" if T64 else "Float32", R=R, **kw)
         orc = O.OracleBatch(B, seed=seed, **okw)
         assert_state_equal(env, orc, rays=True, where="create")
         if rng.integers(0, 2):
@@ -88,7 +91,7 @@ for c in range(n_cfg):
         env.close(); orc.close()
     except Exception as e:   # noqa: BLE001
         fails += 1
-        print(f"config {c} FAILED: T64={T64} B={B} seed={seed} {kw}\n   {type(e).__name__}: {str(e)[:300]}")
+        print(f"config {c} FAILED: T64={T64} R={R} B={B} seed={seed} {kw}\n   {type(e).__name__}: {str(e)[:300]}")
         if fails >= 5:
             break
 print(f"{n_cfg} random configurations, {fails} mismatches")
