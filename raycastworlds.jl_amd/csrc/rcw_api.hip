@@ -548,6 +548,9 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = std::getenv("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
     d.cast_ballot = 0;
     if (const char* v = std::getenv("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
+    d.cast_table_lds = 0;
+    if (const char* v = std::getenv("RCW_CAST_TABLE"))   // only where tile bytes + 5 N table values fit the default 64 KiB
+        d.cast_table_lds = std::strcmp(v, "lds") == 0 && rcw_step_lds_bytes(d) + (size_t)RCW_TABLE_ROWS * N * h->real_size + 64 <= 64 * 1024 ? 1 : 0;
     // tuning knobs for development runs only
     if (const char* v = std::getenv("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
     if (const char* v = std::getenv("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;

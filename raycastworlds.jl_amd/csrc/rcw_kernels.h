@@ -32,6 +32,7 @@ struct RcwDev {
     int32_t fill_plain;      // 1: plain stores, 0: non-temporal
     int32_t cast_block;      // threads per agent in the cast kernel (multiple of 64, <= 256)
     int32_t cast_ballot;     // development only (RCW_CAST_MARCH=ballot): the ballot-bounded march instead of the exec-masked one
+    int32_t cast_table_lds;  // development only (RCW_CAST_TABLE=lds): stage the heading's ray-table slice in LDS first
     int64_t agent_id_offset;
     uint64_t seed;
     // state (SR:21-40), one entry per agent

@@ -389,6 +389,16 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
 
     // ---- phase 1: one lane per view column --------------------------------------------------
     const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * p.N;
+    if (p.cast_table_lds) {
+        // Development switch RCW_CAST_TABLE=lds: stage the heading's table slice (5 N values) in LDS first, as
+        // north_star words it, then read it back.  Every entry is used exactly once by exactly one lane, so the copy
+        // buys no reuse — measured against the direct, coalesced L2 read below (profiles/).
+        T* stab = reinterpret_cast<T*>(lds + ((HW + 15) / 16) * 4);
+        __syncthreads();
+        for (int k = tid; k < RCW_TABLE_ROWS * p.N; k += (int)blockDim.x) stab[k] = tab[k];
+        __syncthreads();
+        tab = stab;
+    }
     for (int i = tid; i < p.N; i += (int)blockDim.x) {                        // SR:220, SR:401
         const T dx = tab[i], dy = tab[p.N + i];
         const T ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
@@ -1085,6 +1095,11 @@ size_t rcw_step_lds_bytes(const RcwDev& p)
 {
     return (((size_t)p.H * p.W + 15) & ~(size_t)15);   // one byte per tile
 }
+// the cast kernel's LDS: the tile bytes (+ the heading's table slice under the RCW_CAST_TABLE=lds development switch)
+static size_t rcw_cast_lds_bytes(const RcwDev& p)
+{
+    return rcw_step_lds_bytes(p) + (p.cast_table_lds ? (size_t)RCW_TABLE_ROWS * p.N * (p.real64 ? 8 : 4) : 0);
+}
 
 hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
                            long long total_cols, const uint8_t* mask_dev, hipStream_t s)
@@ -1127,7 +1142,7 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
 hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
                            hipStream_t s)
 {
-    RCW_DISPATCH(rcw_cast_kernel, dim3(p.B), dim3(p.cast_block), rcw_step_lds_bytes(p), p, actions_dev, mask_dev);
+    RCW_DISPATCH(rcw_cast_kernel, dim3(p.B), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev);
     return hipGetLastError();
 }
 

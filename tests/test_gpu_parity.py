@@ -592,3 +592,14 @@ def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
     env, orc = _make(rcw, oracle, 8, seed=3, T="Float64", **CFG2)
     _rollout(rcw, env, orc, 20, rng, check_every=10, rays_every=10)
     env.close()
+
+
+def test_lds_staged_ray_table_gives_the_same_rays(rcw, oracle, monkeypatch):
+    """Development switch RCW_CAST_TABLE=lds (the heading's ray-table slice copied to LDS before use, as north_star
+    words it; measured against the shipped direct L2 read in profiles/): same results."""
+    monkeypatch.setenv("RCW_CAST_TABLE", "lds")
+    rng = np.random.default_rng(14)
+    for kw in (CFG2, CFG5, dict(T="Float64", **CFG1), dict(num_rays=100, height_tile_map_tu=9, width_tile_map_tu=7)):
+        env, orc = _make(rcw, oracle, 12, seed=4, auto_reset=True, **kw)
+        _rollout(rcw, env, orc, 25, rng, check_every=5, rays_every=5)
+        env.close()

@@ -38,6 +38,11 @@ for march in exec ballot; do
   prof ${tag}_cfg5_${march}_lanes ${tag}_cfg5_${march}_lanes.log --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU --kernel-trace -- --workload cfg5 --steps 10 --warmup 2
 done
 unset RCW_CAST_MARCH
+# --- cast kernel with the heading's table slice staged in LDS first (RCW_CAST_TABLE=lds) vs the direct L2 read
+for w in cfg2 cfg5; do
+  RCW_CAST_TABLE=lds prof ${tag}_${w}_tablelds_stats ${tag}_${w}_tablelds_stats.log --kernel-trace --stats -- --workload $w --steps 30 --warmup 3
+  prof ${tag}_${w}_tablel2_stats ${tag}_${w}_tablel2_stats.log --kernel-trace --stats -- --workload $w --steps 30 --warmup 3
+done
 cd $R
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_write.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_fetch FETCH_SIZE | tee gpurun_out/${tag}_fetch.txt
@@ -52,5 +57,6 @@ for march in exec ballot; do
   for c in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE; do python3 tools/pmc_summary.py gpurun_out/${tag}_cfg5_${march}_sq $c rcw_cast >> gpurun_out/${tag}_cfg5_${march}_sq.txt; done
   for c in SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VALU; do python3 tools/pmc_summary.py gpurun_out/${tag}_cfg5_${march}_lanes $c rcw_cast >> gpurun_out/${tag}_cfg5_${march}_sq.txt; done
 done
+for w in cfg2 cfg5; do for v in tablelds tablel2; do echo "$w $v calls,total_ns,avg_ns,pct,min_ns,max_ns,stddev: $(grep -h rcw_cast_kernel gpurun_out/${tag}_${w}_${v}_stats/*/*_kernel_stats.csv | sed 's/.*)",//' | tail -1)"; done; done | tee gpurun_out/${tag}_cast_table.txt
 grep -h "rcw_" gpurun_out/${tag}_cfg5_*_kernel_stats.csv | cut -c1-200 | head -8
 echo "round script done"
