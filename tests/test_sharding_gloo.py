@@ -30,7 +30,7 @@ class OracleEngine:
 
     @property
     def camera_view(self):
-        return torch.from_numpy(self.o.camera_view.astype(np.int64))
+        return torch.from_numpy(self.o.camera_view.copy())          # torch.uint32, as the engine's alias is
 
     def expand_columns(self, h, c):
         colours = np.array([0x808080, 0xC0C0C0, 0x800000, 0xC00000], dtype=np.int64)
@@ -39,7 +39,7 @@ class OracleEngine:
         pad = np.where(h >= Hc - 1, 0, (Hc - h) // 2)[..., None]
         rows = np.arange(Hc)[None, None, :]
         col = colours[c][..., None]
-        return torch.from_numpy(np.where(rows < pad, 0xFFFFFF, np.where(rows < Hc - pad, col, 0x404040)))
+        return torch.from_numpy(np.where(rows < pad, 0xFFFFFF, np.where(rows < Hc - pad, col, 0x404040)).astype(np.uint32))
 
     def close(self):
         self.o.close()
@@ -72,6 +72,7 @@ def _worker(rank, world, port, q):
         gh, gc = sh.gather_columns()
         frames_c = sh.gather_observations("columns")
         frames_f = sh.gather_observations("frames")
+        assert frames_f.dtype == torch.uint32            # travelled through the process group as int32 (same bytes)
         sh.reset_(seed=5)
         gh2, _ = sh.gather_columns()
         q.put((rank, gh.numpy(), gc.numpy(), frames_c.numpy(), frames_f.numpy(), gh2.numpy()))
