@@ -523,12 +523,14 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // player_radius_pu = wu_to_pu(player_radius_wu, pu_per_tu) SR:469 = floor(Int, r * pu) + 1 in T (UT:6)
     d.top_rp = h->real64 ? (int32_t)std::floor(cfg->player_radius_wu_f64 * (double)cfg->pu_per_tu) + 1
                          : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
-    // the write-once kernel keeps two agents' bit planes in LDS (160 KiB per CU); larger images take the in-place kernel
-    // (1: two buffers, drawing overlapped with storing; 2: one buffer, no overlap; 0: in-place kernel)
-    d.top_lds = 1;                                             // try two buffers,
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 2; // then one,
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0; // then give up on LDS (the size depends on top_lds)
+    // the write-once kernel keeps a ring of 1..3 agents' bit planes in LDS (160 KiB per CU): three where three
+    // workgroups per CU still fit beside each other, else two, else one; larger images take the in-place kernel
+    d.top_lds = 3;
+    if (rcw_top_view_lds_bytes(d) > 52 * 1024) d.top_lds = 2;
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1;
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;             // (the size depends on top_lds)
     if (!cfg->render_top_view) d.top_lds = 0;
+    if (const char* v = std::getenv("RCW_TOP_RING")) { const int k = std::atoi(v); if (k >= 1 && k <= 3 && d.top_lds > 0) { d.top_lds = k; if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1; } }
     {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
         const size_t lds = rcw_top_view_lds_bytes(d);
         int per_cu = lds ? (int)((160 * 1024) / lds) : 4;

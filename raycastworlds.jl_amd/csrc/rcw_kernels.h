@@ -56,7 +56,7 @@ struct RcwDev {
     uint32_t* top_view;      // optional env.top_view UInt32 (H*pu, W*pu, B)  SR:302
     int32_t pu;              // pu_per_tu
     int32_t top_rp;          // player_radius_pu = wu_to_pu(player_radius_wu, pu)  SR:469 (host-computed in T)
-    int32_t top_lds;         // write-once LDS bit-plane kernel: 1 two buffers (overlapped), 2 one buffer; 0: in-place fallback
+    int32_t top_lds;         // write-once LDS bit-plane kernel: the number of buffers in its ring (1..3); 0: in-place fallback
     int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
     int32_t top_debug;       // development only (RCW_TOP_DEBUG): bit 0 skip drawing, bit 1 skip storing — for timing the halves
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step

@@ -1032,13 +1032,19 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
     }
 }
 
-// Sync among the four wavefronts of the draw group only (the store group must not be held up): a counter in LDS
-// that only ever grows; each wavefront adds one when its LDS writes are done and waits for the group's total.
-__device__ __forceinline__ void draw_group_sync(int* counter, int target)
+// Hand-offs between wavefronts of one workgroup through counters in LDS that only ever grow: a wavefront adds one
+// when its own LDS operations are done (`signal`), a waiter spins (with s_sleep) until the count it needs is there.
+// No s_barrier in the steady state: a barrier per agent would make every agent cost max(draw, store), and the
+// drawing time varies with the agent's ray lengths — with a ring of buffers the draw group runs ahead and only the
+// averages have to balance.
+__device__ __forceinline__ void lds_signal(int* counter)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void lds_wait(int* counter, int target)
+{
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
     asm volatile("" ::: "memory");
 }
 
@@ -1049,41 +1055,44 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
     const int role = threadIdx.x >> 8;        // 0: draw group, 1: store group (wave-uniform)
     const int tid = threadIdx.x & (kTopGroup - 1);
     const int G = gridDim.x;
-    const int n = (p.B - (int)blockIdx.x + G - 1) / G;                      // agents of this workgroup: blockIdx.x + k*G
+    const int n = (p.B - (int)blockIdx.x + G - 1) / G;                      // agents of this workgroup: blockIdx.x + q*G
     const size_t bw = top_buf_words(p);
-    int* const counter = reinterpret_cast<int*>(lds);                       // lds[0..3]: the draw group's counter
+    // lds[0]: draw-group wavefronts that have prepared their current agent; lds[1]: ... that have finished drawing
+    // (summed over agents); lds[2]: store-group wavefronts that have finished storing (summed over agents)
+    int* const c_prepared = reinterpret_cast<int*>(lds);
+    int* const c_drawn = c_prepared + 1;
+    int* const c_stored = c_prepared + 2;
     uint32_t* const bufs = lds + 4;
-    if (threadIdx.x == 0) *counter = 0;
+    if (threadIdx.x < 4) c_prepared[threadIdx.x] = 0;
     lds_barrier();
-    // The schedule, one workgroup barrier per step; the two groups run their own loops (separate code paths, so
-    // that the store group's instruction stream carries no wait for anything but its own LDS reads — in a shared
-    // loop the compiler's wait-count bookkeeping for the draw group's loads also drained the store group's stores
-    // once per agent).  Overlapped (two LDS buffers): in step h the draw group prepares and draws agent h while the
-    // store group stores agent h - 1.  Serial (image too large for two buffers): steps 2 s, 2 s + 1 draw, then store.
-    const bool serial = p.top_lds == 2;
-    const int steps = serial ? 2 * n : n + 1;
+    // A ring of K = p.top_lds buffers (1..3, as many as fit in LDS).  The draw group draws agent q into buffer
+    // q mod K as soon as the store group has finished agent q - K; the store group stores agent q as soon as all four
+    // draw wavefronts have finished it.  With K = 1 the two simply alternate.  The two groups run separate loops
+    // (separate code paths): in a shared loop the compiler's wait-count bookkeeping for the draw group's loads also
+    // drained the store group's stores once per agent.
+    const int K = p.top_lds;
     if (role == 0) {
-        int drawn = 0;
-        for (int h = 0; h < steps; ++h) {
-            const int agent = serial ? h >> 1 : h;
-            const int a = blockIdx.x + agent * G;
-            const bool on = agent < n && !(serial && (h & 1)) && (mask == nullptr || mask[a] != 0);
+        int prepared = 0;
+        for (int q = 0; q < n; ++q) {
+            const int a = blockIdx.x + q * G;
+            const bool on = mask == nullptr || mask[a] != 0;
+            if (q >= K) lds_wait(c_stored, 4 * (q - K + 1));                // the buffer is free again
             if (on) {
-                const TopBuf b = top_buf(p, bufs + (size_t)(serial ? 0 : agent & 1) * bw);
+                const TopBuf b = top_buf(p, bufs + (size_t)(q % K) * bw);
                 top_prepare(p, a, b, tid);
-                drawn += 1;
-                draw_group_sync(counter, 4 * drawn);
+                prepared += 1;
+                lds_signal(c_prepared); lds_wait(c_prepared, 4 * prepared);  // planes cleared by all four wavefronts
                 if (!(p.top_debug & 1)) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
             }
-            lds_barrier();
+            lds_signal(c_drawn);
         }
     } else {
-        for (int h = 0; h < steps; ++h) {
-            const int agent = serial ? h >> 1 : h - 1;
-            const int a = blockIdx.x + agent * G;
-            const bool on = agent >= 0 && (!serial || (h & 1)) && (mask == nullptr || mask[a] != 0);
-            if (on && !(p.top_debug & 2)) top_store(p, a, top_buf(p, bufs + (size_t)(serial ? 0 : agent & 1) * bw), tid, 2);
-            lds_barrier();
+        for (int q = 0; q < n; ++q) {
+            const int a = blockIdx.x + q * G;
+            const bool on = mask == nullptr || mask[a] != 0;
+            lds_wait(c_drawn, 4 * (q + 1));
+            if (on && !(p.top_debug & 2)) top_store(p, a, top_buf(p, bufs + (size_t)(q % K) * bw), tid, 2);
+            lds_signal(c_stored);
         }
     }
 }
@@ -1148,7 +1157,7 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
 
 size_t rcw_top_view_lds_bytes(const RcwDev& p)
 {
-    return 16 + (p.top_lds == 2 ? 1 : 2) * 4 * top_buf_words(p);      // counter + two buffers: one being drawn, one being stored
+    return 16 + (size_t)(p.top_lds > 0 ? p.top_lds : 1) * 4 * top_buf_words(p);      // counters + the ring of p.top_lds buffers
 }
 
 hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)

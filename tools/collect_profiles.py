@@ -65,6 +65,12 @@ if os.path.exists(f"gpurun_out/{tag}_cfg5_exec_sq.txt"):
                    f"waiting {v.get('SQ_WAIT_ANY', 0) / max(v.get('SQ_WAVE_CYCLES', 1), 1) * 100:.0f} % of wave cycles, "
                    f"active lanes per VALU instruction {lane * 100:.1f} %\n" + sq)
     open(f"profiles/{tag}_cast_march_cfg5.txt", "w").write("".join(out))
+if os.path.exists(f"gpurun_out/{tag}_cast_table.txt"):
+    open(f"profiles/{tag}_cast_table.txt", "w").write(
+        "rcw_cast_kernel, the heading's ray-table slice (5 N values): read directly from the L2-resident table by the lane\n"
+        "that uses it (shipped, \"tablel2\") vs copied to LDS first and read back (RCW_CAST_TABLE=lds, \"tablelds\", the form\n"
+        "north_star words).  rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --workload <cfg> --steps 30 --warmup 3\n\n"
+        + open(f"gpurun_out/{tag}_cast_table.txt").read())
 if os.path.exists("gpurun_out/rccl_world1.json"):
     shutil.copy("gpurun_out/rccl_world1.json", f"profiles/{tag}_rccl_world1.json")
 b = json.load(open(f"profiles/{tag}_bench.json"))
