@@ -118,7 +118,7 @@ typedef struct rcw_config {
     int32_t  num_directions;          /* SR:262  default 128                               */
     int32_t  num_rays;                /* SR:268  default 512 (= camera view width)         */
     int32_t  height_camera_view_pu;   /* SR:271  default 256                               */
-    int32_t  pu_per_tu;               /* SR:269  default 32 (top view only; kept for ABI)  */
+    int32_t  pu_per_tu;               /* SR:269  default 32 (pixels per tile of the top view) */
     float    player_radius_wu;        /* SR:263  default 1/8, must be in (0, 0.5)          */
     float    position_increment_wu;   /* SR:264  default 1/8                               */
     float    semi_field_of_view_wu;   /* SR:267  default Float32(2/3)                      */
@@ -153,7 +153,7 @@ typedef struct rcw_config {
                                          not the Float32 value widened), positions / rays / tables
                                          cross the boundary as double (the *64 entry points), and
                                          every Float32 operation of the path becomes the same
-                                         Float64 operation.  R (reward) stays Float32.            */
+                                         Float64 operation.  R (reward_type) is independent of T. */
     double   player_radius_wu_f64;    /* SR:263 convert(Float64, 1/8)                           */
     double   position_increment_wu_f64;
     double   semi_field_of_view_wu_f64;
