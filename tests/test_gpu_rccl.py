@@ -4,6 +4,7 @@ Runs tests/rccl_world1.py in a child process because MASTER_ADDR / RANK / WORLD_
 process first touches the GPU."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -14,7 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_rccl_gather_world_of_one(rcw, tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1.py"), "--batch", "256",
                           "--time-batch", "8192", "--reps", "10"], env=env, capture_output=True, text=True, timeout=600)
