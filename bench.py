@@ -107,9 +107,19 @@ def main():
     ap.add_argument("--top-view", action="store_true",
                     help="also render the reference's top view every step (update_top_view! SR:446-483, opt-in in the "
                          "engine) and report that kernel's own roofline block; NOT the headline workload")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time the optional observation gather (RCCL all-gather of descriptors / frames) after the "
+                         "timed region; on by default when --gpus > 1, with one GPU it runs a one-rank process group")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share GPU 0 and rendezvous over gloo (checks the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
+
+    # Rank 0 must print ONE JSON line on stdout and nothing else.  Libraries do not know that (RCCL prints a version
+    # banner on stdout when a communicator is created): from here on file descriptor 1 is stderr, and the JSON line is
+    # written to the saved, real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -127,9 +137,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.gather:
         import torch.distributed as dist
 
+        if world == 1:                               # --gather on one GPU: a process group of one rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -207,6 +222,47 @@ def main():
                          device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms, cast_ms, fill_ms, top_ms = (float(v) for v in t)
+    # Outside the timed region too: the OPTIONAL observation gather north_star names (stepping itself has no
+    # collective).  RCCL all-gather over the process group, issued on the stream the engine runs on: the compact
+    # descriptors (5 B per column) with the pixel expansion on the receiver, and the frames themselves.
+    gather = None
+    if dist is not None and not args.rehearse_on_one_gpu:
+        try:
+            h_loc, c_loc = env.columns_device()
+            h_loc, c_loc = h_loc.torch(sync=False), c_loc.torch(sync=False)
+            obs_loc = env.camera_view.torch(sync=False).view(torch.int32)
+            gh = torch.empty((world * B, N), dtype=torch.int32, device="cuda")
+            gc = torch.empty((world * B, N), dtype=torch.uint8, device="cuda")
+            frames_all = torch.empty((world * B, N, Hc), dtype=torch.uint32, device="cuda")
+
+            def timed(fn, reps):
+                fn()
+                torch.cuda.synchronize(); barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(); barrier()
+                return (time.perf_counter() - t0) / reps * 1e6
+
+            def cols():
+                dist.all_gather_into_tensor(gh, h_loc)
+                dist.all_gather_into_tensor(gc, c_loc)
+
+            def cols_expand():
+                cols()
+                env.expand_columns(gh, gc, out=frames_all)
+
+            t_cols, t_cols_expand = timed(cols, 10), timed(cols_expand, 5)
+            t_frames = timed(lambda: dist.all_gather_into_tensor(frames_all.view(torch.int32), obs_loc), 3)
+            tt = torch.tensor([t_cols, t_cols_expand, t_frames], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            gather = {"ranks": world, "agents_per_rank": B, "descriptor_bytes_per_rank": 5 * N * B,
+                      "frame_bytes_per_rank": 4 * N * Hc * B, "columns_us": float(tt[0]),
+                      "columns_plus_expand_us": float(tt[1]), "frames_us": float(tt[2]),
+                      "note": "max over ranks, host-timed between barriers; not part of `value` (the gather is optional)"}
+            del gh, gc, frames_all
+        except Exception as e:   # noqa: BLE001 — a reported extra must never cost the bench line
+            gather = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     if rank == 0:
         frame_bytes = 4 * Hc * N                          # bytes per env-step
@@ -272,6 +328,8 @@ def main():
                 },
             },
         }
+        if gather is not None:
+            out["gather"] = gather
         if args.top_view:
             pu = env.cfg.pu_per_tu
             top_bytes = 4 * (kw["height_tile_map_tu"] * pu) * (kw["width_tile_map_tu"] * pu) * B
@@ -284,7 +342,8 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, B)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     env.close()
     if dist is not None:
         dist.barrier()
