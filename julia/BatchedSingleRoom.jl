@@ -121,6 +121,11 @@ mutable struct BatchedSingleRoom{T, R} <: RCW.AbstractGame
         T in (Float32, Float64) || throw(ArgumentError("T must be Float32 or Float64"))
         R in REWARD_TYPES || throw(ArgumentError("R must be one of $(REWARD_TYPES)"))
         cfg = RcwConfig(; kwargs...)
+        # convert(T, .) of the caller's world-unit parameters (single_room.jl:263-270): for T = Float64 the library
+        # reads the *_f64 fields — the Float64 value itself, not the Float32 one widened
+        for name in (:player_radius_wu, :position_increment_wu, :semi_field_of_view_wu, :camera_height_tile_wu)
+            haskey(kwargs, name) && setfield!(cfg, Symbol(name, :_f64), Float64(kwargs[name]))
+        end
         cfg.world_unit_bits = T === Float64 ? 64 : 32
         cfg.reward_type = Int32(findfirst(==(R), REWARD_TYPES) - 1)
         cfg.goal_reward = one(Float32); cfg.goal_reward_f64 = 1.0      # one(R) single_room.jl:82
@@ -150,8 +155,8 @@ end
 # RCW.reset!(env)  — single_room.jl:326-331 (all agents, or those whose mask byte is non-zero)
 function RCW.reset!(env::BatchedSingleRoom; mask::Union{Nothing, Vector{UInt8}} = nothing, seed::Integer = env.seed)
     env.seed = seed
-    check(ccall((:rcw_reset, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}, UInt64),
-                env.handle, mask === nothing ? C_NULL : pointer(mask), env.seed))
+    GC.@preserve mask check(ccall((:rcw_reset, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}, UInt64),
+                                  env.handle, mask === nothing ? Ptr{UInt8}(C_NULL) : pointer(mask), env.seed))
     env.stale = true
     return nothing
 end
@@ -196,15 +201,17 @@ clear_error!(env::BatchedSingleRoom) = check(ccall((:rcw_clear_error, librcw), C
 # seeds" is realised against the CPU reference (SURVEY.md §8c).
 function set_state!(env::BatchedSingleRoom{Float32}, goal_ij::Matrix{Int32}, position_wu::Matrix{Float32},
                     direction_au::Vector{Int32}; mask::Union{Nothing, Vector{UInt8}} = nothing)
-    check(ccall((:rcw_set_state, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Int32}, Ptr{UInt8}),
-                env.handle, goal_ij, position_wu, direction_au, mask === nothing ? C_NULL : pointer(mask)))
+    GC.@preserve mask check(ccall((:rcw_set_state, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Int32}, Ptr{UInt8}),
+                                  env.handle, goal_ij, position_wu, direction_au,
+                                  mask === nothing ? Ptr{UInt8}(C_NULL) : pointer(mask)))
     env.stale = true
     return nothing
 end
 function set_state!(env::BatchedSingleRoom{Float64}, goal_ij::Matrix{Int32}, position_wu::Matrix{Float64},
                     direction_au::Vector{Int32}; mask::Union{Nothing, Vector{UInt8}} = nothing)
-    check(ccall((:rcw_set_state64, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{UInt8}),
-                env.handle, goal_ij, position_wu, direction_au, mask === nothing ? C_NULL : pointer(mask)))
+    GC.@preserve mask check(ccall((:rcw_set_state64, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{UInt8}),
+                                  env.handle, goal_ij, position_wu, direction_au,
+                                  mask === nothing ? Ptr{UInt8}(C_NULL) : pointer(mask)))
     env.stale = true
     return nothing
 end
