@@ -603,3 +603,32 @@ def test_lds_staged_ray_table_gives_the_same_rays(rcw, oracle, monkeypatch):
         env, orc = _make(rcw, oracle, 12, seed=4, auto_reset=True, **kw)
         _rollout(rcw, env, orc, 25, rng, check_every=5, rays_every=5)
         env.close()
+
+
+def test_create_destroy_cycles_leave_device_memory_unchanged(rcw):
+    """Handles with every optional buffer (top view, Float64 tables, typed rewards, rays scratch, a bound observation
+    buffer, the gather scratch is covered by the RCCL test) are created, used and destroyed 25 times: free device
+    memory returns to where it was (hipMalloc'd memory is released, not cached, by rcw_destroy)."""
+    torch = pytest.importorskip("torch")
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(0)
+
+    def cycle(k):
+        env = rcw.SingleRoomModule.SingleRoom(batch=192, seed=k, render_top_view=True, R=("Float64", "Int64")[k & 1],
+                                              T=("Float32", "Float64")[(k >> 1) & 1], auto_reset=True, **CFG2)
+        for _ in range(3):
+            rcw.act_(env, rng.integers(1, 5, 192).astype(np.uint8))
+        env.world.rays(0, 64)
+        env.top_view_host(0, 2)
+        rcw.update_camera_view_(env); rcw.update_top_view_(env)
+        env.sync()
+        env.close()
+
+    cycle(0)                                        # first use loads code objects etc.
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(25):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free1 - free0) <= 8 << 20, f"device memory drifted by {(free0 - free1) / 2**20:.1f} MiB over 25 cycles"
