@@ -4,6 +4,8 @@ Bit-exact for every integer output (tile_map, camera_view, ray stop tiles, hit d
 height_line_pu, colour id, direction, done); player_position_wu within 1e-6 as
 BASELINE.json's north_star states (and in fact bit-exact).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -632,3 +634,31 @@ def test_create_destroy_cycles_leave_device_memory_unchanged(rcw):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free1 - free0) <= 8 << 20, f"device memory drifted by {(free0 - free1) / 2**20:.1f} MiB over 25 cycles"
+
+
+def test_play_keys_replays_the_keyboard_callback(rcw, oracle, tmp_path):
+    """Headless `play!` (SR:488-568): a scripted key sequence — W/S/A/D act, R resets, V toggles the view, an unbound
+    key warns, Q closes — with the frame buffer after every key compared with the oracle's views blitted the
+    reference's way (camera view 64 x 256 and top view 256 x 256 in a 256 x 256 MiniFB buffer)."""
+    env, orc = _make(rcw, oracle, 3, seed=21, render_top_view=1, out_of_bounds=1, **CFG1)
+    keys = "wwadVwsVxdRwwQww"
+    with pytest.warns(UserWarning, match="No keybinding exists for x"):
+        out = rcw.play_keys(env, keys, agent=1, frame_dir=str(tmp_path))
+    assert [o[0] for o in out] == list("wwadvwsvxdrww")          # Q closes: nothing after it runs
+    view, steps = 1, 0
+    for key, steps_taken, reward, done, fb in out:
+        if key in "wsad":
+            orc.step(np.full(3, "wsad".index(key) + 1, dtype=np.uint8)); steps += 1
+        elif key == "r":
+            orc.reset(seed=21); steps = 0
+        elif key == "v":
+            view = 2 if view == 1 else 1
+        image = orc.camera_view[1] if view == 1 else orc.top_view[1]
+        want = np.zeros((256, 256), dtype=np.uint32)
+        want[: image.shape[1], : image.shape[0]] = image.T
+        np.testing.assert_array_equal(fb, want, err_msg=f"frame buffer after key {key!r}")
+        assert steps_taken == steps and reward == orc.reward[1] and done == bool(orc.done[1])
+    frames = sorted(os.listdir(tmp_path))
+    assert len(frames) == len(out) and frames[0] == "frame_0000.ppm"
+    assert open(tmp_path / frames[0], "rb").read(15) == b"P6\n256 256\n255\n"
+    env.close()

@@ -139,3 +139,19 @@ def test_line_closed_form_equals_the_error_term_walk():
     for i2 in range(-48, 49):
         for j2 in range(-48, 49):
             assert error_term_walk(i2, j2) == remainder_walk(i2, j2), (i2, j2)
+
+
+def test_frame_buffer_blit_is_the_reference_transpose(rcw):
+    """frame_buffer_of == copy_image_to_frame_buffer! (utils.jl:64-73) into zeros(UInt32, width_image, height_image)
+    (SR:508), checked element by element against the reference loop restated literally."""
+    rng = np.random.default_rng(0)
+    H_img, W_img, height_image, width_image = 5, 3, 7, 6
+    image_julia = rng.integers(0, 2**32, (H_img, W_img), dtype=np.uint64).astype(np.uint32)     # Julia image[i, j]
+    frame_buffer = np.zeros((width_image, height_image), dtype=np.uint32)                        # Julia [j, i]
+    for j in range(W_img):
+        for i in range(H_img):
+            frame_buffer[j, i] = image_julia[i, j]                                               # utils.jl:68-70
+    engine_layout = np.ascontiguousarray(image_julia.T)          # what the engine returns: (W_img, H_img) in C order
+    got = rcw.frame_buffer_of(engine_layout, width_image, height_image)
+    # Julia's (width_image, height_image) column-major buffer is numpy (height_image, width_image) in C order
+    np.testing.assert_array_equal(got, frame_buffer.T)
