@@ -279,6 +279,8 @@ class SingleRoom:
         self._h = C.c_void_p()
         _capi.check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
         self.world = SingleRoomWorld(self)
+        self._held = []          # (event, tensors): torch tensors the engine's stream may still be reading
+        self._free_events = []
         # colour fields of the reference struct SR:241-256
         self.floor_color = cfg.floor_color
         self.ceiling_color = cfg.ceiling_color
@@ -294,7 +296,7 @@ class SingleRoom:
         if getattr(self, "_h", None):
             self._lib.rcw_destroy(self._h)       # waits for the handle's stream
             self._h = C.c_void_p()
-            self.__dict__.pop("_held", None)
+            self._held = []
 
     def __del__(self):
         try:
@@ -415,8 +417,7 @@ class SingleRoom:
         ring of 16 reusable events; the host only ever blocks when it runs 16 launches ahead of the GPU)."""
         import torch
 
-        ring = self.__dict__.setdefault("_held", [])
-        free = self.__dict__.setdefault("_free_events", [])
+        ring, free = self._held, self._free_events
         while ring and ring[0][0].query():
             free.append(ring.pop(0)[0])
         if len(ring) >= 16:
