@@ -26,8 +26,11 @@ ROOM = dict(height_tile_map_tu=8, width_tile_map_tu=8)
 class OracleWorld:
     """One reference world on the CPU oracle, behind the attribute names the cases use."""
 
-    def __init__(self, oracle, num_rays, **kw):
-        self.b = oracle.OracleBatch(1, num_rays=num_rays, **ROOM, **kw)
+    def __init__(self, oracle, num_rays, room=ROOM, T="Float32", **kw):
+        if T == "Float64":
+            kw["world_unit_bits"] = 64
+        self.real = np.float64 if T == "Float64" else np.float32
+        self.b = oracle.OracleBatch(1, num_rays=num_rays, **room, **kw)
 
     def set_state(self, goal, pos, d):
         self.b.set_state([goal], [pos], [d])
@@ -51,6 +54,7 @@ class OracleWorld:
     reward = property(lambda s: s.b.reward[0])
     done = property(lambda s: bool(s.b.done[0]))
     status = property(lambda s: int(s.b.status[0]))
+    top_view = property(lambda s: s.b.top_view[0])
 
     def close(self):
         self.b.close()
@@ -59,10 +63,11 @@ class OracleWorld:
 class HipWorld:
     """The same world on the MI355X engine (C ABI via the Python host mirror)."""
 
-    def __init__(self, rcw, num_rays, **kw):
+    def __init__(self, rcw, num_rays, room=ROOM, T="Float32", **kw):
         self.rcw = rcw
         self._status = 0
-        self.env = rcw.SingleRoomModule.SingleRoom(batch=1, num_rays=num_rays, **ROOM, **kw)
+        self.real = np.float64 if T == "Float64" else np.float32
+        self.env = rcw.SingleRoomModule.SingleRoom(batch=1, num_rays=num_rays, T=T, **room, **kw)
 
     def set_state(self, goal, pos, d):
         self.env.set_state([goal], [pos], [d])
@@ -92,6 +97,7 @@ class HipWorld:
     reward = property(lambda s: s.env.world.reward[0])
     done = property(lambda s: bool(s.env.world.done[0]))
     status = property(lambda s: s._status)
+    top_view = property(lambda s: s.env.top_view_host()[0])
 
     def close(self):
         self.env.close()
@@ -123,10 +129,13 @@ def _ring(H=8, W=8, goal=None):
     return m
 
 
+@pytest.mark.parametrize("T", ["Float32", "Float64"])
 @pytest.mark.parametrize("case", KAT["render"], ids=lambda c: c["name"][:40])
-def test_render_known_answers(make_world, case):
+def test_render_known_answers(make_world, case, T):
+    """(also with T = Float64 world units, SR:259: the cases are far from rounding boundaries, so the answers hold)"""
     N = case["num_rays"]
-    w = make_world(N)
+    room = ROOM if "map" not in case else dict(height_tile_map_tu=case["map"][0], width_tile_map_tu=case["map"][1])
+    w = make_world(N, room=room, T=T)
     w.set_state(case["goal"], case["position"], case["direction"])
     h, c, frame = w.col_height, w.col_colour, w.frame
     if "all_columns" in case:
@@ -281,3 +290,27 @@ def test_reference_bounds_error_quirk_stand_alone(oracle):
     with pytest.raises(IndexError):
         oracle.is_player_colliding(np.zeros((8, 8), bool), np.float32(7.0), np.float32(4.5), np.float32(0.125))
     assert oracle.is_player_colliding(layer, np.float32(7.0), np.float32(4.5), np.float32(0.125), oob_empty=True)
+
+
+def test_top_view_certain_parts_by_hand(make_world):
+    """The parts of the top view that do not depend on SimpleDraw's rasterisers, derived by hand from SR:342-372 and
+    SR:466-480: tile (i, j) occupies pixels (i-1)pu+1..i pu in both axes, its outermost pixel ring is 0x00cccccc, the
+    inside is white for walls, red for the goal, black for free tiles; the player's own pixel wu_to_pu.(position) lies
+    on the first pixel of every ray line (0x00808080 unless the circle, radius floor(r pu)+1 = 5 at pu 32, covers it —
+    it does not cover the centre); facing +x the central ray runs straight down the i axis to the wall face x = 7."""
+    pu = 32
+    w = make_world(64, render_top_view=1, pu_per_tu=pu)
+    w.set_state([7, 2], [4.5, 4.5], 0)
+    tv = w.top_view                           # [jp-1][ip-1]
+    px = lambda ip, jp: int(tv[jp - 1, ip - 1])   # noqa: E731
+    assert px(1, 1) == 0xCCCCCC and px(32, 32) == 0xCCCCCC and px(33, 1) == 0xCCCCCC      # frames
+    assert px(2, 2) == 0xFFFFFF and px(16, 16) == 0xFFFFFF                                # wall tile (1,1) inside
+    assert px(6 * pu + 2, 1 * pu + 2) == 0xFF0000 and px(7 * pu - 1, 2 * pu - 1) == 0xFF0000   # goal tile (7,2) inside
+    assert px(6 * pu + 1, 1 * pu + 1) == 0xCCCCCC                                          # goal tile frame
+    assert px(2 * pu + 2, 2 * pu + 2) == 0x000000                                          # free tile (3,3), away from the fan
+    ip = jp = int(np.floor(4.5 * pu)) + 1                                                  # 145
+    assert px(ip, jp) == 0x808080                                                          # start of every ray line
+    assert px(ip + 5, jp) == 0xC0C0C0 and px(ip, jp + 5) == 0xC0C0C0 and px(ip - 5, jp) == 0xC0C0C0   # circle's axis points
+    assert px(200, jp) == 0x808080 and px(225, jp) == 0x808080 and px(226, jp) != 0x808080
+    # the whole image holds nothing but the six colours of SR:288-290, SR:364
+    assert set(np.unique(tv).tolist()) <= {0x000000, 0xFFFFFF, 0xFF0000, 0xCCCCCC, 0x808080, 0xC0C0C0}

@@ -83,29 +83,6 @@ def test_top_view_two_restatements_agree(oracle):
         np.testing.assert_array_equal(w.top_view, orc.top_view[0])
 
 
-def test_top_view_certain_parts_by_hand(oracle):
-    """The parts of the top view that do not depend on SimpleDraw's rasterisers, derived by hand from
-    SR:342-372: tile (i, j) occupies pixels (i-1)pu+1..i pu in both axes, its outermost pixel ring is
-    0x00cccccc, the inside is white for walls, red for the goal, black for free tiles; the player's own
-    pixel wu_to_pu.(position) lies on the first pixel of every ray line (0x00808080 unless the circle,
-    radius floor(r pu)+1 = 5 at pu 32, covers it — it does not cover the centre)."""
-    pu = 32
-    orc = oracle.OracleBatch(1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, render_top_view=1, pu_per_tu=pu)
-    orc.set_state([[7, 2]], [[4.5, 4.5]], [0])
-    tv = orc.top_view[0]                      # [jp-1][ip-1]
-    px = lambda ip, jp: int(tv[jp - 1, ip - 1])
-    assert px(1, 1) == 0xCCCCCC and px(32, 32) == 0xCCCCCC and px(33, 1) == 0xCCCCCC      # frames
-    assert px(2, 2) == 0xFFFFFF and px(16, 16) == 0xFFFFFF                                # wall tile (1,1) inside
-    assert px(6 * pu + 2, 1 * pu + 2) == 0xFF0000 and px(7 * pu - 1, 2 * pu - 1) == 0xFF0000   # goal tile (7,2) inside
-    assert px(6 * pu + 1, 1 * pu + 1) == 0xCCCCCC                                          # goal tile frame
-    assert px(2 * pu + 2, 2 * pu + 2) == 0x000000                                          # free tile (3,3), away from the fan
-    ip = jp = int(np.floor(4.5 * pu)) + 1                                                  # 145
-    assert px(ip, jp) == 0x808080                                                          # start of every ray line
-    assert px(ip + 5, jp) == 0xC0C0C0 and px(ip, jp + 5) == 0xC0C0C0 and px(ip - 5, jp) == 0xC0C0C0   # circle's axis points
-    # facing +x: the central ray runs straight down the i axis to the wall face x = 7 -> pixel 7*32+1 = 225
-    assert px(200, jp) == 0x808080 and px(225, jp) == 0x808080 and px(226, jp) != 0x808080
-
-
 @pytest.mark.parametrize("H,W,N,steps", [(8, 8, 64, 50), (8, 16, 40, 40), (7, 9, 21, 30)])
 def test_float64_rollout_bit_exact(oracle, H, W, N, steps):
     """T = Float64: the Python restatement with numpy Float64 scalars vs the C oracle compiled with
