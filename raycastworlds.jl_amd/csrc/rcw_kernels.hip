@@ -900,8 +900,8 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     }
 }
 
-// store group: agent a's image, every pixel once.  part 0 / 1: the first / second half of the columns, 2: all of it
-__device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& b, int tid, int part)
+// store group: agent a's image, every pixel once
+__device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& b, int tid)
 {
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     uint32_t* img = p.top_view + (size_t)a * Ht * Wt;
@@ -910,8 +910,7 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
     const int jc0 = b.hdr[1] - rp;
     const int box = 2 * rp;
     const int cbits = top_col_bits(p);
-    const int half = Wt >> 1;
-    const int c_lo = part == 1 ? half : 0, c_hi = part == 0 ? half : Wt;
+    const int c_lo = 0, c_hi = Wt;
     if ((Ht & 255) == 0 && (pu & 3) == 0) {
         // One wavefront per image column (256 rows per pass), lanes along the contiguous rows, four pixels a lane:
         // they never straddle a tile.  What depends on the rows only (tile row, frame rows) is computed once per
@@ -928,59 +927,63 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
             const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, e, 1);   // 0 or ~0
             return (m & colour) | (~m & under);                             // v_bfi_b32
         };
+        const int cpt = pu >> 2;                                            // this wavefront's columns per tile column
+        const int lstep = step * wpc;
+        const size_t dstep = (size_t)step * vpc;
         for (int r0 = 0; r0 < Ht; r0 += 256) {
             const int ip0 = r0 + lane * 4;
             const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
             const bool first_row = ri == 0, last_row = ri + 3 == pu - 1;    // SR:364-365: the tile's frame rows
             const uint8_t* const tile_row = b.tb + ti;
             const int sh = ip0 & 31;
-            int jp0 = c_lo + wave;
-            int tj = __builtin_amdgcn_readfirstlane(jp0 / pu);
-            int rj = jp0 - tj * pu;
+            int jp0 = wave;                                                  // this wavefront's columns: wave, wave + 4, ...
             const uint32_t* lp = b.line + jp0 * wpc + (ip0 >> 5);
             u32x4* dst = out + (size_t)jp0 * vpc + (ip0 >> 2);
-            int tj_loaded = -1;
-            uint32_t fx = 0u, fy = 0u, fw = 0u;                             // the tile's pixels of this lane's four rows
-            // Four columns per trip: their plane words are read from LDS first, so that the stores that follow do
-            // not each wait for an LDS round trip (one dependent LDS read per store costs 6 % of the store rate).
-            constexpr int U = 4;
             if (p.top_debug & 8) {      // development: the bare store stream of this path (no pixel logic, no LDS reads)
-                for (int c = 0; c < ncols; ++c) { const u32x4 o = {grid_c, grid_c, grid_c, grid_c}; *dst = o; dst += (size_t)step * vpc; }
+                for (int c = 0; c < ncols; ++c) { const u32x4 o = {grid_c, grid_c, grid_c, grid_c}; *dst = o; dst += dstep; }
                 continue;
             }
-            for (int c = 0; c < ncols; c += U) {
-                uint32_t words[U];
+            // Tile columns outermost: step = 4 divides pu, so every tile column holds cpt = pu / 4 of this wavefront's
+            // columns, the tile's colour is read once (the next tile's byte is already on its way), and a frame
+            // column (SR:366-367) can only be the first one (wavefront 0) or the last one (wavefront 3) of a tile.
+            uint32_t tile_next = tile_row[0];
+            for (int tj = 0; tj < p.W; ++tj) {
+                const uint32_t fill = tile_fill_colour(tile_next);
+                if (tj + 1 < p.W) tile_next = tile_row[p.H * (tj + 1)];
+                const uint32_t fx = first_row ? grid_c : fill, fw = last_row ? grid_c : fill;
+                constexpr int U = 4;
+                for (int cc = 0; cc < cpt; cc += U) {
+                    // U columns per trip: their plane words are read from LDS first, so that the stores that follow
+                    // do not each wait for an LDS round trip
+                    uint32_t words[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) words[u] = c + u < ncols ? lp[u * step * wpc] : 0u;
+                    for (int u = 0; u < U; ++u) words[u] = cc + u < cpt ? lp[u * lstep] : 0u;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (c + u >= ncols) break;                               // wave-uniform
-                    if (tj != tj_loaded) {                                   // wave-uniform: a new tile column
-                        const uint32_t fill = tile_fill_colour(tile_row[p.H * tj]);
-                        fx = first_row ? grid_c : fill; fy = fill; fw = last_row ? grid_c : fill;
-                        tj_loaded = tj;
+                    for (int u = 0; u < U; ++u) {
+                        if (cc + u >= cpt) break;                            // wave-uniform
+                        const bool frame_col = (wave == 0 && cc + u == 0) || (wave == step - 1 && cc + u == cpt - 1);
+                        u32x4 o;
+                        o.x = frame_col ? grid_c : fx;
+                        o.y = frame_col ? grid_c : fill;
+                        o.z = o.y;
+                        o.w = frame_col ? grid_c : fw;
+                        const uint32_t lb = __builtin_amdgcn_ubfe(words[u], sh, 4);
+                        if (__ballot(lb != 0u) != 0ull) {                    // some pixel of this column is on a ray line
+                            o.x = overlay(lb, 0, ray_c, o.x); o.y = overlay(lb, 1, ray_c, o.y);
+                            o.z = overlay(lb, 2, ray_c, o.z); o.w = overlay(lb, 3, ray_c, o.w);
+                        }
+                        if ((unsigned)(jp0 + 1 - jc0) <= (unsigned)box) {    // wave-uniform: a column of the circle's box
+                            const uint32_t cb = __builtin_amdgcn_ubfe(b.circ[(jp0 + 1 - jc0) * wpc + (ip0 >> 5)], sh, 4);
+                            o.x = overlay(cb, 0, player_c, o.x); o.y = overlay(cb, 1, player_c, o.y);
+                            o.z = overlay(cb, 2, player_c, o.z); o.w = overlay(cb, 3, player_c, o.w);
+                        }
+                        dst[(size_t)u * dstep] = o;   // plain, not non-temporal: 224 vs 237 us for the kernel (the opposite of the camera fill)
+                        jp0 += step;
                     }
-                    const bool frame_col = rj == 0 || rj == pu - 1;          // SR:366-367 (wave-uniform)
-                    u32x4 o;
-                    o.x = frame_col ? grid_c : fx;
-                    o.y = frame_col ? grid_c : fy;
-                    o.z = o.y;
-                    o.w = frame_col ? grid_c : fw;
-                    const uint32_t lb = __builtin_amdgcn_ubfe(words[u], sh, 4);
-                    if (__ballot(lb != 0u) != 0ull) {                        // some pixel of this column is on a ray line
-                        o.x = overlay(lb, 0, ray_c, o.x); o.y = overlay(lb, 1, ray_c, o.y);
-                        o.z = overlay(lb, 2, ray_c, o.z); o.w = overlay(lb, 3, ray_c, o.w);
-                    }
-                    if ((unsigned)(jp0 + 1 - jc0) <= (unsigned)box) {        // wave-uniform: a column of the circle's box
-                        const uint32_t cb = __builtin_amdgcn_ubfe(b.circ[(jp0 + 1 - jc0) * wpc + (ip0 >> 5)], sh, 4);
-                        o.x = overlay(cb, 0, player_c, o.x); o.y = overlay(cb, 1, player_c, o.y);
-                        o.z = overlay(cb, 2, player_c, o.z); o.w = overlay(cb, 3, player_c, o.w);
-                    }
-                    *dst = o;      // plain, not non-temporal: measured 224 vs 237 us for the kernel (the opposite of the camera fill)
-                    jp0 += step; dst += (size_t)step * vpc;
-                    rj += step; while (rj >= pu) { rj -= pu; tj += 1; }
+                    lp += U * lstep; dst += U * dstep;
                 }
-                lp += U * step * wpc;
+                // (a tile with cpt not a multiple of U advanced the pointers past its end)
+                if (cpt % U) { lp -= (U - cpt % U) * lstep; dst -= (U - cpt % U) * dstep; }
             }
         }
     } else if ((Ht & 3) == 0) {
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
             const int a = blockIdx.x + q * G;
             const bool on = mask == nullptr || mask[a] != 0;
             lds_wait(c_drawn, 4 * (q + 1));
-            if (on && !(p.top_debug & 2)) top_store(p, a, top_buf(p, bufs + (size_t)(q % K) * bw), tid, 2);
+            if (on && !(p.top_debug & 2)) top_store(p, a, top_buf(p, bufs + (size_t)(q % K) * bw), tid);
             lds_signal(c_stored);
         }
     }
