@@ -307,6 +307,16 @@ __device__ __forceinline__ uint32_t pixel(int r, int pad, int Hc, uint32_t colou
     return r < pad ? ceil_c : (r < Hc - pad ? colour : floor_c);
 }
 
+// floor(n / d) for 0 <= n < 2^23 and d >= 1 without the integer-division sequence: the Float32 quotient is off by at
+// most one, which the two corrections repair (products stay below 2^24, exact in int32)
+__device__ __forceinline__ int fast_div(int n, int d, float inv_d)
+{
+    int q = (int)((float)n * inv_d);
+    q -= (q * d > n) ? 1 : 0;
+    q += ((q + 1) * d <= n) ? 1 : 0;
+    return q;
+}
+
 // ---- kernel 1 of a step: dynamics + ray cast + projection --------------------------------
 // One workgroup per agent.  Output: the agent's new state and one compact descriptor per
 // image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
@@ -467,8 +477,121 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
     }
 }
 
-// Any H_cam: the same moving window over the flat pixel array; a 1 KiB chunk may straddle
-// columns, so every lane looks its own column up.  VEC: 16-byte stores (H_cam % 4 == 0).
+// The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of
+// the k row blocks of a column: M = 1) and H_cam = 128 or 64 (a chunk holds M = 2 or 4 whole columns; lane l of a
+// chunk belongs to column l / (64 / M)).  Lane l prefetches the descriptor(s) of the wavefront's l-th next chunk, as
+// above; with M > 1 every lane then picks its column's out of the M broadcast ones.
+template <int M>
+__global__ __launch_bounds__(kBlock) void rcw_fill_window_kernel(const RcwDev p,
+                                                                 const int32_t* __restrict__ col_h,
+                                                                 const uint8_t* __restrict__ col_c,
+                                                                 u32x4* __restrict__ out, long long total_chunks,
+                                                                 const uint8_t* __restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const long long G = (long long)gridDim.x * (kBlock / 64);
+    const long long g = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    const int Hc = p.Hc;
+    const int k = M == 1 ? Hc >> 8 : 1;                    // chunks per column (M == 1)
+    const int sub = M == 1 ? 0 : lane / (64 / M);          // this lane's column within a chunk (M > 1)
+    const int r_lane = M == 1 ? lane * 4 : (lane - sub * (64 / M)) * 4;
+    for (long long base = g; base < total_chunks; base += G * 64) {
+        const long long mine = base + (long long)lane * G;
+        int pad_l[M], rb_l = 0;
+        uint32_t colour_l[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) { pad_l[j] = -1; colour_l[j] = 0u; }
+        if (mine < total_chunks) {
+            const long long col0 = M == 1 ? mine / k : mine * M;             // first (only) column of the chunk
+            if (mask == nullptr || mask[col0 / p.N] != 0) {                   // (a chunk never spans two agents: N*Hc % 256 == 0 here)
+                rb_l = M == 1 ? (int)(mine - col0 * k) * 256 : 0;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    pad_l[j] = column_padding(Hc, col_h[col0 + j]);
+                    colour_l[j] = p.colour[col_c[col0 + j] & 3];
+                }
+            }
+        }
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+            const int pad0 = __builtin_amdgcn_readlane(pad_l[0], l);
+            if (pad0 < 0) continue;            // wave-uniform: past the end / masked out
+            int pad = pad0;
+            uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)colour_l[0], l);
+#pragma unroll
+            for (int j = 1; j < M; ++j) {
+                const int pj = __builtin_amdgcn_readlane(pad_l[j], l);
+                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)colour_l[j], l);
+                pad = sub == j ? pj : pad;
+                c = sub == j ? cj : c;
+            }
+            const int r0 = (M == 1 ? __builtin_amdgcn_readlane(rb_l, l) : 0) + r_lane;
+            u32x4 v;
+            v.x = pixel(r0 + 0, pad, Hc, c, ceil_c, floor_c);
+            v.y = pixel(r0 + 1, pad, Hc, c, ceil_c, floor_c);
+            v.z = pixel(r0 + 2, pad, Hc, c, ceil_c, floor_c);
+            v.w = pixel(r0 + 3, pad, Hc, c, ceil_c, floor_c);
+            __builtin_nontemporal_store(v, out + (base + (long long)l * G) * 64 + lane);
+        }
+    }
+}
+
+// Any other H_cam: one workgroup per agent.  The agent's N descriptors are turned
+// into (padding, colour) pairs in LDS once; then the frame is streamed out, lanes along the flat pixel order (the
+// image's contiguous axis), 16 bytes per lane when H_cam % 4 == 0 (four pixels never straddle a column then), the
+// column of a store found with a Float32 reciprocal instead of an integer division.  A frame-per-workgroup stream
+// reaches ≈ 70-75 % of the HBM peak on this chip (tools/fill_bench.hip, shape A) against 86 % for the moving window
+// above — and against 14 % for the grid-stride kernel below, which did a 64-bit division per store and is kept
+// only for frames too large for this one (N > 8192 columns or more than 2^25 pixels).
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void rcw_fill_frame_kernel(const RcwDev p,
+                                                                const int32_t* __restrict__ col_h,
+                                                                const uint8_t* __restrict__ col_c,
+                                                                uint32_t* __restrict__ out,
+                                                                const uint8_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int a = blockIdx.x;
+    if (mask != nullptr && mask[a] == 0) return;
+    const int tid = threadIdx.x, N = p.N, Hc = p.Hc;
+    int* const s_pad = reinterpret_cast<int*>(lds);         // [N] rows of ceiling (= rows of floor) of each column
+    uint32_t* const s_col = lds + N;                        // [N] the column's colour
+    for (int k = tid; k < N; k += kBlock) {
+        s_pad[k] = column_padding(Hc, col_h[(size_t)a * N + k]);
+        s_col[k] = p.colour[col_c[(size_t)a * N + k] & 3];
+    }
+    __syncthreads();
+    uint32_t* const frame = out + (size_t)a * N * Hc;
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    if (VEC) {
+        const int vpc = Hc >> 2, total = N * vpc;
+        const float inv = 1.0f / (float)vpc;
+        u32x4* const o4 = reinterpret_cast<u32x4*>(frame);
+#pragma unroll 2
+        for (int v = tid; v < total; v += kBlock) {
+            const int col = fast_div(v, vpc, inv), r0 = (v - col * vpc) * 4;
+            const int pad = s_pad[col];
+            const uint32_t c = s_col[col];
+            u32x4 px;
+            px.x = pixel(r0 + 0, pad, Hc, c, ceil_c, floor_c);
+            px.y = pixel(r0 + 1, pad, Hc, c, ceil_c, floor_c);
+            px.z = pixel(r0 + 2, pad, Hc, c, ceil_c, floor_c);
+            px.w = pixel(r0 + 3, pad, Hc, c, ceil_c, floor_c);
+            o4[v] = px;
+        }
+    } else {
+        const int total = N * Hc;
+        const float inv = 1.0f / (float)Hc;
+        for (int v = tid; v < total; v += kBlock) {
+            const int col = fast_div(v, Hc, inv), r = v - col * Hc;
+            frame[v] = pixel(r, s_pad[col], Hc, s_col[col], ceil_c, floor_c);
+        }
+    }
+}
+
+// The fallback for frames the kernel above cannot take: a grid-stride loop over the flat pixel array, every lane
+// looks its own column up.  VEC: 16-byte stores (H_cam % 4 == 0).
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void rcw_fill_any_kernel(const RcwDev p,
                                                               const int32_t* __restrict__ col_h,
@@ -776,15 +899,6 @@ __device__ __forceinline__ TopBuf top_buf(const RcwDev& p, uint32_t* base)
 
 // LDS-only workgroup barrier: waits for this wavefront's LDS operations, not for its global stores
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// n / d for 0 <= n < 2^23, 1 <= d <= 4096 without the integer-division sequence
-__device__ __forceinline__ int fast_div(int n, int d, float inv_d)
-{
-    int q = (int)((float)n * inv_d);
-    q -= (q * d > n) ? 1 : 0;
-    q += ((q + 1) * d <= n) ? 1 : 0;
-    return q;
-}
 
 __device__ __forceinline__ uint32_t tile_fill_colour(uint32_t bits)
 {
@@ -1124,6 +1238,25 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
         else
             hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
                                reinterpret_cast<u32x4*>(frames), total_cols, mask_dev);
+    } else if ((p.Hc & 255) == 0 || ((p.Hc == 128 || p.Hc == 64) && ((long long)p.N * p.Hc) % 256 == 0)) {
+        // the moving window again: 1 KiB chunks that are a row block of one column, or 2 / 4 whole columns
+        const long long chunks = total_cols * p.Hc / 256;
+        if ((p.Hc & 255) == 0)
+            hipLaunchKernelGGL(rcw_fill_window_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
+                               reinterpret_cast<u32x4*>(frames), chunks, mask_dev);
+        else if (p.Hc == 128)
+            hipLaunchKernelGGL(rcw_fill_window_kernel<2>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
+                               reinterpret_cast<u32x4*>(frames), chunks, mask_dev);
+        else
+            hipLaunchKernelGGL(rcw_fill_window_kernel<4>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
+                               reinterpret_cast<u32x4*>(frames), chunks, mask_dev);
+    } else if (p.N <= 8192 && (long long)p.N * p.Hc < (1ll << 25)) {
+        const int agents = (int)(total_cols / p.N);
+        const size_t lds = (size_t)p.N * 8;
+        if ((p.Hc & 3) == 0)
+            hipLaunchKernelGGL(rcw_fill_frame_kernel<true>, dim3(agents), dim3(kBlock), lds, s, p, col_h, col_c, frames, mask_dev);
+        else
+            hipLaunchKernelGGL(rcw_fill_frame_kernel<false>, dim3(agents), dim3(kBlock), lds, s, p, col_h, col_c, frames, mask_dev);
     } else if ((p.Hc & 3) == 0) {
         hipLaunchKernelGGL(rcw_fill_any_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames,
                            total_cols, mask_dev);

@@ -168,11 +168,19 @@ def test_expand_columns_reproduces_frames(rcw, oracle):
 
 
 def test_odd_camera_heights(rcw, oracle):
-    """H_cam not 256 / not a multiple of 4 take the generic store paths."""
+    """H_cam other than 256: the moving-window kernel for 64 / 128 / 512 / 768 (chunks of whole columns or row blocks),
+    the frame-per-workgroup kernel for the rest (250: 16-byte stores; 37: 4-byte stores; 64 with N % 4 != 0), with a
+    masked reset in between (the mask path of each kernel)."""
     rng = np.random.default_rng(1)
-    for hc in (64, 250, 37):
-        env, orc = _make(rcw, oracle, 8, seed=3, height_camera_view_pu=hc, **CFG1)
-        _rollout(rcw, env, orc, 20, rng, check_every=5)
+    for hc, cfg in ((64, CFG1), (128, CFG1), (512, CFG1), (768, CFG1), (250, CFG1), (37, CFG1), (84, CFG2),
+                    (64, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=66)),
+                    (128, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=33))):
+        env, orc = _make(rcw, oracle, 9, seed=3, height_camera_view_pu=hc, **cfg)
+        _rollout(rcw, env, orc, 12, rng, check_every=4)
+        mask = np.array([1, 0, 0, 1, 1, 0, 1, 0, 1], dtype=np.uint8)
+        rcw.reset_(env, mask=mask, seed=8); orc.reset(mask=mask, seed=8)
+        assert_state_equal(env, orc, where=f"masked reset, H_cam {hc}")
+        _rollout(rcw, env, orc, 8, rng, check_every=4)
         env.close()
 
 

@@ -32,7 +32,7 @@ for c in range(n_cfg):
               player_radius_wu=radius, position_increment_wu=min(inc, radius),
               semi_field_of_view_wu=float(rng.choice([2 / 3, 0.25, 1.0, 1.7])),
               camera_height_tile_wu=float(rng.choice([1.0, 0.5, 2.5])),
-              height_camera_view_pu=int(rng.choice([256, 64, 100, 37, 512])),
+              height_camera_view_pu=int(rng.choice([256, 64, 100, 37, 512, 128, 84, 768])),
               dda_tie_break=int(rng.integers(0, 2)), dda_distance=int(rng.integers(0, 2)),
               normalize_mode=int(rng.integers(0, 2)), out_of_bounds=int(rng.integers(0, 2)),
               auto_reset=bool(rng.integers(0, 2)), render_top_view=bool(rng.integers(0, 4) == 0) or always_top,
