@@ -1025,8 +1025,8 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
     const int box = 2 * rp;
     const int cbits = top_col_bits(p);
     const int c_lo = 0, c_hi = Wt;
-    if ((Ht & 255) == 0 && (pu & 3) == 0) {
-        // One wavefront per image column (256 rows per pass), lanes along the contiguous rows, four pixels a lane:
+    if ((pu & 3) == 0) {
+        // One wavefront per image column (256 rows per pass; the lanes past the end of a shorter last pass idle), lanes along the contiguous rows, four pixels a lane:
         // they never straddle a tile.  What depends on the rows only (tile row, frame rows) is computed once per
         // row block, what depends on the column's tile once per tile, the column itself is wave-uniform (scalar
         // unit), and the overlay is skipped for a column none of whose 256 pixels carries a line or circle bit:
@@ -1045,7 +1045,8 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
         const int lstep = step * wpc;
         const size_t dstep = (size_t)step * vpc;
         for (int r0 = 0; r0 < Ht; r0 += 256) {
-            const int ip0 = r0 + lane * 4;
+            const bool active = r0 + lane * 4 < Ht;                          // (Ht % 256 != 0: a shorter last pass)
+            const int ip0 = active ? r0 + lane * 4 : 0;
             const int ti = fast_div(ip0, pu, inv_pu), ri = ip0 - ti * pu;
             const bool first_row = ri == 0, last_row = ri + 3 == pu - 1;    // SR:364-365: the tile's frame rows
             const uint8_t* const tile_row = b.tb + ti;
@@ -1054,7 +1055,7 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
             const uint32_t* lp = b.line + jp0 * wpc + (ip0 >> 5);
             u32x4* dst = out + (size_t)jp0 * vpc + (ip0 >> 2);
             if (p.top_debug & 8) {      // development: the bare store stream of this path (no pixel logic, no LDS reads)
-                for (int c = 0; c < ncols; ++c) { const u32x4 o = {grid_c, grid_c, grid_c, grid_c}; *dst = o; dst += dstep; }
+                for (int c = 0; c < ncols; ++c) { const u32x4 o = {grid_c, grid_c, grid_c, grid_c}; if (active) *dst = o; dst += dstep; }
                 continue;
             }
             // Tile columns outermost: step = 4 divides pu, so every tile column holds cpt = pu / 4 of this wavefront's
@@ -1091,7 +1092,7 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
                             o.x = overlay(cb, 0, player_c, o.x); o.y = overlay(cb, 1, player_c, o.y);
                             o.z = overlay(cb, 2, player_c, o.z); o.w = overlay(cb, 3, player_c, o.w);
                         }
-                        dst[(size_t)u * dstep] = o;   // plain, not non-temporal: 224 vs 237 us for the kernel (the opposite of the camera fill)
+                        if (active) dst[(size_t)u * dstep] = o;   // plain, not non-temporal: 224 vs 237 us for the kernel (the opposite of the camera fill)
                         jp0 += step;
                     }
                     lp += U * lstep; dst += U * dstep;

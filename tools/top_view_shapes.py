@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): top view kernel time / bandwidth for a few map and pixel-scale shapes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import raycastworlds_jl_amd as RCW
+
+for H, W, pu, N in ((8, 8, 32, 256), (8, 16, 32, 512), (16, 16, 32, 256), (8, 8, 16, 256), (12, 12, 32, 256), (8, 8, 13, 256),
+                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64)):
+    px = H * pu * W * pu
+    B = max(64, min(8192, (1 << 30) // (4 * px)))
+    env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
+                                          width_tile_map_tu=W, num_rays=N, pu_per_tu=pu, render_top_view=True)
+    st = torch.cuda.Stream(); env.set_stream(st.cuda_stream); torch.cuda.set_stream(st)
+    a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        RCW.act_(env, a)
+    env.profile(True)
+    for _ in range(20):
+        RCW.act_(env, a)
+    c, t, f, n = env.profile_read(); env.profile(False)
+    by = 4 * px * B
+    print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d}: top view {t * 1e3:8.1f} us "
+          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %)", flush=True)
+    env.sync(); env.close()
