@@ -1034,10 +1034,8 @@ int rcw_gather_observations(rcw_handle* h, int32_t mode, void* frames_all)
     if (mode != RCW_GATHER_COLUMNS) return fail(RCW_ERR_INVALID_ARGUMENT, "unknown gather mode %d", mode);
     const size_t all = (size_t)h->B * h->comm_world;
     if ((long long)all > 0x7fffffffll) return fail(RCW_ERR_UNSUPPORTED, "global batch too large");
-    if (!h->d_gather_h) {
-        RCW_HIP(hipMalloc(&h->d_gather_h, all * N * sizeof(int32_t)));
-        RCW_HIP(hipMalloc(&h->d_gather_c, all * N));
-    }
+    if (!h->d_gather_h) RCW_HIP(hipMalloc(&h->d_gather_h, all * N * sizeof(int32_t)));
+    if (!h->d_gather_c) RCW_HIP(hipMalloc(&h->d_gather_c, all * N));
     rc = rcw_gather_columns(h, (int32_t*)h->d_gather_h, (uint8_t*)h->d_gather_c); if (rc) return rc;
     RCW_HIP(rcw_launch_expand(h->dev, (const int32_t*)h->d_gather_h, (const uint8_t*)h->d_gather_c, (int32_t)all,
                               (uint32_t*)frames_all, h->stream));
