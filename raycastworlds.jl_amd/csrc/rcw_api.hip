@@ -53,6 +53,10 @@ struct rcw_handle {
     void* d_dir_table = nullptr; void* d_ray_table = nullptr; void* d_obs = nullptr;
     void* d_col_h = nullptr; void* d_col_c = nullptr; void* d_err = nullptr; void* d_status = nullptr;
     void* d_top_view = nullptr;
+    // two-kernel top view: planes / player pixels / tile codes in HBM, the side stream the draw kernel runs on
+    void* d_top_plane = nullptr; void* d_top_hdr = nullptr; void* d_top_codes = nullptr;
+    hipStream_t top_stream = nullptr;
+    hipEvent_t ev_top_fork = nullptr, ev_top_join = nullptr;
     void* d_actions = nullptr; void* d_mask = nullptr;
     void* d_in_goal = nullptr; void* d_in_pos = nullptr; void* d_in_dir = nullptr;
     int32_t* h_err = nullptr;   // pinned
@@ -81,9 +85,31 @@ namespace {
 
 constexpr int kProfileSlots = 256;
 
-// One step = cast kernel + fill kernel, back to back on the handle's stream.  With profiling on,
+// update_top_view!(env) SR:446-483.  Two-kernel form: the draw kernel (VALU/LDS work, planes -> HBM) and the
+// moving-window store kernel.  `between` (the camera fill, inside a step) is launched on the handle's stream while
+// the draw kernel runs on the side stream: fork after what is already queued (the cast kernel), join before the store.
+template <typename Between>
+hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, Between between)
+{
+    const RcwDev& d = h->dev;
+    hipError_t e;
+    if (!d.top_split) {
+        if ((e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;
+        return between();
+    }
+    if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
+    if ((e = rcw_launch_top_draw(d, mask_dev, h->top_stream)) != hipSuccess) return e;
+    if ((e = hipEventRecord(h->ev_top_join, h->top_stream)) != hipSuccess) return e;
+    if ((e = between()) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(h->stream, h->ev_top_join, 0)) != hipSuccess) return e;
+    return rcw_launch_top_store(d, mask_dev, h->stream);
+}
+
+// One step = cast kernel + fill kernel, back to back on the handle's stream (+ the top view when the handle renders
+// it: before the fill with the one-kernel form, around it with the two-kernel form).  With profiling on,
 // HIP events bracket each kernel (what bench.py's roofline block reads the fill kernel's
-// duration from).
+// duration from): start | after cast | after the top view (one-kernel form) or the fill (two-kernel form) | end.
 hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t* mask_dev)
 {
     const RcwDev& d = h->dev;
@@ -93,9 +119,18 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
     if (prof && (e = hipEventRecord(ev[0], h->stream)) != hipSuccess) return e;
     if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
     if (prof && (e = hipEventRecord(ev[1], h->stream)) != hipSuccess) return e;
-    if (d.top_view && (e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;   // SR:337
-    if (prof && (e = hipEventRecord(ev[2], h->stream)) != hipSuccess) return e;
-    if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
+    auto fill = [&]() -> hipError_t {
+        hipError_t f;
+        if (prof && !d.top_split && (f = hipEventRecord(ev[2], h->stream)) != hipSuccess) return f;
+        if ((f = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return f;
+        if (prof && d.top_split && (f = hipEventRecord(ev[2], h->stream)) != hipSuccess) return f;
+        return hipSuccess;
+    };
+    if (d.top_view) { if ((e = launch_top_view(h, mask_dev, fill)) != hipSuccess) return e; }   // SR:337
+    else {
+        if (prof && (e = hipEventRecord(ev[2], h->stream)) != hipSuccess) return e;
+        if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
+    }
     if (prof) {
         if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e;
         h->prof_count++;
@@ -122,6 +157,11 @@ void free_all(rcw_handle* h)
         h->ev_actions[k] = nullptr;
     }
     for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    if (h->ev_top_fork) (void)hipEventDestroy(h->ev_top_fork);
+    if (h->ev_top_join) (void)hipEventDestroy(h->ev_top_join);
+    if (h->top_stream) (void)hipStreamDestroy(h->top_stream);
+    h->ev_top_fork = h->ev_top_join = nullptr; h->top_stream = nullptr;
     if (h->d_gather_h) (void)hipFree(h->d_gather_h);
     if (h->d_gather_c) (void)hipFree(h->d_gather_c);
     h->d_gather_h = h->d_gather_c = nullptr;
@@ -557,6 +597,23 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = std::getenv("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
     if (const char* v = std::getenv("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
 
+    // the two-kernel top view where the geometry allows it (RCW_TOP_SPLIT=0: keep the one-kernel ring form)
+    d.top_store_grid = d.fill_grid;
+    if (const char* v = std::getenv("RCW_TOP_STORE_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_store_grid = g; }
+    d.top_split = cfg->render_top_view && d.top_lds > 0 && rcw_top_split_ok(d) ? 1 : 0;
+    if (const char* v = std::getenv("RCW_TOP_SPLIT")) { if (!std::atoi(v)) d.top_split = 0; }
+    d.top_store_plain = 0;
+    if (const char* v = std::getenv("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
+    if (d.top_split) {
+        hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));
+        if (e == hipSuccess) e = hipMalloc(&h->d_top_hdr, (size_t)batch * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc(&h->d_top_codes, rcw_top_codes_bytes(d));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_join, hipEventDisableTiming);
+        if (e != hipSuccess) { free_all(h); delete h; return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "top view planes: %s", hipGetErrorString(e)); }
+        d.top_plane = (uint32_t*)h->d_top_plane; d.top_hdr = (int2*)h->d_top_hdr; d.top_codes = (uint2*)h->d_top_codes;
+    }
     if (cfg->render_top_view) {
         hipError_t e = rcw_prepare_top_view(d);
         if (e != hipSuccess) { free_all(h); delete h; return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e)); }
@@ -758,7 +815,7 @@ int rcw_update_top_view(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
     if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
-    RCW_HIP(rcw_launch_top_view(h->dev, nullptr, h->stream));
+    RCW_HIP(launch_top_view(h, nullptr, []() { return hipSuccess; }));
     return RCW_OK;
 }
 
@@ -1136,7 +1193,8 @@ int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* f
         RCW_HIP(hipEventElapsedTime(&a, h->prof_ev[4 * k], h->prof_ev[4 * k + 1]));
         RCW_HIP(hipEventElapsedTime(&b, h->prof_ev[4 * k + 1], h->prof_ev[4 * k + 2]));
         RCW_HIP(hipEventElapsedTime(&d, h->prof_ev[4 * k + 2], h->prof_ev[4 * k + 3]));
-        c += a; t += b; f += d;
+        c += a;
+        if (h->dev.top_split) { f += b; t += d; } else { t += b; f += d; }      // two-kernel top view: cast | fill (+ draw beside it) | store
     }
     *steps = h->prof_count;
     *cast_ms = h->prof_count ? (float)(c / h->prof_count) : 0.0f;

@@ -58,6 +58,12 @@ struct RcwDev {
     int32_t top_rp;          // player_radius_pu = wu_to_pu(player_radius_wu, pu)  SR:469 (host-computed in T)
     int32_t top_lds;         // write-once LDS bit-plane kernel: the number of buffers in its ring (1..3); 0: in-place fallback
     int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
+    int32_t top_split;       // 1: the two-kernel top view (draw kernel -> planes in HBM -> moving-window store kernel)
+    int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
+    int32_t top_store_grid;  // ... and its workgroups (the moving window = top_store_grid KiB x 4)
+    uint32_t* top_plane;     // [B][W*pu][H*pu/32] ray-line bit plane of every agent (two-kernel top view)
+    int2* top_hdr;           // [B] the player's pixel (ip, jp), 1-based  SR:468
+    uint2* top_codes;        // [B][W][H*pu/256] 2-bit fill codes of a chunk's tiles
     int32_t top_debug;       // development only (RCW_TOP_DEBUG): bit 0 skip drawing, bit 1 skip storing — for timing the halves
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
     int32_t* status;         // per-agent sticky status
@@ -84,6 +90,12 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
 // LDS bytes of the write-once top view kernel for this geometry, and the one-off preparation (raises the
 // kernel's dynamic LDS limit when the bit planes need more than 64 KiB); sets nothing on the device.
 size_t rcw_top_view_lds_bytes(const RcwDev& p);
+// the two-kernel top view: eligibility of a geometry, its HBM scratch sizes, and the two launches
+bool rcw_top_split_ok(const RcwDev& p);
+size_t rcw_top_plane_bytes(const RcwDev& p);
+size_t rcw_top_codes_bytes(const RcwDev& p);
+hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
+hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_prepare_top_view(const RcwDev& p);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos /* float2* or double2* */,

@@ -917,7 +917,7 @@ __device__ __forceinline__ void top_prepare(const RcwDev& p, int a, const TopBuf
 
 // draw group, second half: one line per ray from the player to the ray's stop point (SR:473-477) and the player
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b, int tid)
+__device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b, int tid, bool with_circle = true)
 {
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     const typename Real<T>::vec2 pos = Real<T>::pos(p)[a];
@@ -995,7 +995,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     }
     // the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed).  Its plane is
     // separate from the lines', so one lane of the LAST wavefront draws it while the others finish their lines.
-    if (tid == kTopGroup - 1) {
+    if (with_circle && tid == kTopGroup - 1) {
         const int jc0 = jp - rp;                                             // first image column of the circle plane (1-based)
         int x = 0, y = rp, dd = 1 - rp;
         auto put = [&](int i, int j) {
@@ -1215,6 +1215,241 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
     }
 }
 
+// ---- the top view as two kernels: draw (VALU/LDS work) | store (HBM work) ------------------------------------------
+// A frame-per-workgroup store stream (the ring kernel above) tops out at ≈ 75 % of the HBM write peak on this chip;
+// the camera fill's moving window — all wavefronts of the device sweeping ONE compact window of 1 KiB chunks —
+// reaches 86 %.  The window needs every agent's line plane visible to every wavefront, so here the drawing is a
+// kernel of its own that leaves the planes in HBM (Ht·Wt/8 bytes per agent, 1/32 of the image), and the store
+// kernel is the fill kernel's sweep with the top view's pixel logic.  Inside a step the draw kernel runs on a side
+// stream next to the camera fill (rcw_api.hip: launch_step) — one is VALU/LDS-bound, the other HBM-bound — so its
+// time is hidden; stand-alone the two run back to back.
+// Taken when a 1 KiB chunk (256 pixels of one image column) holds whole tiles and a lane's four pixels whole
+// quarters of one: pu in {8, 16, 32, 64, 128, 256}, H·pu a multiple of 256; and the player's circle fits one
+// 32-bit mask per image column (2·rp + 1 <= 32).  Other geometries keep the ring kernel.
+//
+// Draw kernel: one workgroup per agent; what the draw group of the ring kernel does, then the line plane is copied
+// out unpadded, with the player's pixel (SR:468) and, per (tile column, row block), the 2-bit fill codes of the
+// chunk's tiles packed into 64 bits.
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kTopGroup) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    if (mask != nullptr && mask[a] == 0) return;                             // workgroup-uniform
+    const TopBuf b = top_buf(p, lds);
+    top_prepare(p, a, b, tid);
+    __syncthreads();
+    top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid, false);
+    __syncthreads();
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu;
+    const int wpc = top_col_bits(p) >> 5, wpu = Ht >> 5, k = Ht >> 8, tpc = 256 / pu;
+    uint32_t* const out = p.top_plane + (size_t)a * Wt * wpu;
+    const int total = Wt * wpu, qstep = kTopGroup / wpu, rstep = kTopGroup - qstep * wpu;
+    int j = tid / wpu, w = tid - j * wpu;
+    for (int idx = tid; idx < total; idx += kTopGroup) {
+        out[idx] = b.line[j * wpc + w];
+        j += qstep; w += rstep;
+        if (w >= wpu) { w -= wpu; j += 1; }
+    }
+    if (tid == 0) p.top_hdr[a] = make_int2(b.hdr[0], b.hdr[1]);
+    for (int e = tid; e < p.W * k; e += kTopGroup) {
+        const int tj = e / k, rb = e - tj * k;
+        const uint8_t* const tiles = b.tb + rb * tpc + p.H * tj;
+        uint32_t lo = 0u, hi = 0u;
+        for (int t = 0; t < tpc; ++t) {
+            const uint32_t code = (tiles[t] & 1u) ? 1u : (tiles[t] & 2u);          // wall (white) before goal (red)  SR:355-360
+            if (t < 16) lo |= code << (2 * t); else hi |= code << (2 * (t - 16));
+        }
+        p.top_codes[((size_t)a * p.W + tj) * k + rb] = make_uint2(lo, hi);
+    }
+}
+
+// Store kernel: the moving window of rcw_fill256_kernel over the top view's 1 KiB chunks (chunk id = flat pixel
+// offset / 256: image column (a, j), row block rb).  Per 64 chunks of a wavefront, lane l computes the descriptor
+// of the l-th (tile codes, frame column, the player's circle as a 32-bit row mask for that column), and the 8 plane
+// words of each chunk are fetched by 8 lanes (8 loads per lane for the 64 chunks); per chunk the descriptor is
+// broadcast with v_readlane, the plane word reaches its lane with ds_bpermute, and lane l writes rows 4l..4l+3 with
+// one 16-byte store: colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480).
+// The circle: SD.Circle's pixels in the image column at distance c from the player's are the same rows relative to
+// the player for every agent (midpoint circle, assumed): lane c computes that row mask once per kernel.
+// what depends on the lane only
+struct TopLane {
+    int r_lane, sh, code_sh, bp0;
+    bool code_hi, first_row, last_row;
+    uint32_t cm;                 // lane c: the circle's rows at column distance c
+};
+__device__ __forceinline__ TopLane top_lane(const RcwDev& p, int lane)
+{
+    TopLane L;
+    const int pu = p.pu, rp = p.top_rp;
+    L.r_lane = lane * 4;
+    const int tl = L.r_lane / pu, ri = L.r_lane - tl * pu;                   // tile within the chunk, row within the tile
+    L.first_row = ri == 0; L.last_row = ri + 3 == pu - 1;                    // SR:364-365: the tile's frame rows
+    L.sh = L.r_lane & 31;
+    L.code_sh = 2 * (tl & 15);
+    L.code_hi = tl >= 16;
+    L.bp0 = (lane >> 3) * 4;                                                 // ds_bpermute address of lane (lane >> 3)
+    L.cm = 0u;
+    int x = 0, y = rp, dd = 1 - rp;
+    while (x <= y) {
+        if (y == lane) L.cm |= (1u << (rp + x)) | (1u << (rp - x));
+        if (x == lane) L.cm |= (1u << (rp + y)) | (1u << (rp - y));
+        x += 1;
+        if (dd < 0) dd += 2 * x + 1;
+        else { y -= 1; dd += 2 * (x - y) + 1; }
+    }
+    return L;
+}
+
+// v_bfe_i32 (one bit, sign-extended: 0 or ~0) and v_bfi_b32 by name: written in C the compiler turns the pair into
+// and + compare + select, three instructions a pixel instead of two — and this kernel's wavefronts (one per SIMD, as
+// the moving window wants) are short of issue slots, not of bandwidth.
+__device__ __forceinline__ uint32_t bit_to_mask(uint32_t bits, uint32_t pos)
+{
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "v"(pos));
+    return m;
+}
+__device__ __forceinline__ uint32_t bit_to_mask_s(uint32_t uniform_bits, uint32_t pos)
+{
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "s"(uniform_bits), "v"(pos));
+    return m;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t on, uint32_t off)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(on), "v"(off));
+    return r;
+}
+
+// the four pixels of a lane: `word` = the plane word holding its rows, the rest wave-uniform (the chunk's descriptor).
+// Tile codes: bit 0 = wall (white), bit 1 = goal and not wall (red)  SR:355-360, SR:288.
+__device__ __forceinline__ u32x4 top_chunk_pixels(const TopLane& L, uint32_t word, uint32_t s_lo, uint32_t s_hi,
+                                                  int s_flags, uint32_t s_cm, int s_r0)
+{
+    const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
+    u32x4 o;
+    if (s_flags & 2) {                                                       // wave-uniform: a tile's frame column
+        o.x = o.y = o.z = o.w = grid_c;
+    } else {
+        uint32_t white, red;
+        if (s_flags & 4) {                                                   // wave-uniform: more than 16 tiles in a chunk
+            const uint32_t codes = L.code_hi ? s_hi : s_lo;
+            white = bit_to_mask(codes, L.code_sh); red = bit_to_mask(codes, L.code_sh + 1);
+        } else {
+            white = bit_to_mask_s(s_lo, L.code_sh); red = bit_to_mask_s(s_lo, L.code_sh + 1);
+        }
+        const uint32_t fill = (white & 0x00FFFFFFu) | (red & 0x00FF0000u);
+        o.x = L.first_row ? grid_c : fill;
+        o.y = fill; o.z = fill;
+        o.w = L.last_row ? grid_c : fill;
+    }
+    o.x = bfi(bit_to_mask(word, L.sh), ray_c, o.x);     o.y = bfi(bit_to_mask(word, L.sh + 1), ray_c, o.y);
+    o.z = bfi(bit_to_mask(word, L.sh + 2), ray_c, o.z); o.w = bfi(bit_to_mask(word, L.sh + 3), ray_c, o.w);
+    if (s_cm != 0u) {                                                        // a column of the player's circle
+        const int q0 = L.r_lane - s_r0;                                      // mask bit of this lane's first pixel
+        uint32_t cb = q0 >= 0 ? (q0 < 32 ? s_cm >> q0 : 0u) : (q0 > -4 ? s_cm << -q0 : 0u);
+        o.x = bfi(bit_to_mask(cb, 0), player_c, o.x); o.y = bfi(bit_to_mask(cb, 1), player_c, o.y);
+        o.z = bfi(bit_to_mask(cb, 2), player_c, o.z); o.w = bfi(bit_to_mask(cb, 3), player_c, o.w);
+    }
+    return o;
+}
+
+// A group = the next 64 chunks of a wavefront; lane l holds the descriptor of the l-th.
+struct TopGroup {
+    int flags, r0, woff;         // bit 0 valid, bit 1 frame column | chunk row of the circle mask's bit 0 | plane word offset
+    uint32_t code_lo, code_hi, cmask;
+    uint32_t pw[8];              // register m of lane l = plane word (l & 7) of chunk 8 m + (l >> 3)
+    int2 hd; uint32_t j, rb;     // (between issue and finish)
+};
+// first half: addresses and the loads (nothing here waits for a load)
+__device__ __forceinline__ void top_group_issue(const RcwDev& p, const uint8_t* __restrict__ mask, uint32_t base, uint32_t G,
+                                                uint32_t total, int lane, TopGroup& g)
+{
+    const int pu = p.pu, Wt = p.W * pu;
+    const uint32_t k = (uint32_t)(p.H * pu) >> 8, wpu = (uint32_t)(p.H * pu) >> 5;
+    const uint32_t id = base + (uint32_t)lane * G;
+    bool valid = id < total;
+    const uint32_t col = id / k, rb = id - col * k;
+    const uint32_t a = col / (uint32_t)Wt, j = col - a * (uint32_t)Wt;
+    const uint32_t tj = j / (uint32_t)pu, rj = j - tj * (uint32_t)pu;
+    if (valid && mask != nullptr && mask[a] == 0) valid = false;
+    g.flags = 0; g.woff = -1; g.code_lo = g.code_hi = 0u; g.hd = make_int2(0, 0); g.j = j; g.rb = rb;
+    if (valid) {
+        g.flags = 1 | ((rj == 0 || rj == (uint32_t)pu - 1) ? 2 : 0) | (pu < 16 ? 4 : 0);   // SR:366-367: the tile's frame columns | 32 tiles in a chunk
+        const uint2 cd = p.top_codes[((size_t)a * p.W + tj) * k + rb];
+        g.hd = p.top_hdr[a];
+        g.code_lo = cd.x; g.code_hi = cd.y;
+        g.woff = (int)(col * wpu + rb * 8);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int wo = __shfl(g.woff, 8 * m + (lane >> 3), 64);
+        g.pw[m] = wo >= 0 ? p.top_plane[(size_t)wo + (lane & 7)] : 0u;
+    }
+}
+// second half: everything that uses a loaded value.  The loads are waited for HERE, once per 64 chunks: left to the
+// compiler the wait lands in every chunk's body as s_waitcnt vmcnt(0) (its wait-count bookkeeping merges the paths of
+// the wave-uniform branches) — which also drains the wavefront's stores, one at a time.
+__device__ __forceinline__ void top_group_finish(const RcwDev& p, const TopLane& L, TopGroup& g)
+{
+    const int rp = p.top_rp;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("v_mov_b32 %0, %1" : "=v"(g.pw[m]) : "v"(g.pw[m]));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(g.code_lo) : "v"(g.code_lo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(g.code_hi) : "v"(g.code_hi));
+    const int dist = (g.flags & 1) ? abs((int)g.j + 1 - g.hd.y) : 64;
+    g.r0 = g.hd.x - 1 - rp - 256 * (int)g.rb;
+    g.cmask = (uint32_t)__shfl((int)L.cm, dist & 63, 64);
+    if (dist > rp || g.r0 >= 256 || g.r0 + 2 * rp < 0) g.cmask = 0u;
+}
+
+// Store kernel: the moving window of rcw_fill256_kernel over the top view's 1 KiB chunks (chunk id = flat pixel
+// offset / 256: image column (a, j), row block rb).  Per 64 chunks of a wavefront, lane l computes the descriptor
+// of the l-th (tile codes, frame column, the player's circle as a 32-bit row mask for that column), and the 8 plane
+// words of each chunk are fetched by 8 lanes (8 loads per lane for the 64 chunks); per chunk the descriptor is
+// broadcast with v_readlane, the plane word reaches its lane with ds_bpermute, and lane l writes rows 4l..4l+3 with
+// one 16-byte store: colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480).
+// The circle: SD.Circle's pixels in the image column at distance c from the player's are the same rows relative to
+// the player for every agent (midpoint circle, assumed): lane c computes that row mask once per kernel.
+// (Issuing the next group's loads before this group's 64 stores, so that waiting for them would not wait for the
+// stores, measured SLOWER: 201 vs 178 µs at 4096 x 256² px — the drain once per 64 chunks costs less than it looks.)
+template <bool PLAIN>
+__global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t G = gridDim.x * (kBlock / 64);
+    const uint32_t g = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t total = (uint32_t)p.B * (uint32_t)(p.W * p.pu) * ((uint32_t)(p.H * p.pu) >> 8);
+    u32x4* const out = reinterpret_cast<u32x4*>(p.top_view);
+    const TopLane L = top_lane(p, lane);
+    const size_t dstep = (size_t)G * 64;
+    uint32_t base = g;
+    for (; base < total; base += G * 64) {
+        TopGroup cur;
+        top_group_issue(p, mask, base, G, total, lane, cur);
+        top_group_finish(p, L, cur);
+        u32x4* dst = out + (size_t)base * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            int bpa = L.bp0;
+#pragma unroll 2
+            for (int c = 0; c < 8; ++c, dst += dstep, bpa += 32) {
+                const int t = 8 * m + c;
+                const int s_flags = __builtin_amdgcn_readlane(cur.flags, t);
+                if (!(s_flags & 1)) continue;                                // wave-uniform: past the end / masked out
+                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(bpa, (int)cur.pw[m]);
+                const u32x4 o = top_chunk_pixels(L, w, (uint32_t)__builtin_amdgcn_readlane((int)cur.code_lo, t),
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)cur.code_hi, t), s_flags,
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)cur.cmask, t),
+                                                 __builtin_amdgcn_readlane(cur.r0, t));
+                store16<PLAIN>(dst, o);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -1308,6 +1543,31 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
     return hipGetLastError();
 }
 
+// The two-kernel top view (see rcw_top_draw_kernel): whether this geometry takes it
+bool rcw_top_split_ok(const RcwDev& p)
+{
+    const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
+    if (p.pu < 8 || 256 % p.pu != 0 || Ht % 256 != 0) return false;
+    if (2 * p.top_rp > 31) return false;
+    if ((long long)p.B * Wt * (Ht >> 8) + 64ll * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return false;   // chunk ids in 32 bits
+    if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31)) return false;                                            // plane word offsets
+    return 4 * top_buf_words(p) <= 156 * 1024;
+}
+size_t rcw_top_plane_bytes(const RcwDev& p) { return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4; }
+size_t rcw_top_codes_bytes(const RcwDev& p) { return (size_t)p.B * p.W * ((size_t)p.H * p.pu / 256) * sizeof(uint2); }
+
+hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
+{
+    RCW_DISPATCH(rcw_top_draw_kernel, dim3(p.B), dim3(kTopGroup), 4 * top_buf_words(p), p, mask_dev);
+    return hipGetLastError();
+}
+hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
+{
+    if (p.top_store_plain) hipLaunchKernelGGL(rcw_top_store_kernel<true>, dim3(p.top_store_grid), dim3(kBlock), 0, s, p, mask_dev);
+    else                   hipLaunchKernelGGL(rcw_top_store_kernel<false>, dim3(p.top_store_grid), dim3(kBlock), 0, s, p, mask_dev);
+    return hipGetLastError();
+}
+
 // Above 64 KiB of dynamic LDS a kernel has to be told so once (the CU has 160 KiB).
 hipError_t rcw_prepare_top_view(const RcwDev& p)
 {
@@ -1317,7 +1577,10 @@ hipError_t rcw_prepare_top_view(const RcwDev& p)
 #define RCW_TOP_ATTR(TT, A, B_)                                                                                         \
     if (e == hipSuccess)                                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rcw_top_view_kernel<TT, A, B_>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);                                \
+    if (e == hipSuccess && p.top_split)                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rcw_top_draw_kernel<TT, A, B_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * top_buf_words(p)))
     if (p.real64) { RCW_TOP_ATTR(double, false, false); RCW_TOP_ATTR(double, false, true); RCW_TOP_ATTR(double, true, false); RCW_TOP_ATTR(double, true, true); }
     else          { RCW_TOP_ATTR(float, false, false); RCW_TOP_ATTR(float, false, true); RCW_TOP_ATTR(float, true, false); RCW_TOP_ATTR(float, true, true); }
 #undef RCW_TOP_ATTR

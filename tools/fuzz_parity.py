@@ -3,7 +3,8 @@
 configurations (map size, columns, headings, field of view, radius, step, camera height, image
 height, world-unit type, the three unpinned switches, both BoundsError policies, auto-reset).
 
-    python tools/fuzz_parity.py [configs] [seed] [top]     # "top": every configuration renders the top view
+    python tools/fuzz_parity.py [configs] [seed] [top|split]   # "top": every configuration renders the top view;
+                                                              # "split": ... with a geometry the two-kernel top view takes
 """
 import os
 import sys
@@ -18,7 +19,8 @@ from oracle import oracle as O
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-always_top = len(sys.argv) > 3 and sys.argv[3] == "top"
+always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split")
+split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the two-kernel top view: pu | 256, H*pu % 256 == 0
 fails = 0
 O.set_num_threads(8)
 for c in range(n_cfg):
@@ -39,6 +41,12 @@ for c in range(n_cfg):
               pu_per_tu=int(rng.choice([4, 8, 13, 32, 40, 52] if always_top else [4, 8, 13, 32])))
     R = str(rng.choice(["Float32", "Float64", "Int32", "Int64"]))
     B = int(rng.integers(1, 40))
+    if split_geometry:
+        pu = int(rng.choice([8, 16, 32, 32, 64, 128]))
+        kw["pu_per_tu"] = pu
+        kw["height_tile_map_tu"] = max(4, (256 // pu) * int(rng.integers(1, 4)))       # Ht = 256, 512 or 768 (or 4 tall tiles)
+        kw["width_tile_map_tu"] = int(rng.integers(4, 10 if pu >= 64 else 20))
+        B = int(rng.integers(1, 12 if pu >= 64 else 40))
     seed = int(rng.integers(0, 2**31))
     okw = {k: v for k, v in kw.items()}
     okw["auto_reset"] = int(kw["auto_reset"]); okw["render_top_view"] = int(kw["render_top_view"])
