@@ -1325,6 +1325,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t on, uint32_t off
 
 // the four pixels of a lane: `word` = the plane word holding its rows, the rest wave-uniform (the chunk's descriptor).
 // Tile codes: bit 0 = wall (white), bit 1 = goal and not wall (red)  SR:355-360, SR:288.
+template <bool WIDE>      // WIDE: more than 16 tiles in a chunk (pu = 8), their codes take both words
 __device__ __forceinline__ u32x4 top_chunk_pixels(const TopLane& L, uint32_t word, uint32_t s_lo, uint32_t s_hi,
                                                   int s_flags, uint32_t s_cm, int s_r0)
 {
@@ -1334,7 +1335,7 @@ __device__ __forceinline__ u32x4 top_chunk_pixels(const TopLane& L, uint32_t wor
         o.x = o.y = o.z = o.w = grid_c;
     } else {
         uint32_t white, red;
-        if (s_flags & 4) {                                                   // wave-uniform: more than 16 tiles in a chunk
+        if (WIDE) {
             const uint32_t codes = L.code_hi ? s_hi : s_lo;
             white = bit_to_mask(codes, L.code_sh); red = bit_to_mask(codes, L.code_sh + 1);
         } else {
@@ -1377,7 +1378,7 @@ __device__ __forceinline__ void top_group_issue(const RcwDev& p, const uint8_t* 
     if (valid && mask != nullptr && mask[a] == 0) valid = false;
     g.flags = 0; g.woff = -1; g.code_lo = g.code_hi = 0u; g.hd = make_int2(0, 0); g.j = j; g.rb = rb;
     if (valid) {
-        g.flags = 1 | ((rj == 0 || rj == (uint32_t)pu - 1) ? 2 : 0) | (pu < 16 ? 4 : 0);   // SR:366-367: the tile's frame columns | 32 tiles in a chunk
+        g.flags = 1 | ((rj == 0 || rj == (uint32_t)pu - 1) ? 2 : 0);         // SR:366-367: the tile's frame columns
         const uint2 cd = p.top_codes[((size_t)a * p.W + tj) * k + rb];
         g.hd = p.top_hdr[a];
         g.code_lo = cd.x; g.code_hi = cd.y;
@@ -1415,36 +1416,43 @@ __device__ __forceinline__ void top_group_finish(const RcwDev& p, const TopLane&
 // the player for every agent (midpoint circle, assumed): lane c computes that row mask once per kernel.
 // (Issuing the next group's loads before this group's 64 stores, so that waiting for them would not wait for the
 // stores, measured SLOWER: 201 vs 178 µs at 4096 x 256² px — the drain once per 64 chunks costs less than it looks.)
-template <bool PLAIN>
+template <bool PLAIN, bool WIDE>
 __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t G = gridDim.x * (kBlock / 64);
-    const uint32_t g = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the store's address is SGPR base + lane offset)
     const uint32_t total = (uint32_t)p.B * (uint32_t)(p.W * p.pu) * ((uint32_t)(p.H * p.pu) >> 8);
     u32x4* const out = reinterpret_cast<u32x4*>(p.top_view);
     const TopLane L = top_lane(p, lane);
     const size_t dstep = (size_t)G * 64;
+    __shared__ uint32_t plane_words[(kBlock / 64) * 512];
+    uint32_t* const lw_write = plane_words + (threadIdx.x >> 6) * 512 + lane;
+    const uint32_t* const lw_read = plane_words + (threadIdx.x >> 6) * 512 + (lane >> 3);
     uint32_t base = g;
     for (; base < total; base += G * 64) {
         TopGroup cur;
         top_group_issue(p, mask, base, G, total, lane, cur);
         top_group_finish(p, L, cur);
-        u32x4* dst = out + (size_t)base * 64 + lane;
+        // the plane words go through a wave-private 2 KiB of LDS (index 8 t + word: lane l's register m is entry
+        // 64 m + l), so that ONE loop over the 64 chunks can fetch them (a register per eight chunks would need eight
+        // copies of the loop — and the compiler then carries all their store pointers through every one of them)
+        __builtin_amdgcn_wave_barrier();                                     // (the lanes of a wavefront exchange through it: no reordering across)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            int bpa = L.bp0;
+        for (int m = 0; m < 8; ++m) lw_write[64 * m] = cur.pw[m];
+        __builtin_amdgcn_wave_barrier();
+        u32x4* dst = out + (size_t)base * 64;                                // wave-uniform
 #pragma unroll 2
-            for (int c = 0; c < 8; ++c, dst += dstep, bpa += 32) {
-                const int t = 8 * m + c;
+        for (int t = 0; t < 64; ++t, dst += dstep) {
+            {
                 const int s_flags = __builtin_amdgcn_readlane(cur.flags, t);
                 if (!(s_flags & 1)) continue;                                // wave-uniform: past the end / masked out
-                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(bpa, (int)cur.pw[m]);
-                const u32x4 o = top_chunk_pixels(L, w, (uint32_t)__builtin_amdgcn_readlane((int)cur.code_lo, t),
-                                                 (uint32_t)__builtin_amdgcn_readlane((int)cur.code_hi, t), s_flags,
-                                                 (uint32_t)__builtin_amdgcn_readlane((int)cur.cmask, t),
-                                                 __builtin_amdgcn_readlane(cur.r0, t));
-                store16<PLAIN>(dst, o);
+                const uint32_t w = lw_read[8 * t];
+                const u32x4 o = top_chunk_pixels<WIDE>(L, w, (uint32_t)__builtin_amdgcn_readlane((int)cur.code_lo, t),
+                                                       WIDE ? (uint32_t)__builtin_amdgcn_readlane((int)cur.code_hi, t) : 0u, s_flags,
+                                                       (uint32_t)__builtin_amdgcn_readlane((int)cur.cmask, t),
+                                                       __builtin_amdgcn_readlane(cur.r0, t));
+                store16<PLAIN>(dst + lane, o);
             }
         }
     }
@@ -1563,8 +1571,14 @@ hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStre
 }
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
-    if (p.top_store_plain) hipLaunchKernelGGL(rcw_top_store_kernel<true>, dim3(p.top_store_grid), dim3(kBlock), 0, s, p, mask_dev);
-    else                   hipLaunchKernelGGL(rcw_top_store_kernel<false>, dim3(p.top_store_grid), dim3(kBlock), 0, s, p, mask_dev);
+    const dim3 grid(p.top_store_grid), block(kBlock);
+    if (p.pu < 16) {                                                         // 32 tiles in a chunk
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, true>), grid, block, 0, s, p, mask_dev);
+        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, true>), grid, block, 0, s, p, mask_dev);
+    } else {
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, false>), grid, block, 0, s, p, mask_dev);
+        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, false>), grid, block, 0, s, p, mask_dev);
+    }
     return hipGetLastError();
 }
 
