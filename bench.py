@@ -335,10 +335,16 @@ def main():
             top_bytes = 4 * (kw["height_tile_map_tu"] * pu) * (kw["width_tile_map_tu"] * pu) * B
             top_gbs = top_bytes / (top_ms / 1e3) / 1e9
             out["config"]["render_top_view"] = True
+            form = env.top_view_form()
             out["top_view"] = {
-                "kernel": "rcw_top_view_kernel", "bound": "hbm", "bytes_per_launch": top_bytes, "launch_ms": top_ms,
+                "form": form,
+                "kernel": "rcw_top_store_kernel" if form == "two-kernels" else "rcw_top_view_kernel",
+                "bound": "hbm", "bytes_per_launch": top_bytes, "launch_ms": top_ms,
                 "achieved": top_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top_gbs / HBM_PEAK_GBS,
-                "note": "update_top_view! SR:446-483, 4*(H*pu)*(W*pu) bytes per agent written once; opt-in, not in `value` of the headline run",
+                "note": "update_top_view! SR:446-483, 4*(H*pu)*(W*pu) bytes per agent written once; opt-in, not in `value` of the headline run"
+                        + ("; two-kernel form: launch_ms is the store kernel (the one that writes the image), the draw kernel "
+                           "(rcw_top_draw_kernel, VALU/LDS work, planes of 1/32 of the image) runs on a side stream beside the "
+                           "camera fill and is inside the fill's launch_ms — see profiles/ for its own duration" if form == "two-kernels" else ""),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, B)

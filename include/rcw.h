@@ -343,9 +343,20 @@ RCW_API int rcw_timer_stop(rcw_handle* h, float* elapsed_ms);
 
 /* Per-kernel timing: while enabled, HIP events bracket the cast kernel, the top view kernel (when
  * cfg.render_top_view) and the fill kernel of each step (at most 256 steps are recorded).
- * rcw_profile_read returns their mean durations over the recorded steps (top_view_ms = 0 without it). */
+ * rcw_profile_read returns their mean durations over the recorded steps (top_view_ms = 0 without it).
+ * With the two-kernel top view (RCW_TOP_VIEW_TWO_KERNELS below) top_view_ms is its store kernel — the one that
+ * writes the image; its draw kernel runs on a side stream beside the camera fill, inside fill_ms. */
 RCW_API int rcw_profile(rcw_handle* h, int32_t enable);
 RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* fill_ms, int32_t* steps);
+
+/* Which form of update_top_view! (SR:446-483) the handle's geometry takes — all write the same pixels:
+ *   RCW_TOP_VIEW_NONE         cfg.render_top_view = 0
+ *   RCW_TOP_VIEW_IN_PLACE     tiles, then lines and circle drawn over them in HBM (images beyond the LDS bit planes)
+ *   RCW_TOP_VIEW_ONE_KERNEL   write-once: bit planes in LDS, draw and store groups of one persistent kernel
+ *   RCW_TOP_VIEW_TWO_KERNELS  write-once: draw kernel (bit planes -> HBM, beside the camera fill inside a step),
+ *                             then the moving-window store kernel (pu_per_tu in 8..256 dividing 256, H*pu % 256 == 0) */
+enum { RCW_TOP_VIEW_NONE = 0, RCW_TOP_VIEW_IN_PLACE = 1, RCW_TOP_VIEW_ONE_KERNEL = 2, RCW_TOP_VIEW_TWO_KERNELS = 3 };
+RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
 
 /* Introspection */
 RCW_API int rcw_batch(rcw_handle* h, int32_t* out);

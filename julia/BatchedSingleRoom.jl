@@ -420,6 +420,12 @@ function profile_read(env::BatchedSingleRoom)
                 env.handle, c, t, f, n))
     return (cast_ms = c[], top_view_ms = t[], fill_ms = f[], steps = n[])
 end
+"Which kernel form `update_top_view!` takes: `:none`, `:in_place`, `:one_kernel` or `:two_kernels` (rcw.h)."
+function top_view_form(env::BatchedSingleRoom)
+    f = Ref{Int32}(0)
+    check(ccall((:rcw_top_view_form, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, f))
+    return (:none, :in_place, :one_kernel, :two_kernels)[f[] + 1]
+end
 function batch(env::BatchedSingleRoom)
     n = Ref{Int32}(0)
     check(ccall((:rcw_batch, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, n)); Int(n[])

@@ -131,6 +131,7 @@ SIGNATURES = {
     "rcw_timer_stop": [_vp, C.POINTER(C.c_float)],
     "rcw_profile": [_vp, _i32],
     "rcw_profile_read": [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)],
+    "rcw_top_view_form": [_vp, C.POINTER(_i32)],
     "rcw_comm_unique_id": [_vp],
     "rcw_comm_init": [_vp, _vp, _i32, _i32],
     "rcw_comm_destroy": [_vp],

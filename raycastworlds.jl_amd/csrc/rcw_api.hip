@@ -1203,6 +1203,14 @@ int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* f
     return RCW_OK;
 }
 
+int rcw_top_view_form(rcw_handle* h, int32_t* form)
+{
+    if (!h || !form) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    const RcwDev& d = h->dev;
+    *form = !d.top_view ? RCW_TOP_VIEW_NONE : d.top_split ? RCW_TOP_VIEW_TWO_KERNELS : d.top_lds ? RCW_TOP_VIEW_ONE_KERNEL : RCW_TOP_VIEW_IN_PLACE;
+    return RCW_OK;
+}
+
 int rcw_batch(rcw_handle* h, int32_t* out)
 {
     if (!h || !out) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");

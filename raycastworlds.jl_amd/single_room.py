@@ -490,10 +490,17 @@ class SingleRoom:
         _capi.check(self._lib.rcw_profile(self._h, 1 if enable else 0))
 
     def profile_read(self):
-        """(mean cast kernel ms, mean top view kernel ms (0 without it), mean fill kernel ms, steps recorded)."""
+        """(mean cast kernel ms, mean top view kernel ms (0 without it), mean fill kernel ms, steps recorded).
+        With the two-kernel top view the second is its store kernel; its draw kernel runs beside the fill."""
         c, t, f, n = C.c_float(), C.c_float(), C.c_float(), C.c_int32()
         _capi.check(self._lib.rcw_profile_read(self._h, C.byref(c), C.byref(t), C.byref(f), C.byref(n)))
         return float(c.value), float(t.value), float(f.value), int(n.value)
+
+    def top_view_form(self) -> str:
+        """Which kernel form update_top_view! takes for this geometry: "none", "in-place", "one-kernel", "two-kernels"."""
+        f = C.c_int32()
+        _capi.check(self._lib.rcw_top_view_form(self._h, C.byref(f)))
+        return ("none", "in-place", "one-kernel", "two-kernels")[f.value]
 
     def timer_start(self):
         _capi.check(self._lib.rcw_timer_start(self._h))

@@ -279,7 +279,7 @@ def test_top_view_matches_oracle(rcw, oracle):
     rng = np.random.default_rng(13)
     for kw in (dict(pu_per_tu=32, **CFG1), dict(pu_per_tu=32), dict(pu_per_tu=10, **CFG2),
                dict(pu_per_tu=7, height_tile_map_tu=9, width_tile_map_tu=12, num_rays=100),
-               dict(pu_per_tu=32, **CFG3)):      # 512 x 512 px: too big for the LDS bit planes -> in-place path
+               dict(pu_per_tu=32, **CFG3)):      # 512 x 512 px
         env, orc = _make(rcw, oracle, 12, seed=17, render_top_view=1, **kw)
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
         for s in range(40):
@@ -583,6 +583,55 @@ def test_top_view_in_place_fallback(rcw, oracle):
             env.clear_error(); orc.clear_status()
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after steps {kw}")
         env.close()
+
+
+@pytest.mark.parametrize("env_switch, form", [(None, "two-kernels"), (("RCW_TOP_SPLIT", "0"), "one-kernel"),
+                                              (("RCW_TOP_INPLACE", "1"), "in-place")])
+def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_switch, form):
+    """The three kernel forms of update_top_view! (rcw.h: rcw_top_view_form) against the oracle on the same states:
+    the two-kernel form (draw kernel beside the camera fill, moving-window store kernel) is what an eligible geometry
+    takes; the development switches force the other two.  300 agents x 256 columns of 256 px = 76,800 chunks: more
+    than one sweep of the store kernel's window (65,536), so its last group is a partial one; the masked reset
+    exercises its skipped chunks; 16 px tiles put two tile rows into one lane group."""
+    if env_switch:
+        monkeypatch.setenv(*env_switch)
+    rng = np.random.default_rng(29)
+    for kw, batch in ((dict(pu_per_tu=32, **CFG2), 300), (dict(pu_per_tu=16, height_tile_map_tu=16, width_tile_map_tu=9, num_rays=100), 21),
+                      (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
+                      (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=20, num_rays=33, player_radius_wu=0.3,
+                            position_increment_wu=0.2), 9)):
+        env, orc = _make(rcw, oracle, batch, seed=23, render_top_view=1, **kw)
+        assert env.top_view_form() == form, kw
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
+        for s in range(12):
+            a = rng.integers(1, 5, batch).astype(np.uint8)
+            rcw.act_(env, a); orc.step(a)
+        try:
+            env.sync()
+        except IndexError:
+            env.clear_error(); orc.clear_status()
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after steps {kw}")
+        mask = (rng.random(batch) < 0.4).astype(np.uint8)
+        rcw.reset_(env, mask=mask, seed=8); orc.reset(mask=mask, seed=8)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after masked reset {kw}")
+        rcw.update_top_view_(env)                                            # the stand-alone call: draw, then store, one stream
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after update_top_view! {kw}")
+        assert_state_equal(env, orc, where=f"camera path unaffected {kw}")
+        env.close()
+
+
+def test_top_view_form_of_other_geometries(rcw):
+    """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form."""
+    for kw, form in ((dict(pu_per_tu=10, **CFG2), "one-kernel"),                      # 10 does not divide 256
+                     (dict(pu_per_tu=32, height_tile_map_tu=9, width_tile_map_tu=8), "one-kernel"),   # 288 rows
+                     (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), "one-kernel"),   # circle of 33 rows
+                     (dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), "in-place")):
+        env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, render_top_view=True, **kw)
+        assert env.top_view_form() == form, kw
+        env.close()
+    env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, **CFG2)
+    assert env.top_view_form() == "none"
+    env.close()
 
 
 def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
