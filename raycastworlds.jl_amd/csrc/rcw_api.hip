@@ -88,12 +88,13 @@ constexpr int kProfileSlots = 256;
 // update_top_view!(env) SR:446-483.  Two-kernel form: the draw kernel (VALU/LDS work, planes -> HBM) and the
 // moving-window store kernel.  `between` (the camera fill, inside a step) is launched on the handle's stream while
 // the draw kernel runs on the side stream: fork after what is already queued (the cast kernel), join before the store.
+// The stand-alone call (`beside` = false) has no camera fill to run beside and takes the one-kernel form.
 template <typename Between>
-hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, Between between)
+hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between)
 {
     const RcwDev& d = h->dev;
     hipError_t e;
-    if (!d.top_split) {
+    if (!d.top_split || !beside) {           // (nothing to hide the draw kernel behind: the one-kernel form is the faster one)
         if ((e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;
         return between();
     }
@@ -126,7 +127,7 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
         if (prof && d.top_split && (f = hipEventRecord(ev[2], h->stream)) != hipSuccess) return f;
         return hipSuccess;
     };
-    if (d.top_view) { if ((e = launch_top_view(h, mask_dev, fill)) != hipSuccess) return e; }   // SR:337
+    if (d.top_view) { if ((e = launch_top_view(h, mask_dev, true, fill)) != hipSuccess) return e; }   // SR:337
     else {
         if (prof && (e = hipEventRecord(ev[2], h->stream)) != hipSuccess) return e;
         if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
@@ -815,7 +816,7 @@ int rcw_update_top_view(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
     if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
-    RCW_HIP(launch_top_view(h, nullptr, []() { return hipSuccess; }));
+    RCW_HIP(launch_top_view(h, nullptr, false, []() { return hipSuccess; }));
     return RCW_OK;
 }
 

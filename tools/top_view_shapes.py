@@ -9,7 +9,7 @@ import torch
 import raycastworlds_jl_amd as RCW
 
 for H, W, pu, N in ((8, 8, 32, 256), (8, 16, 32, 512), (16, 16, 32, 256), (8, 8, 16, 256), (12, 12, 32, 256), (8, 8, 13, 256),
-                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64)):
+                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64), (32, 32, 8, 256), (24, 24, 32, 256)):
     px = H * pu * W * pu
     B = max(64, min(8192, (1 << 30) // (4 * px)))
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
@@ -23,6 +23,11 @@ for H, W, pu, N in ((8, 8, 32, 256), (8, 16, 32, 512), (16, 16, 32, 256), (8, 8,
         RCW.act_(env, a)
     c, t, f, n = env.profile_read(); env.profile(False)
     by = 4 * px * B
-    print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d}: top view {t * 1e3:8.1f} us "
-          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %)", flush=True)
+    # the stand-alone call (two-kernel form: draw, then store, back to back on one stream)
+    env.sync(); env.timer_start()
+    for _ in range(10):
+        RCW.update_top_view_(env)
+    alone = env.timer_stop() / 10
+    print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d} {env.top_view_form():11s}: in a step {t * 1e3:7.1f} us "
+          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %), camera fill beside it {f * 1e3:7.1f} us, stand-alone {alone * 1e3:7.1f} us", flush=True)
     env.sync(); env.close()
