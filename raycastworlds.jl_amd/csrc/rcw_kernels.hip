@@ -931,6 +931,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     for (int i0 = 0; i0 < p.N; i0 += kTopGroup) {
         const int i = i0 + tid;
         int n = 0, acc = 0, a2 = 0, b2 = 0, addr = 0, step_maj = 0, step_both = 0;
+        int acc0 = 0, addr0 = 0, kk = 0;
         bool checked = false;
         int i2 = ip, j2 = jp;
         if (i < p.N) {
@@ -946,32 +947,41 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
             const bool imaj = di >= dj;
             const int la = imaj ? di : dj, lb = imaj ? dj : di;
             n = la + 1;
-            a2 = 2 * la; b2 = 2 * lb; acc = la;
+            a2 = 2 * la; b2 = 2 * lb; acc0 = la;
             step_maj = imaj ? si : sj;
             step_both = si + sj;
-            addr = (jp - 1) * cb_ + (ip - 1);
+            addr0 = (jp - 1) * cb_ + (ip - 1);
             // a line whose end points are both on the image stays on it; anything else takes the clipped walk
             checked = !(start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt);
             if (checked) n = 0;
+            // Every lane walks its whole line, but starts somewhere along it and wraps round (pixel k of the line is
+            // known in closed form, see above): walked in step from the player, the 64 neighbouring rays of a
+            // wavefront sit on one small arc at every step — the same plane word or two for the first dozens of
+            // steps, and same-word LDS atomics serialise (a third of the draw kernel's wave-cycles waited for the
+            // LDS queue, SQ_WAIT_INST_LDS).  Neighbouring lanes start 37/64 of a line apart.
+            kk = n > 1 ? (int)(((unsigned)(tid * 37) & 63u) * (unsigned)n) >> 6 : 0;
+            const unsigned num = (unsigned)b2 * (unsigned)kk + (unsigned)la;
+            const unsigned m0 = la > 0 ? num / (unsigned)a2 : 0u;
+            acc = (int)(num - m0 * (unsigned)a2);
+            addr = addr0 + kk * step_maj + (int)m0 * (step_both - step_maj);
         }
-        // All lanes stay in the loop until the longest line of the wavefront is done (a lane past its own end
-        // offers -1 to its right neighbour), so the neighbour exchange always reads a live lane.  No branch in
-        // the body: a lane with nothing to draw ORs its bit into a private dummy word.
+        // All lanes stay in the loop until the longest line of the wavefront is done.  No branch in the body: a lane
+        // with nothing (more) to draw ORs its bit into a private dummy word.
         // (the trip count is the wavefront's longest line: a scalar loop)
         int nmax = n;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
         nmax = __builtin_amdgcn_readfirstlane(nmax);
         for (int k = 0; k < nmax; ++k) {
-            const int cur = k < n ? addr : -1;
-            const int left = __builtin_amdgcn_update_dpp(-1, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0: -1
-            const bool draw = k < n && left != cur;
-            uint32_t* const w = draw ? b.line + (cur >> 5) : dummy;
-            __hip_atomic_fetch_or(w, 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t* const w = k < n ? b.line + (addr >> 5) : dummy;
+            __hip_atomic_fetch_or(w, 1u << (addr & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             acc += b2;
             const bool t = acc >= a2;
             acc -= t ? a2 : 0;
             addr += t ? step_both : step_maj;
+            kk += 1;
+            const bool wrap = kk == n;                                       // back to the player's pixel
+            kk = wrap ? 0 : kk; acc = wrap ? acc0 : acc; addr = wrap ? addr0 : addr;
         }
         if (__ballot(checked)) {
             // clipped walk (SimpleDraw skips pixels off the image): the error-term loop as written
