@@ -356,7 +356,7 @@ RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, 
  *   RCW_TOP_VIEW_TWO_KERNELS  write-once, inside rcw_step / rcw_reset / rcw_set_state: draw kernel (bit planes -> HBM,
  *                             beside the camera fill), then the moving-window store kernel; rcw_update_top_view
  *                             alone takes the one-kernel form.  Geometries: pu_per_tu in 8..256 dividing 256,
- *                             H*pu % 256 == 0, (H + W)*pu <= 3 * height_camera_view_pu, player circle <= 32 rows */
+ *                             H*pu % 256 == 0, player circle <= 32 rows */
 enum { RCW_TOP_VIEW_NONE = 0, RCW_TOP_VIEW_IN_PLACE = 1, RCW_TOP_VIEW_ONE_KERNEL = 2, RCW_TOP_VIEW_TWO_KERNELS = 3 };
 RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
 

@@ -1567,10 +1567,6 @@ bool rcw_top_split_ok(const RcwDev& p)
     const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
     if (p.pu < 8 || 256 % p.pu != 0 || Ht % 256 != 0) return false;
     if (2 * p.top_rp > 31) return false;
-    // ... and where it pays: the draw kernel hides beside the camera fill only while its work (rays x line length,
-    // ~ (Ht + Wt) / 2 pixels a ray) is not much longer than the fill's (rays x H_cam pixels); measured
-    // (tools/top_view_shapes.py, profiles/): wins by 50 us at (Ht + Wt) / 2 <= 1.5 H_cam, loses 10-30 us at 2 H_cam
-    if (Ht + Wt > 3ll * p.Hc) return false;
     if ((long long)p.B * Wt * (Ht >> 8) + 64ll * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return false;   // chunk ids in 32 bits
     if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31)) return false;                                            // plane word offsets
     return 4 * top_buf_words(p) <= 156 * 1024;

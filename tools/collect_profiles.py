@@ -34,18 +34,37 @@ if os.path.exists(f"gpurun_out/{tag}_top_kernel_stats.csv"):
     csv.writer(open(f"profiles/{tag}_top_view_kernel_stats.csv", "w")).writerows([rows[0]] + [[r[0][:160]] + r[1:] for r in rows[1:]])
     tw = open(f"gpurun_out/{tag}_top_write.txt").read()
     sq = open(f"gpurun_out/{tag}_top_sq.txt").read()
-    top = [r for r in rows[1:] if "rcw_top_view_kernel" in r[0]][0]
-    avg_us = float(top[3]) / 1e3
-    TW = float(re.search(r"rcw_top_view_kernel\s+WRITE_SIZE.*?mean=\s*([\d.]+)", tw).group(1))
+    def stat(name, table=rows):
+        r = [r for r in table[1:] if name in r[0]]
+        return (float(r[0][3]) / 1e3, int(r[0][1]), float(r[0][5]) / 1e3, float(r[0][6]) / 1e3) if r else None
+    store, draw, fill = stat("rcw_top_store_kernel"), stat("rcw_top_draw_kernel"), stat("rcw_fill256_kernel")
+    TW = float(re.search(r"rcw_top_store_kernel\s+WRITE_SIZE.*?mean=\s*([\d.]+)", tw).group(1))
+    DW = float(re.search(r"rcw_top_draw_kernel\s+WRITE_SIZE.*?mean=\s*([\d.]+)", tw).group(1))
+    fr = open(f"gpurun_out/{tag}_top_fetch.txt").read() if os.path.exists(f"gpurun_out/{tag}_top_fetch.txt") else ""
+    ring = ""
+    if os.path.exists(f"gpurun_out/{tag}_top_ring_kernel_stats.csv"):
+        rr = stat("rcw_top_view_kernel", list(csv.reader(open(f"gpurun_out/{tag}_top_ring_kernel_stats.csv"))))
+        if rr:
+            ring = (f"\none-kernel form on the same workload (RCW_TOP_SPLIT=0: LDS bit planes, draw and store groups of one persistent kernel, what\n"
+                    f"rcw_update_top_view alone and the geometries outside the two-kernel form's take): rcw_top_view_kernel avg {rr[0]:.1f} us "
+                    f"= {1073741824 / rr[0] / 1e6 / 8 * 100:.1f} % of the HBM peak\n")
+    bench_top = json.loads(open(f"gpurun_out/{tag}_top_bench.json").read().strip().splitlines()[-1]) if os.path.exists(f"gpurun_out/{tag}_top_bench.json") else None
     open(f"profiles/{tag}_top_view_summary.txt", "w").write(
-        "rcw_top_view_kernel (update_top_view! SR:446-483, opt-in), cfg2 + pu_per_tu 32: 4096 agents x 256 x 256 px, 1 MI355X\n"
+        "update_top_view! (SR:446-483, opt-in), two-kernel form, cfg2 + pu_per_tu 32: 4096 agents x 256 x 256 px, 1 MI355X\n"
+        "  rcw_top_draw_kernel   rays -> Bresenham lines into an LDS bit plane -> plane (1/32 of the image) to HBM; side stream, beside the camera fill\n"
+        "  rcw_top_store_kernel  the fill kernel's moving window over the image: every pixel written once, 16 bytes a lane\n"
         "commands: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --top-view --steps 60 --warmup 5\n"
-        "          rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --top-view --steps 20 --warmup 2\n"
+        "          rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --top-view --steps 20 --warmup 2   (and FETCH_SIZE)\n"
         "          rocprofv3 --pmc SQ_... --kernel-trace -- (same)\n\n"
-        f"kernel stats: avg {avg_us:.1f} us over {top[1]} dispatches (min {float(top[5]) / 1e3:.1f}, max {float(top[6]) / 1e3:.1f})\n"
-        f"algorithmic bytes per launch: 4 * 256 * 256 * 4096 = 1,073,741,824 B -> {1073741824 / avg_us / 1e6:.2f} TB/s = "
-        f"{1073741824 / avg_us / 1e6 / 8 * 100:.1f} % of the 8 TB/s HBM peak\n"
-        f"WRITE_SIZE per launch: {TW:,.1f} KiB vs algorithmic 1,048,576 KiB (+{(TW / 1048576 - 1) * 100:.2f} %): every pixel is written once\n\n" + tw + "\n" + sq)
+        f"store kernel: avg {store[0]:.1f} us over {store[1]} dispatches (min {store[2]:.1f}, max {store[3]:.1f})\n"
+        f"  algorithmic bytes per launch: 4 * 256 * 256 * 4096 = 1,073,741,824 B -> {1073741824 / store[0] / 1e6:.2f} TB/s = "
+        f"{1073741824 / store[0] / 1e6 / 8 * 100:.1f} % of the 8 TB/s HBM peak\n"
+        f"  WRITE_SIZE per launch: {TW:,.1f} KiB vs algorithmic 1,048,576 KiB (+{(TW / 1048576 - 1) * 100:.2f} %): every pixel is written once\n"
+        f"draw kernel: avg {draw[0]:.1f} us (min {draw[2]:.1f}, max {draw[3]:.1f}), concurrent with rcw_fill256_kernel (avg {fill[0]:.1f} us in this run; "
+        f"alone, in the headline run: see {tag}_kernel_stats.csv); WRITE_SIZE {DW:,.1f} KiB (planes 32,768 KiB + codes)\n"
+        + (f"serial sum draw + store = {draw[0] + store[0]:.1f} us = {1073741824 / (draw[0] + store[0]) / 1e6 / 8 * 100:.1f} % if nothing ran beside the draw kernel\n")
+        + (f"bench line of the same workload: {bench_top['ms_per_step'] * 1e3:.1f} us per step = {bench_top['value'] / 1e6:.2f} M env-steps/s with both images rendered\n" if bench_top else "")
+        + ring + "\n" + tw + fr + "\n" + sq)
 # ---- cast kernel at cfg-5: exec-masked march (shipped) vs ballot-bounded march (RCW_CAST_MARCH=ballot)
 if os.path.exists(f"gpurun_out/{tag}_cfg5_exec_sq.txt"):
     out = ["rcw_cast_kernel at cfg-5 (SingleRoom 32x32, 1024 columns, 8192 agents: rays up to 60 tile steps), 1 MI355X\n"

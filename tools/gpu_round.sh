@@ -14,7 +14,8 @@ if [ "$2" != "notests" ]; then
   timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?; tail -2 gpurun_out/${tag}_pytest_gpu.log; stop_if_killed $rc pytest
 fi
 timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; rc=$?; cut -c1-160 gpurun_out/${tag}_bench.json; stop_if_killed $rc bench
-rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_top_stats gpurun_out/${tag}_top_pmc_write gpurun_out/${tag}_cfg5_*
+(cd $R && timeout -k 10 300 python bench.py --no-cpu-baseline --top-view --steps 100 --warmup 10 > gpurun_out/${tag}_top_bench.json 2> gpurun_out/${tag}_top_bench.err); rc=$?; stop_if_killed $rc top_bench
+rm -rf gpurun_out/${tag}_top_pmc_fetch gpurun_out/${tag}_top_ring_stats gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_top_stats gpurun_out/${tag}_top_pmc_write gpurun_out/${tag}_cfg5_*
 cd /tmp
 prof() {  # prof <outdir> <log> <rocprof args...> -- <bench args...>
   local out=$1 log=$2; shift 2
@@ -29,6 +30,8 @@ prof ${tag}_pmc_fetch ${tag}_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --
 # --- top view kernel (opt-in): kernel stats + bytes written
 prof ${tag}_top_stats ${tag}_top_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
 prof ${tag}_top_pmc_write ${tag}_top_pmc_write.log --pmc WRITE_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
+prof ${tag}_top_pmc_fetch ${tag}_top_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
+RCW_TOP_SPLIT=0 prof ${tag}_top_ring_stats ${tag}_top_ring_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
 prof ${tag}_top_pmc_sq ${tag}_top_pmc_sq.log --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -- --top-view --steps 20 --warmup 2
 # --- cast kernel at cfg-5 (32x32 map, 1024 columns: 60-step rays), exec-masked march vs ballot-bounded march
 for march in exec ballot; do
@@ -47,6 +50,8 @@ cd $R
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_write.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_fetch FETCH_SIZE | tee gpurun_out/${tag}_fetch.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_top_write.txt
+python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_fetch FETCH_SIZE rcw_top | tee gpurun_out/${tag}_top_fetch.txt
+cp gpurun_out/${tag}_top_ring_stats/*/*_kernel_stats.csv gpurun_out/${tag}_top_ring_kernel_stats.csv
 cp gpurun_out/${tag}_stats/*/*_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
 cp gpurun_out/${tag}_top_stats/*/*_kernel_stats.csv gpurun_out/${tag}_top_kernel_stats.csv
 for march in exec ballot; do cp gpurun_out/${tag}_cfg5_${march}_stats/*/*_kernel_stats.csv gpurun_out/${tag}_cfg5_${march}_kernel_stats.csv; done
