@@ -571,6 +571,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1;
     if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;             // (the size depends on top_lds)
     if (!cfg->render_top_view) d.top_lds = 0;
+    if ((long long)H * cfg->pu_per_tu > 16384 || (long long)W * cfg->pu_per_tu > 16384) d.top_lds = 0;   // the bit-plane kernels' line walk is exact for lines of up to 2^14 pixels
     if (const char* v = std::getenv("RCW_TOP_RING")) { const int k = std::atoi(v); if (k >= 1 && k <= 3 && d.top_lds > 0) { d.top_lds = k; if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1; } }
     {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
         const size_t lds = rcw_top_view_lds_bytes(d);

@@ -930,8 +930,10 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     uint32_t* const dummy = b.dummy + (tid & 63);
     for (int i0 = 0; i0 < p.N; i0 += kTopGroup) {
         const int i = i0 + tid;
-        int n = 0, acc = 0, a2 = 0, b2 = 0, addr = 0, step_maj = 0, step_both = 0;
-        int acc0 = 0, addr0 = 0, kk = 0;
+        // (bit addresses below are relative to the start of the `line` plane; the dummy words lie behind it and `circ`)
+        const int dummy_bit = (int)((dummy - b.line) * 32);
+        int n = 0, addr0 = dummy_bit, step_maj = 0, step_both = 0;
+        uint32_t slope = 0u;
         bool checked = false;
         int i2 = ip, j2 = jp;
         if (i < p.N) {
@@ -942,46 +944,56 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
             const T ox = dist * dx, oy = dist * dy;                          // ray_distance_wu * ray_direction_wu
             const T ex = pos.x + ox, ey = pos.y + oy;
             i2 = wu_to_pu<T>(ex, pu); j2 = wu_to_pu<T>(ey, pu);             // SR:476
-            const int di = abs(i2 - ip), dj = abs(j2 - jp);
-            const int si = ip < i2 ? 1 : -1, sj = jp < j2 ? cb_ : -cb_;    // steps of the plane's bit index
-            const bool imaj = di >= dj;
-            const int la = imaj ? di : dj, lb = imaj ? dj : di;
-            n = la + 1;
-            a2 = 2 * la; b2 = 2 * lb; acc0 = la;
-            step_maj = imaj ? si : sj;
-            step_both = si + sj;
-            addr0 = (jp - 1) * cb_ + (ip - 1);
             // a line whose end points are both on the image stays on it; anything else takes the clipped walk
             checked = !(start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt);
-            if (checked) n = 0;
-            // Every lane walks its whole line, but starts somewhere along it and wraps round (pixel k of the line is
-            // known in closed form, see above): walked in step from the player, the 64 neighbouring rays of a
-            // wavefront sit on one small arc at every step — the same plane word or two for the first dozens of
-            // steps, and same-word LDS atomics serialise (a third of the draw kernel's wave-cycles waited for the
-            // LDS queue, SQ_WAIT_INST_LDS).  Neighbouring lanes start 37/64 of a line apart.
-            kk = n > 1 ? (int)(((unsigned)(tid * 37) & 63u) * (unsigned)n) >> 6 : 0;
-            const unsigned num = (unsigned)b2 * (unsigned)kk + (unsigned)la;
-            const unsigned m0 = la > 0 ? num / (unsigned)a2 : 0u;
-            acc = (int)(num - m0 * (unsigned)a2);
-            addr = addr0 + kk * step_maj + (int)m0 * (step_both - step_maj);
+            if (!checked) {
+                const int di = abs(i2 - ip), dj = abs(j2 - jp);
+                const int si = ip < i2 ? 1 : -1, sj = jp < j2 ? cb_ : -cb_;    // steps of the plane's bit index
+                const bool imaj = di >= dj;
+                const int la = imaj ? di : dj, lb = imaj ? dj : di;
+                n = la + 1;
+                step_maj = imaj ? si : sj;
+                step_both = si + sj;
+                addr0 = (jp - 1) * cb_ + (ip - 1);
+                // floor(2^32 · b / a), exact in Float64 (b · 2^32 is exact, the quotient's fraction is a multiple of 1/a)
+                slope = lb >= la ? 0xFFFFFFFFu : (uint32_t)((double)lb * 4294967296.0 / (double)la);
+            }
         }
-        // All lanes stay in the loop until the longest line of the wavefront is done.  No branch in the body: a lane
-        // with nothing (more) to draw ORs its bit into a private dummy word.
-        // (the trip count is the wavefront's longest line: a scalar loop)
+        // Pixel k of the line sits k steps along the major axis and floor(k·b/a + 1/2) along the minor one (see above).
+        // The loop carries the FRACTION of k·slope/2^32 + 1/2 + 2^-18 in 32 bits and steps the minor axis on its
+        // carry: with slope/2^32 in (b/a - 2^-32, b/a] the carried value exceeds the true one by less than 2^-18 and
+        // by more than 0 for k < 2^14, and the true value's fraction is a multiple of 1/(2a) > 2^-18 — so no integer
+        // lies between them and the floors agree (lines on an image whose bit plane fits in LDS have a < 2^12; the
+        // closed form against the error-term walk: tests/test_host_logic.py; against the oracle: every top view test).
+        // Every lane walks its whole line but starts somewhere along it and wraps round: walked in step from the
+        // player, the 64 neighbouring rays of a wavefront sit on one small arc at every step — the same plane word or
+        // two for the first dozens of steps, and same-word LDS atomics serialise (a third of the draw kernel's
+        // wave-cycles waited for the LDS queue, SQ_WAIT_INST_LDS).  Neighbouring lanes start 37/64 of a line apart.
+        // A lane that is through before the wavefront's longest line simply goes round again (OR is idempotent); a
+        // lane without a line ORs into a private dummy word.  No divergent branch in the loop.
+        const uint32_t frac0 = 0x80000000u + (1u << 14);
+        const int k0 = n > 1 ? (int)((((unsigned)(tid * 37) & 63u) * (unsigned)n) >> 6) : 0;
+        const unsigned long long at_k0 = (unsigned long long)(unsigned)k0 * slope + frac0;     // v_mad_u64_u32
+        uint32_t frac = (uint32_t)at_k0;
+        int addr = addr0 + k0 * step_maj + (int)(at_k0 >> 32) * (step_both - step_maj);
+        int rem = n > 0 ? n - k0 : 0x7fffffff;                               // steps until the wrap
         int nmax = n;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        nmax = __builtin_amdgcn_readfirstlane(nmax);                         // (the trip count is the wavefront's longest line: a scalar loop)
+        char* const plane = reinterpret_cast<char*>(b.line);
         for (int k = 0; k < nmax; ++k) {
-            uint32_t* const w = k < n ? b.line + (addr >> 5) : dummy;
+            uint32_t* const w = reinterpret_cast<uint32_t*>(plane + (((unsigned)addr >> 3) & ~3u));
             __hip_atomic_fetch_or(w, 1u << (addr & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            acc += b2;
-            const bool t = acc >= a2;
-            acc -= t ? a2 : 0;
-            addr += t ? step_both : step_maj;
-            kk += 1;
-            const bool wrap = kk == n;                                       // back to the player's pixel
-            kk = wrap ? 0 : kk; acc = wrap ? acc0 : acc; addr = wrap ? addr0 : addr;
+            const uint32_t next = frac + slope;
+            addr += next < frac ? step_both : step_maj;                      // carry: a step along the minor axis too
+            frac = next;
+            rem -= 1;
+            if (__ballot(rem == 0) != 0ull) {                                // some lane is back at the player's pixel
+                asm volatile("" ::: "memory");                               // (keeps this a branch: if-converted, its selects run every step)
+                const bool wrap = rem == 0;
+                rem = wrap ? n : rem; frac = wrap ? frac0 : frac; addr = wrap ? addr0 : addr;
+            }
         }
         if (__ballot(checked)) {
             // clipped walk (SimpleDraw skips pixels off the image): the error-term loop as written

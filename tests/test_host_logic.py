@@ -141,6 +141,37 @@ def test_line_closed_form_equals_the_error_term_walk():
             assert error_term_walk(i2, j2) == remainder_walk(i2, j2), (i2, j2)
 
 
+def test_line_carry_walk_equals_the_closed_form():
+    """What top_draw actually carries: the 32-bit FRACTION of k * slope / 2^32 + 1/2 + 2^-18 with
+    slope = floor(2^32 b / a) (computed in Float64 as the kernel does), the minor axis stepping on the carry, started
+    at an arbitrary pixel k0 with one 64-bit multiply-add.  Against floor((2 b k + a) / (2 a)) for every (a, b) up to
+    96, for the extreme slopes, and for random lines up to the 16,384 pixels the kernels accept (rcw_api.hip)."""
+    frac0 = 0x80000000 + (1 << 14)
+
+    def check(a, b, ks):
+        slope = 0xFFFFFFFF if b >= a else int(np.floor(np.float64(b) * 4294967296.0 / np.float64(a)))
+        assert slope == (0xFFFFFFFF if b >= a else (b << 32) // a)          # the Float64 quotient's floor is exact
+        ks = np.asarray(ks, dtype=np.uint64)
+        at_k = ks * np.uint64(slope) + np.uint64(frac0)                      # v_mad_u64_u32 (k < 2^14: no overflow)
+        minor = (at_k >> np.uint64(32)).astype(np.int64)
+        want = (2 * b * ks.astype(np.int64) + a) // (2 * a) if a else np.zeros(len(ks), np.int64)
+        np.testing.assert_array_equal(minor, want, err_msg=f"a={a} b={b}")
+        # the loop: frac += slope, a carry steps the minor axis — same as the closed form one pixel on
+        frac = (at_k & np.uint64(0xFFFFFFFF)) + np.uint64(slope)
+        stepped = minor + (frac >> np.uint64(32)).astype(np.int64)
+        want1 = (2 * b * (ks.astype(np.int64) + 1) + a) // (2 * a) if a else np.zeros(len(ks), np.int64)
+        np.testing.assert_array_equal(stepped[ks < a], want1[ks < a], err_msg=f"step a={a} b={b}")
+
+    for a in range(1, 97):
+        for b in range(0, a + 1):
+            check(a, b, range(a + 1))
+    rng = np.random.default_rng(4)
+    for a in [16383, 16382, 8191, 4097, 4096, 1023, 1024, 513] + [int(v) for v in rng.integers(97, 16384, 300)]:
+        for b in {0, 1, 2, a // 3, a // 2, a // 2 + 1, a - 2, a - 1, a, int(rng.integers(0, a + 1)), int(rng.integers(0, a + 1))}:
+            if 0 <= b <= a:
+                check(a, b, range(a + 1))
+
+
 def test_frame_buffer_blit_is_the_reference_transpose(rcw):
     """frame_buffer_of == copy_image_to_frame_buffer! (utils.jl:64-73) into zeros(UInt32, width_image, height_image)
     (SR:508), checked element by element against the reference loop restated literally."""
