@@ -59,6 +59,7 @@ struct RcwDev {
     int32_t top_lds;         // write-once LDS bit-plane kernel: the number of buffers in its ring (1..3); 0: in-place fallback
     int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
     int32_t top_split;       // 1: the two-kernel top view (draw kernel -> planes in HBM -> moving-window store kernel)
+    int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU
     int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
     int32_t top_store_grid;  // ... and its workgroups (the moving window = top_store_grid KiB x 4)
     uint32_t* top_plane;     // [B][W*pu][H*pu/32] ray-line bit plane of every agent (two-kernel top view)

@@ -906,18 +906,18 @@ __device__ __forceinline__ uint32_t tile_fill_colour(uint32_t bits)
 }
 
 // draw group, first half of a slot: stage the agent's tile map, clear the planes
-__device__ __forceinline__ void top_prepare(const RcwDev& p, int a, const TopBuf& b, int tid)
+__device__ __forceinline__ void top_prepare(const RcwDev& p, int a, const TopBuf& b, int tid, int group = kTopGroup)
 {
-    stage_tile_bytes(b.tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, kTopGroup);
+    stage_tile_bytes(b.tb, p.tile_map + (size_t)a * p.nwords, p.H * p.W, tid, group);
     u32x4* z = reinterpret_cast<u32x4*>(b.line);
     const int nz = (int)((top_line_words(p) + top_circ_words(p)) >> 2);
     const u32x4 zero = {0u, 0u, 0u, 0u};
-    for (int k = tid; k < nz; k += kTopGroup) z[k] = zero;
+    for (int k = tid; k < nz; k += group) z[k] = zero;
 }
 
 // draw group, second half: one line per ray from the player to the ray's stop point (SR:473-477) and the player
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b, int tid, bool with_circle = true)
+__device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b, int tid, bool with_circle = true, int group = kTopGroup)
 {
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     const typename Real<T>::vec2 pos = Real<T>::pos(p)[a];
@@ -928,8 +928,15 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     const bool start_inside = ip >= 1 && ip <= Ht && jp >= 1 && jp <= Wt;
     const int cb_ = top_col_bits(p);
     uint32_t* const dummy = b.dummy + (tid & 63);
-    for (int i0 = 0; i0 < p.N; i0 += kTopGroup) {
-        const int i = i0 + tid;
+    // Lanes per ray: with fewer rays than lanes (N <= group / 2) a line is cut into `parts` segments, one lane each
+    // (lanes of one ray are group / parts apart, so a wavefront holds neighbouring rays' same segment).
+    const int npad = (p.N + 63) & ~63;
+    int parts = 1;
+    while (parts * 2 * npad <= group) parts *= 2;
+    const int rays_per_pass = group / parts;                                 // a multiple of 64
+    const int part = tid / rays_per_pass, ray_in_pass = tid - part * rays_per_pass;
+    for (int i0 = 0; i0 < p.N; i0 += rays_per_pass) {
+        const int i = i0 + ray_in_pass;
         // (bit addresses below are relative to the start of the `line` plane; the dummy words lie behind it and `circ`)
         const int dummy_bit = (int)((dummy - b.line) * 32);
         int n = 0, addr0 = dummy_bit, step_maj = 0, step_both = 0;
@@ -946,7 +953,9 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
             i2 = wu_to_pu<T>(ex, pu); j2 = wu_to_pu<T>(ey, pu);             // SR:476
             // a line whose end points are both on the image stays on it; anything else takes the clipped walk
             checked = !(start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt);
-            if (!checked) {
+            if (checked) {
+                checked = part == 0;                                         // (one lane of the ray takes the clipped walk)
+            } else {
                 const int di = abs(i2 - ip), dj = abs(j2 - jp);
                 const int si = ip < i2 ? 1 : -1, sj = jp < j2 ? cb_ : -cb_;    // steps of the plane's bit index
                 const bool imaj = di >= dj;
@@ -972,15 +981,21 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
         // A lane that is through before the wavefront's longest line simply goes round again (OR is idempotent); a
         // lane without a line ORs into a private dummy word.  No divergent branch in the loop.
         const uint32_t frac0 = 0x80000000u + (1u << 14);
-        const int k0 = n > 1 ? (int)((((unsigned)(tid * 37) & 63u) * (unsigned)n) >> 6) : 0;
-        const unsigned long long at_k0 = (unsigned long long)(unsigned)k0 * slope + frac0;     // v_mad_u64_u32
+        const int ks = (int)(((long long)part * n) / parts), ke = (int)(((long long)(part + 1) * n) / parts);   // this lane's pixels of the line
+        const int len = ke - ks;
+        if (len == 0) { addr0 = dummy_bit; step_maj = step_both = 0; slope = 0u; }
+        const int k0 = len > 1 ? ks + (int)((((unsigned)(tid * 37) & 63u) * (unsigned)len) >> 6) : ks;
+        const unsigned long long at_ks = (unsigned long long)(unsigned)ks * slope + frac0;     // v_mad_u64_u32
+        const unsigned long long at_k0 = (unsigned long long)(unsigned)k0 * slope + frac0;
+        const uint32_t frac_s = (uint32_t)at_ks;
+        const int addr_s = addr0 + ks * step_maj + (int)(at_ks >> 32) * (step_both - step_maj);
         uint32_t frac = (uint32_t)at_k0;
         int addr = addr0 + k0 * step_maj + (int)(at_k0 >> 32) * (step_both - step_maj);
-        int rem = n > 0 ? n - k0 : 0x7fffffff;                               // steps until the wrap
-        int nmax = n;
+        int rem = len > 0 ? ke - k0 : 0x7fffffff;                            // steps until the wrap
+        int nmax = len;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-        nmax = __builtin_amdgcn_readfirstlane(nmax);                         // (the trip count is the wavefront's longest line: a scalar loop)
+        nmax = __builtin_amdgcn_readfirstlane(nmax);                         // (the trip count is the wavefront's longest segment: a scalar loop)
         char* const plane = reinterpret_cast<char*>(b.line);
         for (int k = 0; k < nmax; ++k) {
             uint32_t* const w = reinterpret_cast<uint32_t*>(plane + (((unsigned)addr >> 3) & ~3u));
@@ -989,10 +1004,10 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
             addr += next < frac ? step_both : step_maj;                      // carry: a step along the minor axis too
             frac = next;
             rem -= 1;
-            if (__ballot(rem == 0) != 0ull) {                                // some lane is back at the player's pixel
+            if (__ballot(rem == 0) != 0ull) {                                // some lane is back at the start of its segment
                 asm volatile("" ::: "memory");                               // (keeps this a branch: if-converted, its selects run every step)
                 const bool wrap = rem == 0;
-                rem = wrap ? n : rem; frac = wrap ? frac0 : frac; addr = wrap ? addr0 : addr;
+                rem = wrap ? len : rem; frac = wrap ? frac_s : frac; addr = wrap ? addr_s : addr;
             }
         }
         if (__ballot(checked)) {
@@ -1017,7 +1032,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
     }
     // the player: SD.Circle(Point(ip - rp, jp - rp), 2 rp + 1)  SR:480 (midpoint circle, assumed).  Its plane is
     // separate from the lines', so one lane of the LAST wavefront draws it while the others finish their lines.
-    if (with_circle && tid == kTopGroup - 1) {
+    if (with_circle && tid == group - 1) {
         const int jc0 = jp - rp;                                             // first image column of the circle plane (1-based)
         int x = 0, y = rp, dd = 1 - rp;
         auto put = [&](int i, int j) {
@@ -1253,28 +1268,28 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
 // out unpadded, with the player's pixel (SR:468) and, per (tile column, row block), the 2-bit fill codes of the
 // chunk's tiles packed into 64 bits.
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(kTopGroup) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int a = blockIdx.x, tid = threadIdx.x;
+    const int a = blockIdx.x, tid = threadIdx.x, group = blockDim.x;         // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
     if (mask != nullptr && mask[a] == 0) return;                             // workgroup-uniform
     const TopBuf b = top_buf(p, lds);
-    top_prepare(p, a, b, tid);
+    top_prepare(p, a, b, tid, group);
     __syncthreads();
-    top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid, false);
+    top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid, false, group);
     __syncthreads();
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu;
     const int wpc = top_col_bits(p) >> 5, wpu = Ht >> 5, k = Ht >> 8, tpc = 256 / pu;
     uint32_t* const out = p.top_plane + (size_t)a * Wt * wpu;
-    const int total = Wt * wpu, qstep = kTopGroup / wpu, rstep = kTopGroup - qstep * wpu;
+    const int total = Wt * wpu, qstep = group / wpu, rstep = group - qstep * wpu;
     int j = tid / wpu, w = tid - j * wpu;
-    for (int idx = tid; idx < total; idx += kTopGroup) {
+    for (int idx = tid; idx < total; idx += group) {
         out[idx] = b.line[j * wpc + w];
         j += qstep; w += rstep;
         if (w >= wpu) { w -= wpu; j += 1; }
     }
     if (tid == 0) p.top_hdr[a] = make_int2(b.hdr[0], b.hdr[1]);
-    for (int e = tid; e < p.W * k; e += kTopGroup) {
+    for (int e = tid; e < p.W * k; e += group) {
         const int tj = e / k, rb = e - tj * k;
         const uint8_t* const tiles = b.tb + rb * tpc + p.H * tj;
         uint32_t lo = 0u, hi = 0u;
@@ -1588,7 +1603,7 @@ size_t rcw_top_codes_bytes(const RcwDev& p) { return (size_t)p.B * p.W * ((size_
 
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
-    RCW_DISPATCH(rcw_top_draw_kernel, dim3(p.B), dim3(kTopGroup), 4 * top_buf_words(p), p, mask_dev);
+    RCW_DISPATCH(rcw_top_draw_kernel, dim3(p.B), dim3(p.top_draw_block), 4 * top_buf_words(p), p, mask_dev);
     return hipGetLastError();
 }
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
