@@ -973,7 +973,7 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
         // carry: with slope/2^32 in (b/a - 2^-32, b/a] the carried value exceeds the true one by less than 2^-18 and
         // by more than 0 for k < 2^14, and the true value's fraction is a multiple of 1/(2a) > 2^-18 — so no integer
         // lies between them and the floors agree (lines on an image whose bit plane fits in LDS have a < 2^12; the
-        // closed form against the error-term walk: tests/test_host_logic.py; against the oracle: every top view test).
+        // closed form against the error-term walk and the carry against the closed form: tests/test_host_logic.py).
         // Every lane walks its whole line but starts somewhere along it and wraps round: walked in step from the
         // player, the 64 neighbouring rays of a wavefront sit on one small arc at every step — the same plane word or
         // two for the first dozens of steps, and same-word LDS atomics serialise (a third of the draw kernel's
