@@ -635,6 +635,34 @@ def test_top_view_form_of_other_geometries(rcw):
     env.close()
 
 
+def test_captured_step_with_top_view_replays(rcw, oracle):
+    """A step is capturable into a HIP graph (torch.cuda.CUDAGraph on the stream the engine shares), including the
+    two-kernel top view's fork to the handle's side stream and the join back: eight replays with the same device
+    actions equal eight oracle steps, both images."""
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 48, seed=31, render_top_view=1, pu_per_tu=32, out_of_bounds=1, **CFG2)
+    assert env.top_view_form() == "two-kernels"
+    stream = torch.cuda.Stream()
+    env.set_stream(stream.cuda_stream)
+    a_host = np.random.default_rng(2).integers(1, 5, env.batch).astype(np.uint8)
+    with torch.cuda.stream(stream):
+        actions = torch.from_numpy(a_host).cuda()
+        for _ in range(2):                                                   # (warm-up outside the capture)
+            rcw.act_(env, actions); orc.step(a_host)
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            rcw.act_(env, actions)
+        orc.step(a_host)                                                     # (torch runs nothing during capture; the engine's launches were captured, not run)
+        g.replay(); stream.synchronize()
+        for _ in range(7):
+            g.replay(); orc.step(a_host)
+        stream.synchronize()
+    assert_state_equal(env, orc, where="after 8 graph replays")
+    np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+    env.close()
+
+
 def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
     """The ballot-bounded march (the form north_star words; development switch RCW_CAST_MARCH=ballot, measured against
     the shipped exec-masked march in profiles/) is the same function: bit-exact at the deep-march config and under
