@@ -69,6 +69,40 @@ def test_full_size_parity(rcw, oracle, cfg, batch, steps):
     env.close()
 
 
+@pytest.mark.parametrize("cfg,batch,form", [(CFG2, 4096, "two-kernels"), (dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=512), 2048, "two-kernels"),
+                                            (CFG4, 1024, "two-kernels")],
+                         ids=["cfg2_4096", "reference_default_2048", "cfg4_1024"])
+def test_full_size_top_view(rcw, oracle, cfg, batch, form):
+    """The opt-in top view at full batch sizes (1 GiB of pixels a step: the two-kernel form's store kernel sweeps its
+    window 16 times).  State of every agent against the non-rendering oracle; both images of a sample of agents (the
+    first and last, around the middle, random ones) against a small rendering oracle given the same states; and over
+    ALL images a size-independent property: no pixel outside the six colours update_top_view! can write (SR:288-290,
+    SR:364-367) — a chunk the store kernel skipped or wrote twice with stale descriptors would show."""
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=77, out_of_bounds=1, render_top_view=True, pu_per_tu=32, **cfg)
+    assert env.top_view_form() == form
+    orc = oracle.OracleBatch(batch, seed=77, render=False, out_of_bounds=1, **cfg)
+    rng = np.random.default_rng(3)
+    for s in range(5):
+        a = rng.integers(1, 5, batch).astype(np.uint8)
+        rcw.act_(env, a)
+        assert orc.step(a) == 0
+    w = env.world
+    np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
+    np.testing.assert_array_equal(w.player_direction_au, orc.direction)
+    sample = np.unique(np.concatenate([[0, 1, 3, 4, batch // 2 - 1, batch // 2, batch - 2, batch - 1], rng.choice(batch, 16, replace=False)]))
+    small = oracle.OracleBatch(len(sample), seed=0, render_top_view=1, pu_per_tu=32, **cfg)
+    small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
+    got = np.stack([env.top_view_host(int(i), 1)[0] for i in sample])
+    np.testing.assert_array_equal(got, small.top_view)
+    cam = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
+    np.testing.assert_array_equal(cam, small.camera_view)
+    tv = env.top_view.torch().view(torch.int32)
+    palette = torch.tensor([0x000000, 0xFFFFFF, 0xFF0000, 0xCCCCCC, 0x808080, 0xC0C0C0], dtype=torch.int32, device=tv.device)
+    for a0 in range(0, batch, 256):
+        assert bool(torch.isin(tv[a0:a0 + 256], palette).all()), f"a pixel outside the palette in agents {a0}.."
+    env.close()
+
+
 def test_sharding_invariance_on_device(rcw):
     kw = dict(seed=9, out_of_bounds=1, **CFG2)
     whole = rcw.SingleRoomModule.SingleRoom(batch=512, **kw)
