@@ -602,8 +602,10 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // the two-kernel top view where the geometry allows it (RCW_TOP_SPLIT=0: keep the one-kernel ring form)
     d.top_store_grid = d.fill_grid;
     if (const char* v = std::getenv("RCW_TOP_STORE_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_store_grid = g; }
-    d.top_split = cfg->render_top_view && d.top_lds > 0 && rcw_top_split_ok(d) ? 1 : 0;
+    d.top_unit_px = cfg->render_top_view && d.top_lds > 0 ? rcw_top_split_unit(d) : 0;
+    d.top_split = d.top_unit_px ? 1 : 0;
     if (const char* v = std::getenv("RCW_TOP_SPLIT")) { if (!std::atoi(v)) d.top_split = 0; }
+    if (!d.top_split) d.top_unit_px = 256;
     // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on
     // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top
     // view in a step with 256 / 512 / 1024 threads: 512² px, 256 rays 180 / 182 / 200; 768² px 212 / 200 / 203; 1024² px, 1024 rays 357 / 265 / 216)

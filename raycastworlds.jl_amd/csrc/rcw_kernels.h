@@ -58,6 +58,7 @@ struct RcwDev {
     int32_t top_rp;          // player_radius_pu = wu_to_pu(player_radius_wu, pu)  SR:469 (host-computed in T)
     int32_t top_lds;         // write-once LDS bit-plane kernel: the number of buffers in its ring (1..3); 0: in-place fallback
     int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
+    int32_t top_unit_px;     // ... its store kernel's unit: 256 rows of an image column (a whole 1 KiB chunk), 128 or 64
     int32_t top_split;       // 1: the two-kernel top view (draw kernel -> planes in HBM -> moving-window store kernel)
     int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU
     int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
@@ -92,7 +93,7 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
 // kernel's dynamic LDS limit when the bit planes need more than 64 KiB); sets nothing on the device.
 size_t rcw_top_view_lds_bytes(const RcwDev& p);
 // the two-kernel top view: eligibility of a geometry, its HBM scratch sizes, and the two launches
-bool rcw_top_split_ok(const RcwDev& p);
+int rcw_top_split_unit(const RcwDev& p);   // rows of a store-kernel unit (256 / 128 / 64), 0: geometry not taken
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);

@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
     top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid, false, group);
     __syncthreads();
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu;
-    const int wpc = top_col_bits(p) >> 5, wpu = Ht >> 5, k = Ht >> 8, tpc = 256 / pu;
+    const int wpc = top_col_bits(p) >> 5, wpu = Ht >> 5, k = Ht / p.top_unit_px, tpc = p.top_unit_px / pu;   // (unit: 256 rows, or 128 / 64: rcw_top_store_units_kernel)
     uint32_t* const out = p.top_plane + (size_t)a * Wt * wpu;
     const int total = Wt * wpu, qstep = group / wpu, rstep = group - qstep * wpu;
     int j = tid / wpu, w = tid - j * wpu;
@@ -1305,8 +1305,8 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
 // offset / 256: image column (a, j), row block rb).  Per 64 chunks of a wavefront, lane l computes the descriptor
 // of the l-th (tile codes, frame column, the player's circle as a 32-bit row mask for that column), and the 8 plane
 // words of each chunk are fetched by 8 lanes (8 loads per lane for the 64 chunks); per chunk the descriptor is
-// broadcast with v_readlane, the plane word reaches its lane with ds_bpermute, and lane l writes rows 4l..4l+3 with
-// one 16-byte store: colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480).
+// broadcast with v_readlane, the plane words go through a wave-private 2 KiB of LDS, and lane l writes rows 4l..4l+3
+// with one 16-byte store: colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480).
 // The circle: SD.Circle's pixels in the image column at distance c from the player's are the same rows relative to
 // the player for every agent (midpoint circle, assumed): lane c computes that row mask once per kernel.
 // what depends on the lane only
@@ -1447,8 +1447,8 @@ __device__ __forceinline__ void top_group_finish(const RcwDev& p, const TopLane&
 // offset / 256: image column (a, j), row block rb).  Per 64 chunks of a wavefront, lane l computes the descriptor
 // of the l-th (tile codes, frame column, the player's circle as a 32-bit row mask for that column), and the 8 plane
 // words of each chunk are fetched by 8 lanes (8 loads per lane for the 64 chunks); per chunk the descriptor is
-// broadcast with v_readlane, the plane word reaches its lane with ds_bpermute, and lane l writes rows 4l..4l+3 with
-// one 16-byte store: colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480).
+// broadcast with v_readlane, the plane words go through a wave-private 2 KiB of LDS, and lane l writes rows 4l..4l+3
+// with one 16-byte store: colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480).
 // The circle: SD.Circle's pixels in the image column at distance c from the player's are the same rows relative to
 // the player for every agent (midpoint circle, assumed): lane c computes that row mask once per kernel.
 // (Issuing the next group's loads before this group's 64 stores, so that waiting for them would not wait for the
@@ -1491,6 +1491,115 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
                                                        __builtin_amdgcn_readlane(cur.r0, t));
                 store16<PLAIN>(dst + lane, o);
             }
+        }
+    }
+}
+
+// The same sweep for image heights that are a multiple of 128 or 64 but not of 256 (and tiles that divide 128 or 64):
+// a 1 KiB chunk then holds U = 2 or 4 UNITS — runs of 128 or 64 rows of one image column — which may belong to different
+// columns (even different agents), so the descriptor is per unit: lane l of the prefetch computes the U descriptors of
+// its chunk, and in the chunk loop a lane takes its unit's (lane / (64 / U)) out of the U broadcast ones.  The plane
+// needs nothing new: unpadded, its bit index IS the flat pixel index, so a chunk's plane words are 8 consecutive ones.
+// A unit's descriptor word: bits 0..27 the 2-bit fill codes of its (at most 14) tiles, bit 28 frame column, bit 31 valid.
+template <bool PLAIN, int U>
+__global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+{
+    constexpr int LPU = 64 / U, UPX = 256 / U;                               // lanes, pixels of a unit
+    const int lane = threadIdx.x & 63;
+    const uint32_t G = gridDim.x * (kBlock / 64);
+    const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
+    const uint32_t k = (uint32_t)Ht / UPX;                                   // units of an image column
+    const uint32_t total_units = (uint32_t)p.B * (uint32_t)Wt * k;
+    const uint32_t total = (total_units + U - 1) / U;                        // chunks (the last one may be short)
+    const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
+    u32x4* const out = reinterpret_cast<u32x4*>(p.top_view);
+    const TopLane L = top_lane(p, lane);                                     // (only its circle table and plane-bit shift apply here)
+    const int u_lane = lane / LPU, r_lane = (lane - u_lane * LPU) * 4;       // this lane's unit of the chunk, its first row in it
+    const int tl = r_lane / pu, ri = r_lane - tl * pu;
+    const bool first_row = ri == 0, last_row = ri + 3 == pu - 1;             // SR:364-365
+    const uint32_t code_sh = 2u * (uint32_t)tl;
+    const size_t dstep = (size_t)G * 64;
+    __shared__ uint32_t plane_words[(kBlock / 64) * 512];
+    uint32_t* const lw_write = plane_words + (threadIdx.x >> 6) * 512 + lane;
+    const uint32_t* const lw_read = plane_words + (threadIdx.x >> 6) * 512 + (lane >> 3);
+    for (uint32_t base = g; base < total; base += G * 64) {
+        const uint32_t id = base + (uint32_t)lane * G;
+        uint32_t packed[U], cmask[U];
+        int r0[U];
+        int nvalid = 0;
+        bool any_circle = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t un = id * U + u;
+            bool valid = id < total && un < total_units;
+            const uint32_t col = un / k, rb = un - col * k;
+            const uint32_t a = col / (uint32_t)Wt, j = col - a * (uint32_t)Wt;
+            const uint32_t tj = j / (uint32_t)pu, rj = j - tj * (uint32_t)pu;
+            if (valid && mask != nullptr && mask[a] == 0) valid = false;
+            packed[u] = 0u; r0[u] = 0;
+            int dist = 64;
+            if (valid) {
+                const uint2 cd = p.top_codes[((size_t)a * p.W + tj) * k + rb];
+                const int2 hd = p.top_hdr[a];
+                packed[u] = (cd.x & 0x0FFFFFFFu) | ((rj == 0 || rj == (uint32_t)pu - 1) ? 1u << 28 : 0u) | (1u << 31);
+                dist = abs((int)j + 1 - hd.y);
+                r0[u] = hd.x - 1 - rp - UPX * (int)rb;                       // unit row of the circle mask's bit 0
+                nvalid += 1;
+            }
+            uint32_t c = (uint32_t)__shfl((int)L.cm, dist & 63, 64);
+            if (dist > rp || r0[u] >= UPX || r0[u] + 2 * rp < 0) c = 0u;
+            cmask[u] = c;
+            any_circle = any_circle || c != 0u;
+        }
+        const int state_l = (nvalid > 0 ? 1 : 0) | (nvalid == U ? 2 : 0) | (any_circle ? 4 : 0);
+        const int woff_l = nvalid > 0 ? (int)(id * 8u) : -1;                 // plane word = flat pixel / 32
+        uint32_t pw[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int wo = __shfl(woff_l, 8 * m + (lane >> 3), 64);
+            pw[m] = wo >= 0 ? p.top_plane[(size_t)wo + (lane & 7)] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("v_mov_b32 %0, %1" : "=v"(packed[u]) : "v"(packed[u]));   // (the loads are waited for here, see top_group_finish)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) lw_write[64 * m] = pw[m];
+        __builtin_amdgcn_wave_barrier();
+        u32x4* dst = out + (size_t)base * 64;
+#pragma unroll 2
+        for (int t = 0; t < 64; ++t, dst += dstep) {
+            const int s_state = __builtin_amdgcn_readlane(state_l, t);
+            if (!(s_state & 1)) continue;                                    // wave-uniform: past the end / masked out
+            const uint32_t w = lw_read[8 * t];
+            uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed[0], t);
+#pragma unroll
+            for (int u = 1; u < U; ++u) { const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)packed[u], t); pk = u_lane == u ? q : pk; }
+            const uint32_t fill = (bit_to_mask(pk, code_sh) & 0x00FFFFFFu) | (bit_to_mask(pk, code_sh + 1) & 0x00FF0000u);
+            const uint32_t frame = bit_to_mask(pk, 28);                      // SR:366-367: the tile's frame columns
+            u32x4 o;
+            o.x = bfi(frame, grid_c, first_row ? grid_c : fill);
+            o.y = bfi(frame, grid_c, fill);
+            o.z = o.y;
+            o.w = bfi(frame, grid_c, last_row ? grid_c : fill);
+            o.x = bfi(bit_to_mask(w, L.sh), ray_c, o.x);     o.y = bfi(bit_to_mask(w, L.sh + 1), ray_c, o.y);
+            o.z = bfi(bit_to_mask(w, L.sh + 2), ray_c, o.z); o.w = bfi(bit_to_mask(w, L.sh + 3), ray_c, o.w);
+            if (s_state & 4) {                                               // some unit of the chunk crosses the player's circle
+                uint32_t cmv = (uint32_t)__builtin_amdgcn_readlane((int)cmask[0], t);
+                int r0v = __builtin_amdgcn_readlane(r0[0], t);
+#pragma unroll
+                for (int u = 1; u < U; ++u) {
+                    const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)cmask[u], t);
+                    const int qr = __builtin_amdgcn_readlane(r0[u], t);
+                    cmv = u_lane == u ? qc : cmv; r0v = u_lane == u ? qr : r0v;
+                }
+                const int q0 = r_lane - r0v;
+                const uint32_t cb = q0 >= 0 ? (q0 < 32 ? cmv >> q0 : 0u) : (q0 > -4 ? cmv << -q0 : 0u);
+                o.x = bfi(bit_to_mask(cb, 0), player_c, o.x); o.y = bfi(bit_to_mask(cb, 1), player_c, o.y);
+                o.z = bfi(bit_to_mask(cb, 2), player_c, o.z); o.w = bfi(bit_to_mask(cb, 3), player_c, o.w);
+            }
+            if (s_state & 2) store16<PLAIN>(dst + lane, o);                  // every unit of the chunk is written
+            else if (pk >> 31) store16<PLAIN>(dst + lane, o);                // a chunk at the end / at a masked agent's border
         }
     }
 }
@@ -1589,17 +1698,23 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
 }
 
 // The two-kernel top view (see rcw_top_draw_kernel): whether this geometry takes it
-bool rcw_top_split_ok(const RcwDev& p)
+// ... as the number of rows of a unit (256: rcw_top_store_kernel; 128 or 64: rcw_top_store_units_kernel), 0: not taken.
+// A unit is a run of rows of ONE image column that holds whole tiles, a lane's four pixels a whole quarter of one.
+int rcw_top_split_unit(const RcwDev& p)
 {
     const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
-    if (p.pu < 8 || 256 % p.pu != 0 || Ht % 256 != 0) return false;
-    if (2 * p.top_rp > 31) return false;
-    if ((long long)p.B * Wt * (Ht >> 8) + 64ll * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return false;   // chunk ids in 32 bits
-    if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31)) return false;                                            // plane word offsets
-    return 4 * top_buf_words(p) <= 156 * 1024;
+    if (p.pu < 8 || 2 * p.top_rp > 31) return 0;
+    int unit = 0;
+    if (256 % p.pu == 0 && Ht % 256 == 0) unit = 256;
+    else if (128 % p.pu == 0 && Ht % 128 == 0 && 128 / p.pu <= 14) unit = 128;
+    else if (64 % p.pu == 0 && Ht % 64 == 0) unit = 64;
+    if (!unit) return 0;
+    if ((long long)p.B * Wt * (Ht / unit) + 4ll * 64 * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;   // unit / chunk ids in 32 bits
+    if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31) - 64) return 0;                                               // plane word offsets
+    return 4 * top_buf_words(p) <= 156 * 1024 ? unit : 0;
 }
-size_t rcw_top_plane_bytes(const RcwDev& p) { return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4; }
-size_t rcw_top_codes_bytes(const RcwDev& p) { return (size_t)p.B * p.W * ((size_t)p.H * p.pu / 256) * sizeof(uint2); }
+size_t rcw_top_plane_bytes(const RcwDev& p) { return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4 + 64; }   // (+ a short last chunk's reach)
+size_t rcw_top_codes_bytes(const RcwDev& p) { return (size_t)p.B * p.W * ((size_t)p.H * p.pu / p.top_unit_px) * sizeof(uint2); }
 
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
@@ -1609,7 +1724,13 @@ hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStre
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
     const dim3 grid(p.top_store_grid), block(kBlock);
-    if (p.pu < 16) {                                                         // 32 tiles in a chunk
+    if (p.top_unit_px == 128) {
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 2>), grid, block, 0, s, p, mask_dev);
+        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 2>), grid, block, 0, s, p, mask_dev);
+    } else if (p.top_unit_px == 64) {
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 4>), grid, block, 0, s, p, mask_dev);
+        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 4>), grid, block, 0, s, p, mask_dev);
+    } else if (p.pu < 16) {                                                  // 32 tiles in a chunk
         if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, true>), grid, block, 0, s, p, mask_dev);
         else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, true>), grid, block, 0, s, p, mask_dev);
     } else {

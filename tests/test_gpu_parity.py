@@ -599,7 +599,13 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
     for kw, batch in ((dict(pu_per_tu=32, **CFG2), 300), (dict(pu_per_tu=16, height_tile_map_tu=16, width_tile_map_tu=9, num_rays=100), 21),
                       (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
                       (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=20, num_rays=33, player_radius_wu=0.3,
-                            position_increment_wu=0.2), 9)):
+                            position_increment_wu=0.2), 9),
+                      # heights of 128 m and 64 m rows: two / four units (runs of rows of one column) to a 1 KiB chunk
+                      (dict(pu_per_tu=32, height_tile_map_tu=12, width_tile_map_tu=7, num_rays=128), 37),     # 384 rows
+                      (dict(pu_per_tu=16, **CFG2), 130),                                                     # 128 rows
+                      (dict(pu_per_tu=32, height_tile_map_tu=10, width_tile_map_tu=9, num_rays=200), 11),     # 320 rows
+                      (dict(pu_per_tu=8, height_tile_map_tu=8, width_tile_map_tu=5, num_rays=64, player_radius_wu=0.3,
+                            position_increment_wu=0.2), 260)):                                               # 64 rows
         env, orc = _make(rcw, oracle, batch, seed=23, render_top_view=1, **kw)
         assert env.top_view_form() == form, kw
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
