@@ -1707,7 +1707,7 @@ int rcw_top_split_unit(const RcwDev& p)
     int unit = 0;
     if (256 % p.pu == 0 && Ht % 256 == 0) unit = 256;
     else if (128 % p.pu == 0 && Ht % 128 == 0 && 128 / p.pu <= 14) unit = 128;
-    else if (64 % p.pu == 0 && Ht % 64 == 0) unit = 64;
+    else if (64 % p.pu == 0 && Ht % 64 == 0) unit = 64;      // (units of 32 rows, eight to a chunk: 244 µs at 288² px against the one-kernel form's 236)
     if (!unit) return 0;
     if ((long long)p.B * Wt * (Ht / unit) + 4ll * 64 * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;   // unit / chunk ids in 32 bits
     if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31) - 64) return 0;                                               // plane word offsets
