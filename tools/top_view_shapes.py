@@ -8,8 +8,11 @@ import torch
 
 import raycastworlds_jl_amd as RCW
 
-for H, W, pu, N in ((8, 8, 32, 256), (8, 16, 32, 512), (16, 16, 32, 256), (8, 8, 16, 256), (12, 12, 32, 256), (8, 8, 13, 256),
-                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64), (32, 32, 8, 256), (24, 24, 32, 256), (9, 9, 32, 256), (9, 12, 32, 256)):
+SHAPES = ((8, 8, 32, 256), (8, 16, 32, 512), (16, 16, 32, 256), (8, 8, 16, 256), (12, 12, 32, 256), (8, 8, 13, 256),
+                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64), (32, 32, 8, 256), (24, 24, 32, 256), (9, 9, 32, 256), (9, 12, 32, 256))
+if len(sys.argv) > 1:                                    # one shape: H,W,pu,N
+    SHAPES = (tuple(int(v) for v in sys.argv[1].split(",")),)
+for H, W, pu, N in SHAPES:
     px = H * pu * W * pu
     B = max(64, min(8192, (1 << 30) // (4 * px)))
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
