@@ -1495,16 +1495,20 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
     }
 }
 
-// The same sweep for image heights that are a multiple of 128 or 64 but not of 256 (and tiles that divide 128 or 64):
-// a 1 KiB chunk then holds U = 2 or 4 UNITS — runs of 128 or 64 rows of one image column — which may belong to different
-// columns (even different agents), so the descriptor is per unit: lane l of the prefetch computes the U descriptors of
-// its chunk, and in the chunk loop a lane takes its unit's (lane / (64 / U)) out of the U broadcast ones.  The plane
-// needs nothing new: unpadded, its bit index IS the flat pixel index, so a chunk's plane words are 8 consecutive ones.
+// The same sweep for image heights that are a multiple of 128, 64 or 32 rows but not of 256 (and tiles that divide that
+// number): a 1 KiB chunk then holds U = 2, 4 or 8 UNITS — runs of 128 / 64 / 32 rows of one image column — which may
+// belong to different columns, so the descriptor is per unit: lane l of the prefetch computes the U descriptors of its
+// chunk and parks them, like the plane words, in wave-private LDS; in the chunk loop a lane reads its unit's
+// (lane / (64 / U)) back with one ds_read (broadcast with v_readlane and picked with selects instead: the same at
+// U = 2 and 4, 244 instead of 212 µs at U = 8).  The plane needs nothing new: unpadded, its bit index IS the flat pixel
+// index, so a chunk's plane words are 8 consecutive ones whatever the columns.
 // A unit's descriptor word: bits 0..27 the 2-bit fill codes of its (at most 14) tiles, bit 28 frame column, bit 31 valid.
+// (Issuing all U units' loads before the first use, one wait instead of U, changes nothing measurable.)
 template <bool PLAIN, int U>
 __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
 {
     constexpr int LPU = 64 / U, UPX = 256 / U;                               // lanes, pixels of a unit
+    constexpr int kWaveWords = 512 + 3 * 64 * U;                             // plane words | descriptors | circle masks | circle rows
     const int lane = threadIdx.x & 63;
     const uint32_t G = gridDim.x * (kBlock / 64);
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1520,9 +1524,13 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
     const bool first_row = ri == 0, last_row = ri + 3 == pu - 1;             // SR:364-365
     const uint32_t code_sh = 2u * (uint32_t)tl;
     const size_t dstep = (size_t)G * 64;
-    __shared__ uint32_t plane_words[(kBlock / 64) * 512];
-    uint32_t* const lw_write = plane_words + (threadIdx.x >> 6) * 512 + lane;
-    const uint32_t* const lw_read = plane_words + (threadIdx.x >> 6) * 512 + (lane >> 3);
+    __shared__ uint32_t wave_words[(kBlock / 64) * kWaveWords];
+    uint32_t* const ws = wave_words + (threadIdx.x >> 6) * kWaveWords;
+    uint32_t* const lw_write = ws + lane;
+    const uint32_t* const lw_read = ws + (lane >> 3);
+    uint32_t* const desc = ws + 512;                                         // [64 chunks][U]
+    uint32_t* const circ = desc + 64 * U;
+    uint32_t* const crow = circ + 64 * U;
     for (uint32_t base = g; base < total; base += G * 64) {
         const uint32_t id = base + (uint32_t)lane * G;
         uint32_t packed[U], cmask[U];
@@ -1560,11 +1568,12 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
             const int wo = __shfl(woff_l, 8 * m + (lane >> 3), 64);
             pw[m] = wo >= 0 ? p.top_plane[(size_t)wo + (lane & 7)] : 0u;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("v_mov_b32 %0, %1" : "=v"(packed[u]) : "v"(packed[u]));   // (the loads are waited for here, see top_group_finish)
+        // (the loads are waited for here, by the LDS writes that use them — once per 64 chunks, see top_group_finish)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int m = 0; m < 8; ++m) lw_write[64 * m] = pw[m];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { desc[lane * U + u] = packed[u]; circ[lane * U + u] = cmask[u]; crow[lane * U + u] = (uint32_t)r0[u]; }
         __builtin_amdgcn_wave_barrier();
         u32x4* dst = out + (size_t)base * 64;
 #pragma unroll 2
@@ -1572,9 +1581,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
             const int s_state = __builtin_amdgcn_readlane(state_l, t);
             if (!(s_state & 1)) continue;                                    // wave-uniform: past the end / masked out
             const uint32_t w = lw_read[8 * t];
-            uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed[0], t);
-#pragma unroll
-            for (int u = 1; u < U; ++u) { const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)packed[u], t); pk = u_lane == u ? q : pk; }
+            const uint32_t pk = desc[t * U + u_lane];
             const uint32_t fill = (bit_to_mask(pk, code_sh) & 0x00FFFFFFu) | (bit_to_mask(pk, code_sh + 1) & 0x00FF0000u);
             const uint32_t frame = bit_to_mask(pk, 28);                      // SR:366-367: the tile's frame columns
             u32x4 o;
@@ -1585,15 +1592,8 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
             o.x = bfi(bit_to_mask(w, L.sh), ray_c, o.x);     o.y = bfi(bit_to_mask(w, L.sh + 1), ray_c, o.y);
             o.z = bfi(bit_to_mask(w, L.sh + 2), ray_c, o.z); o.w = bfi(bit_to_mask(w, L.sh + 3), ray_c, o.w);
             if (s_state & 4) {                                               // some unit of the chunk crosses the player's circle
-                uint32_t cmv = (uint32_t)__builtin_amdgcn_readlane((int)cmask[0], t);
-                int r0v = __builtin_amdgcn_readlane(r0[0], t);
-#pragma unroll
-                for (int u = 1; u < U; ++u) {
-                    const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)cmask[u], t);
-                    const int qr = __builtin_amdgcn_readlane(r0[u], t);
-                    cmv = u_lane == u ? qc : cmv; r0v = u_lane == u ? qr : r0v;
-                }
-                const int q0 = r_lane - r0v;
+                const uint32_t cmv = circ[t * U + u_lane];
+                const int q0 = r_lane - (int)crow[t * U + u_lane];
                 const uint32_t cb = q0 >= 0 ? (q0 < 32 ? cmv >> q0 : 0u) : (q0 > -4 ? cmv << -q0 : 0u);
                 o.x = bfi(bit_to_mask(cb, 0), player_c, o.x); o.y = bfi(bit_to_mask(cb, 1), player_c, o.y);
                 o.z = bfi(bit_to_mask(cb, 2), player_c, o.z); o.w = bfi(bit_to_mask(cb, 3), player_c, o.w);
@@ -1698,7 +1698,7 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
 }
 
 // The two-kernel top view (see rcw_top_draw_kernel): whether this geometry takes it
-// ... as the number of rows of a unit (256: rcw_top_store_kernel; 128 or 64: rcw_top_store_units_kernel), 0: not taken.
+// ... as the number of rows of a unit (256: rcw_top_store_kernel; 128, 64 or 32: rcw_top_store_units_kernel), 0: not taken.
 // A unit is a run of rows of ONE image column that holds whole tiles, a lane's four pixels a whole quarter of one.
 int rcw_top_split_unit(const RcwDev& p)
 {
@@ -1707,9 +1707,10 @@ int rcw_top_split_unit(const RcwDev& p)
     int unit = 0;
     if (256 % p.pu == 0 && Ht % 256 == 0) unit = 256;
     else if (128 % p.pu == 0 && Ht % 128 == 0 && 128 / p.pu <= 14) unit = 128;
-    else if (64 % p.pu == 0 && Ht % 64 == 0) unit = 64;      // (units of 32 rows, eight to a chunk: 244 µs at 288² px against the one-kernel form's 236)
+    else if (64 % p.pu == 0 && Ht % 64 == 0) unit = 64;
+    else if (32 % p.pu == 0 && Ht % 32 == 0) unit = 32;
     if (!unit) return 0;
-    if ((long long)p.B * Wt * (Ht / unit) + 4ll * 64 * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;   // unit / chunk ids in 32 bits
+    if ((long long)p.B * Wt * (Ht / unit) + 8ll * 64 * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;   // unit / chunk ids in 32 bits
     if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31) - 64) return 0;                                               // plane word offsets
     return 4 * top_buf_words(p) <= 156 * 1024 ? unit : 0;
 }
@@ -1730,6 +1731,9 @@ hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStr
     } else if (p.top_unit_px == 64) {
         if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 4>), grid, block, 0, s, p, mask_dev);
         else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 4>), grid, block, 0, s, p, mask_dev);
+    } else if (p.top_unit_px == 32) {
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 8>), grid, block, 0, s, p, mask_dev);
+        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 8>), grid, block, 0, s, p, mask_dev);
     } else if (p.pu < 16) {                                                  // 32 tiles in a chunk
         if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, true>), grid, block, 0, s, p, mask_dev);
         else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, true>), grid, block, 0, s, p, mask_dev);

@@ -600,12 +600,14 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
                       (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
                       (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=20, num_rays=33, player_radius_wu=0.3,
                             position_increment_wu=0.2), 9),
-                      # heights of 128 m and 64 m rows: two / four units (runs of rows of one column) to a 1 KiB chunk
+                      # heights of 128 m, 64 m and 32 m rows: two / four / eight units (runs of rows of one column) to a 1 KiB chunk
                       (dict(pu_per_tu=32, height_tile_map_tu=12, width_tile_map_tu=7, num_rays=128), 37),     # 384 rows
                       (dict(pu_per_tu=16, **CFG2), 130),                                                     # 128 rows
                       (dict(pu_per_tu=32, height_tile_map_tu=10, width_tile_map_tu=9, num_rays=200), 11),     # 320 rows
                       (dict(pu_per_tu=8, height_tile_map_tu=8, width_tile_map_tu=5, num_rays=64, player_radius_wu=0.3,
-                            position_increment_wu=0.2), 260)):                                               # 64 rows
+                            position_increment_wu=0.2), 260),                                                # 64 rows
+                      (dict(pu_per_tu=32, height_tile_map_tu=9, width_tile_map_tu=11, num_rays=150), 23),     # 288 rows: eight units of 32
+                      (dict(pu_per_tu=16, height_tile_map_tu=10, width_tile_map_tu=6, num_rays=90), 50)):     # 160 rows
         env, orc = _make(rcw, oracle, batch, seed=23, render_top_view=1, **kw)
         assert env.top_view_form() == form, kw
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
@@ -629,7 +631,7 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
 def test_top_view_form_of_other_geometries(rcw):
     """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form."""
     for kw, form in ((dict(pu_per_tu=10, **CFG2), "one-kernel"),                      # 10 does not divide 256
-                     (dict(pu_per_tu=32, height_tile_map_tu=9, width_tile_map_tu=8), "one-kernel"),   # 288 rows
+                     (dict(pu_per_tu=12, height_tile_map_tu=16, width_tile_map_tu=8), "one-kernel"),   # 192 rows of 12-pixel tiles
                      (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), "one-kernel"),   # circle of 33 rows
                      (dict(pu_per_tu=32, **CFG4), "two-kernels"),
                      (dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), "in-place")):

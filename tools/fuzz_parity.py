@@ -42,11 +42,11 @@ for c in range(n_cfg):
     R = str(rng.choice(["Float32", "Float64", "Int32", "Int64"]))
     B = int(rng.integers(1, 40))
     if split_geometry:
-        # image heights of 64 m rows with tiles that divide the store kernel's unit (256, 128 or 64 rows)
+        # image heights of 32 m rows with tiles that divide the store kernel's unit (256, 128, 64 or 32 rows)
         pu = int(rng.choice([8, 16, 32, 32, 64, 128]))
         kw["pu_per_tu"] = pu
-        m = int(rng.integers(1, 13))
-        H = max(4, (64 * m) // pu) if pu <= 64 else int(rng.integers(4, 7)) // 2 * 2
+        m = int(rng.integers(2, 25))
+        H = max(4, (32 * m) // pu) if pu <= 64 else int(rng.integers(4, 7)) // 2 * 2
         kw["height_tile_map_tu"] = H
         kw["width_tile_map_tu"] = int(rng.integers(4, 10 if pu >= 64 else 20))
         B = int(rng.integers(1, 12 if pu >= 64 else 40))
