@@ -91,5 +91,26 @@ int main(int argc, char** argv)
     }
     free(frames);
     CHECK(rcw_destroy(h));
+    /* the opt-in top view (update_top_view! SR:446-483) through the ABI alone: a second handle, the same action stream */
+    {
+        cfg.render_top_view = 1; cfg.pu_per_tu = 32;
+        rcw_handle* ht = NULL;
+        CHECK(rcw_create(&cfg, B, 0, 2024, &ht));
+        int32_t form = -1;
+        CHECK(rcw_top_view_form(ht, &form));
+        seed = 99;
+        for (int s = 0; s < STEPS; ++s) {
+            for (int a = 0; a < B; ++a) actions[a] = (uint8_t)(1 + lcg(&seed) % 4);
+            CHECK(rcw_step(ht, actions));
+        }
+        const size_t tpix = (size_t)B * 256 * 256;
+        uint32_t* top = (uint32_t*)malloc(tpix * sizeof(uint32_t));
+        CHECK(rcw_top_view_copy(ht, top, 0, B));
+        uint64_t tsum = 0;                                 /* position-weighted sum mod 2^64 (vectorisable on the checking side) */
+        for (size_t k = 0; k < tpix; ++k) tsum += (uint64_t)top[k] * (2 * (uint64_t)k + 1);
+        printf("top_view_form=%d top_checksum=%016llx\n", (int)form, (unsigned long long)tsum);
+        free(top);
+        CHECK(rcw_destroy(ht));
+    }
     return 0;
 }

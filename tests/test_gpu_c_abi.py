@@ -48,3 +48,16 @@ def test_plain_c_caller(oracle, tmp_path):
     assert int(m.group(5)) == orc.direction[0]
     # rcw_comm_init / rcw_gather_observations (both modes) with a world of one rank, RCCL called by the library
     assert "gather=ok" in res.stdout, res.stdout
+    # the top view through the ABI alone: the two-kernel form (RCW_TOP_VIEW_TWO_KERNELS = 3), same pixels as the oracle's
+    mt = re.search(r"top_view_form=(\d+) top_checksum=([0-9a-f]{16})", res.stdout)
+    assert mt, res.stdout
+    assert int(mt.group(1)) == 3
+    ort = oracle.OracleBatch(64, seed=2024, out_of_bounds=1, render_top_view=1, pu_per_tu=32,
+                             height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    for t in range(steps):
+        assert ort.step(acts[t]) == 0
+    top = ort.top_view.reshape(-1).astype(np.uint64)
+    weights = np.arange(top.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        ht_ = int((top * weights).sum(dtype=np.uint64))                      # position-weighted sum mod 2^64, as in the harness
+    assert mt.group(2) == f"{ht_:016x}"
