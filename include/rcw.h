@@ -356,7 +356,8 @@ RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, 
  *   RCW_TOP_VIEW_TWO_KERNELS  write-once, inside rcw_step / rcw_reset / rcw_set_state: draw kernel (bit planes -> HBM,
  *                             beside the camera fill), then the moving-window store kernel; rcw_update_top_view
  *                             alone takes the one-kernel form.  Geometries: H*pu a multiple of 256, 128, 64 or 32 rows,
- *                             pu_per_tu >= 8 dividing that number, player circle <= 32 rows */
+ *                             pu_per_tu >= 8 dividing that number, player circle <= 32 rows; batches of at
+ *                             least 256 MiB of top view a step (smaller ones: the one-kernel form is faster) */
 enum { RCW_TOP_VIEW_NONE = 0, RCW_TOP_VIEW_IN_PLACE = 1, RCW_TOP_VIEW_ONE_KERNEL = 2, RCW_TOP_VIEW_TWO_KERNELS = 3 };
 RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
 

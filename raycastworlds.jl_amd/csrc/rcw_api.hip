@@ -604,7 +604,11 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = std::getenv("RCW_TOP_STORE_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_store_grid = g; }
     d.top_unit_px = cfg->render_top_view && d.top_lds > 0 ? rcw_top_split_unit(d) : 0;
     d.top_split = d.top_unit_px ? 1 : 0;
-    if (const char* v = std::getenv("RCW_TOP_SPLIT")) { if (!std::atoi(v)) d.top_split = 0; }
+    // ... where the batch is big enough to pay for its two extra launches and the side-stream fork / join (≈ 13 µs a step:
+    // with 8×8 tiles of 32 px, 1 / 256 / 1024 / 4096 agents take 51 / 62 / 102 / 340 µs a step against 37 / 49 / 104 / 387 in
+    // the one-kernel form): from 256 MiB of top view a step.  RCW_TOP_SPLIT=0: never, =2: wherever the geometry allows.
+    if (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) d.top_split = 0;
+    if (const char* v = std::getenv("RCW_TOP_SPLIT")) { const int f = std::atoi(v); if (!f) d.top_split = 0; else if (f == 2 && d.top_unit_px) d.top_split = 1; }
     if (!d.top_split) d.top_unit_px = 256;
     // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on
     // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top

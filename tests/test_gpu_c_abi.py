@@ -28,7 +28,8 @@ def test_plain_c_caller(oracle, tmp_path):
     subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_harness.c"),
                     "-o", exe, "-L", lib, "-lrcw_hip", f"-Wl,-rpath,{lib}"], check=True)
     steps = 120
-    res = subprocess.run([exe, str(steps)], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, str(steps)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, RCW_TOP_SPLIT="2"))             # (64 agents: the two-kernel top view only when asked for)
     assert res.returncode == 0, res.stderr
     m = re.search(r"terminal_events=(\d+) checksum=([0-9a-f]{16}) pos0=([-\d.e+]+),([-\d.e+]+) dir0=(\d+)", res.stdout)
     assert m, res.stdout

@@ -585,12 +585,13 @@ def test_top_view_in_place_fallback(rcw, oracle):
         env.close()
 
 
-@pytest.mark.parametrize("env_switch, form", [(None, "two-kernels"), (("RCW_TOP_SPLIT", "0"), "one-kernel"),
+@pytest.mark.parametrize("env_switch, form", [(("RCW_TOP_SPLIT", "2"), "two-kernels"), (("RCW_TOP_SPLIT", "0"), "one-kernel"),
                                               (("RCW_TOP_INPLACE", "1"), "in-place")])
 def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_switch, form):
     """The three kernel forms of update_top_view! (rcw.h: rcw_top_view_form) against the oracle on the same states:
     the two-kernel form (draw kernel beside the camera fill, moving-window store kernel) is what an eligible geometry
-    takes; the development switches force the other two.  300 agents x 256 columns of 256 px = 76,800 chunks: more
+    takes from 256 MiB of top view a step (RCW_TOP_SPLIT=2 takes it at these small batches too; at full size:
+    test_gpu_full_size.py); the development switches force the other two.  300 agents x 256 columns of 256 px = 76,800 chunks: more
     than one sweep of the store kernel's window (65,536), so its last group is a partial one; the masked reset
     exercises its skipped chunks; 16 px tiles put two tile rows into one lane group."""
     if env_switch:
@@ -628,8 +629,16 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
         env.close()
 
 
-def test_top_view_form_of_other_geometries(rcw):
-    """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form."""
+def test_top_view_form_of_other_geometries(rcw, monkeypatch):
+    """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form — and so
+    does a batch too small to pay for two more launches and a stream fork / join (below 256 MiB of top view a step)."""
+    env = rcw.SingleRoomModule.SingleRoom(batch=512, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)     # 128 MiB
+    assert env.top_view_form() == "one-kernel"
+    env.close()
+    env = rcw.SingleRoomModule.SingleRoom(batch=1024, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)    # 256 MiB
+    assert env.top_view_form() == "two-kernels"
+    env.close()
+    monkeypatch.setenv("RCW_TOP_SPLIT", "2")                                 # (geometry alone, whatever the batch)
     for kw, form in ((dict(pu_per_tu=10, **CFG2), "one-kernel"),                      # 10 does not divide 256
                      (dict(pu_per_tu=12, height_tile_map_tu=16, width_tile_map_tu=8), "one-kernel"),   # 192 rows of 12-pixel tiles
                      (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), "one-kernel"),   # circle of 33 rows
@@ -643,11 +652,12 @@ def test_top_view_form_of_other_geometries(rcw):
     env.close()
 
 
-def test_captured_step_with_top_view_replays(rcw, oracle):
+def test_captured_step_with_top_view_replays(rcw, oracle, monkeypatch):
     """A step is capturable into a HIP graph (torch.cuda.CUDAGraph on the stream the engine shares), including the
     two-kernel top view's fork to the handle's side stream and the join back: eight replays with the same device
     actions equal eight oracle steps, both images."""
     torch = pytest.importorskip("torch")
+    monkeypatch.setenv("RCW_TOP_SPLIT", "2")                                 # (48 agents would take the one-kernel form)
     env, orc = _make(rcw, oracle, 48, seed=31, render_top_view=1, pu_per_tu=32, out_of_bounds=1, **CFG2)
     assert env.top_view_form() == "two-kernels"
     stream = torch.cuda.Stream()

@@ -20,7 +20,9 @@ from oracle import oracle as O
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split")
-split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the two-kernel top view: pu | 256, H*pu % 256 == 0
+split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the two-kernel top view (units of 256 / 128 / 64 / 32 rows)
+if split_geometry:
+    os.environ["RCW_TOP_SPLIT"] = "2"          # ... and that form at these small batches too (by default only from 256 MiB of top view a step)
 fails = 0
 O.set_num_threads(8)
 for c in range(n_cfg):

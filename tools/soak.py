@@ -17,7 +17,9 @@ from helpers import assert_state_equal
 from oracle import oracle as O
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-top = len(sys.argv) > 2 and sys.argv[2] == "top"          # also render the top view every step (two-kernel form: side stream fork / join)
+top = len(sys.argv) > 2 and sys.argv[2] == "top"
+if top:
+    os.environ["RCW_TOP_SPLIT"] = "2"                      # (256 agents would take the one-kernel form)          # also render the top view every step (two-kernel form: side stream fork / join)
 B = 256
 kw = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
 env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=99, auto_reset=True, out_of_bounds=1, render_top_view=top, **kw)
