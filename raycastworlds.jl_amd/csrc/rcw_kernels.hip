@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
 // the player for every agent (midpoint circle, assumed): lane c computes that row mask once per kernel.
 // what depends on the lane only
 struct TopLane {
-    int r_lane, sh, code_sh, bp0;
+    int r_lane, sh, code_sh;
     bool code_hi, first_row, last_row;
     uint32_t cm;                 // lane c: the circle's rows at column distance c
 };
@@ -1325,7 +1325,6 @@ __device__ __forceinline__ TopLane top_lane(const RcwDev& p, int lane)
     L.sh = L.r_lane & 31;
     L.code_sh = 2 * (tl & 15);
     L.code_hi = tl >= 16;
-    L.bp0 = (lane >> 3) * 4;                                                 // ds_bpermute address of lane (lane >> 3)
     L.cm = 0u;
     int x = 0, y = rp, dd = 1 - rp;
     while (x <= y) {
