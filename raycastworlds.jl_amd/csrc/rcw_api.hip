@@ -56,7 +56,8 @@ struct rcw_handle {
     // two-kernel top view: planes / player pixels / tile codes in HBM, the side stream the draw kernel runs on
     void* d_top_plane = nullptr; void* d_top_hdr = nullptr; void* d_top_codes = nullptr;
     hipStream_t top_stream = nullptr;
-    hipEvent_t ev_top_fork = nullptr, ev_top_join = nullptr;
+    hipEvent_t ev_top_fork = nullptr;
+    hipEvent_t ev_top_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per run of agents
     void* d_actions = nullptr; void* d_mask = nullptr;
     void* d_in_goal = nullptr; void* d_in_pos = nullptr; void* d_in_dir = nullptr;
     int32_t* h_err = nullptr;   // pinned
@@ -100,11 +101,23 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
     }
     if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
-    if ((e = rcw_launch_top_draw(d, mask_dev, h->top_stream)) != hipSuccess) return e;
-    if ((e = hipEventRecord(h->ev_top_join, h->top_stream)) != hipSuccess) return e;
+    // The batch goes in d.top_runs runs of agents (one, unless the batch is several GiB of top view AND the drawing is
+    // long against the camera fill): the side stream draws run after run without waiting for anything, the handle's
+    // stream stores run r as soon as it is drawn — so what of the drawing does not fit beside the camera fill runs beside
+    // the (HBM-bound) storing of earlier runs.
+    const int runs = d.top_runs > 1 ? d.top_runs : 1;
+    for (int r = 0; r < runs; ++r) {
+        const int first = (int)((long long)d.B * r / runs), count = (int)((long long)d.B * (r + 1) / runs) - first;
+        if ((e = rcw_launch_top_draw(d, mask_dev, first, count, h->top_stream)) != hipSuccess) return e;
+        if ((e = hipEventRecord(h->ev_top_join[r], h->top_stream)) != hipSuccess) return e;
+    }
     if ((e = between()) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(h->stream, h->ev_top_join, 0)) != hipSuccess) return e;
-    return rcw_launch_top_store(d, mask_dev, h->stream);
+    for (int r = 0; r < runs; ++r) {
+        const int first = (int)((long long)d.B * r / runs), count = (int)((long long)d.B * (r + 1) / runs) - first;
+        if ((e = hipStreamWaitEvent(h->stream, h->ev_top_join[r], 0)) != hipSuccess) return e;
+        if ((e = rcw_launch_top_store(d, mask_dev, first, count, h->stream)) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // One step = cast kernel + fill kernel, back to back on the handle's stream (+ the top view when the handle renders
@@ -160,9 +173,9 @@ void free_all(rcw_handle* h)
     for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
     for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (h->ev_top_fork) (void)hipEventDestroy(h->ev_top_fork);
-    if (h->ev_top_join) (void)hipEventDestroy(h->ev_top_join);
+    for (hipEvent_t& q : h->ev_top_join) { if (q) (void)hipEventDestroy(q); q = nullptr; }
     if (h->top_stream) (void)hipStreamDestroy(h->top_stream);
-    h->ev_top_fork = h->ev_top_join = nullptr; h->top_stream = nullptr;
+    h->ev_top_fork = nullptr; h->top_stream = nullptr;
     if (h->d_gather_h) (void)hipFree(h->d_gather_h);
     if (h->d_gather_c) (void)hipFree(h->d_gather_c);
     h->d_gather_h = h->d_gather_c = nullptr;
@@ -616,6 +629,17 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.top_draw_block = 256;
     if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > 64 * 1024) { const int b = ((N + 255) / 256) * 256; d.top_draw_block = b < 512 ? 512 : (b > 1024 ? 1024 : b); }
     if (const char* v = std::getenv("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = b; }
+    // runs of agents: where the lines are long against the camera image's columns ((Ht + Wt) / 2 >= 1.75 H_cam) the drawing
+    // does not fit beside the camera fill; with several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside
+    // the storing of earlier runs.  Measured (µs a step with 1 / 2 / 4 / 8 runs): 16×16 map, 512 rays, 16,384 agents (16 GiB of
+    // top view) 4516 / 4409 / 4332 / 4294; 32×32 map, 1024 rays, 8192 agents (32 GiB) 8586 / 8459 / 7658 / 8068.  Runs of
+    // 256 MiB do NOT pay (four short store launches and their joins: 205 vs 181 µs at 1 GiB of 512² px images).
+    d.top_runs = 1;
+    if (2ll * ((long long)H + W) * cfg->pu_per_tu >= 7ll * Hc) {
+        const size_t gib = (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)) >> 30;
+        d.top_runs = gib >= 4 ? 4 : (gib >= 2 ? 2 : 1);
+    }
+    if (const char* v = std::getenv("RCW_TOP_RUNS")) { const int r = std::atoi(v); if (r >= 1 && r <= 8 && r <= batch) d.top_runs = r; }
     d.top_store_plain = 0;
     if (const char* v = std::getenv("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
     if (d.top_split) {
@@ -624,7 +648,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
         if (e == hipSuccess) e = hipMalloc(&h->d_top_codes, rcw_top_codes_bytes(d));
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_join, hipEventDisableTiming);
+        for (hipEvent_t& q : h->ev_top_join) if (e == hipSuccess) e = hipEventCreateWithFlags(&q, hipEventDisableTiming);
         if (e != hipSuccess) { free_all(h); delete h; return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "top view planes: %s", hipGetErrorString(e)); }
         d.top_plane = (uint32_t*)h->d_top_plane; d.top_hdr = (int2*)h->d_top_hdr; d.top_codes = (uint2*)h->d_top_codes;
     }

@@ -60,6 +60,7 @@ struct RcwDev {
     int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
     int32_t top_unit_px;     // ... its store kernel's unit: 256 rows of an image column (a whole 1 KiB chunk), 128 or 64
     int32_t top_split;       // 1: the two-kernel top view (draw kernel -> planes in HBM -> moving-window store kernel)
+    int32_t top_runs;        // the batch is drawn and stored in this many runs of agents (store of run r beside the drawing of run r + 1)
     int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU
     int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
     int32_t top_store_grid;  // ... and its workgroups (the moving window = top_store_grid KiB x 4)
@@ -96,8 +97,8 @@ size_t rcw_top_view_lds_bytes(const RcwDev& p);
 int rcw_top_split_unit(const RcwDev& p);   // rows of a store-kernel unit (256 / 128 / 64), 0: geometry not taken
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
-hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
-hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
+hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);    // agents [first, first + count)
+hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
 hipError_t rcw_prepare_top_view(const RcwDev& p);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos /* float2* or double2* */,

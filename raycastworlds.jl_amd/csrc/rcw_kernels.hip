@@ -1268,10 +1268,10 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
 // out unpadded, with the player's pixel (SR:468) and, per (tile column, row block), the 2-bit fill codes of the
 // chunk's tiles packed into 64 bits.
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask, int first)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int a = blockIdx.x, tid = threadIdx.x, group = blockDim.x;         // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
+    const int a = first + (int)blockIdx.x, tid = threadIdx.x, group = blockDim.x;         // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
     if (mask != nullptr && mask[a] == 0) return;                             // workgroup-uniform
     const TopBuf b = top_buf(p, lds);
     top_prepare(p, a, b, tid, group);
@@ -1453,19 +1453,20 @@ __device__ __forceinline__ void top_group_finish(const RcwDev& p, const TopLane&
 // (Issuing the next group's loads before this group's 64 stores, so that waiting for them would not wait for the
 // stores, measured SLOWER: 201 vs 178 µs at 4096 x 256² px — the drain once per 64 chunks costs less than it looks.)
 template <bool PLAIN, bool WIDE>
-__global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, const uint8_t* __restrict__ mask,
+                                                               uint32_t chunk_begin, uint32_t chunk_end)   // the chunks of a run of agents
 {
     const int lane = threadIdx.x & 63;
     const uint32_t G = gridDim.x * (kBlock / 64);
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the store's address is SGPR base + lane offset)
-    const uint32_t total = (uint32_t)p.B * (uint32_t)(p.W * p.pu) * ((uint32_t)(p.H * p.pu) >> 8);
+    const uint32_t total = chunk_end;
     u32x4* const out = reinterpret_cast<u32x4*>(p.top_view);
     const TopLane L = top_lane(p, lane);
     const size_t dstep = (size_t)G * 64;
     __shared__ uint32_t plane_words[(kBlock / 64) * 512];
     uint32_t* const lw_write = plane_words + (threadIdx.x >> 6) * 512 + lane;
     const uint32_t* const lw_read = plane_words + (threadIdx.x >> 6) * 512 + (lane >> 3);
-    uint32_t base = g;
+    uint32_t base = chunk_begin + g;
     for (; base < total; base += G * 64) {
         TopGroup cur;
         top_group_issue(p, mask, base, G, total, lane, cur);
@@ -1504,7 +1505,8 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
 // A unit's descriptor word: bits 0..27 the 2-bit fill codes of its (at most 14) tiles, bit 28 frame column, bit 31 valid.
 // (Issuing all U units' loads before the first use, one wait instead of U, changes nothing measurable.)
 template <bool PLAIN, int U>
-__global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDev p, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDev p, const uint8_t* __restrict__ mask,
+                                                                     uint32_t chunk_begin, uint32_t chunk_end)
 {
     constexpr int LPU = 64 / U, UPX = 256 / U;                               // lanes, pixels of a unit
     constexpr int kWaveWords = 512 + 3 * 64 * U;                             // plane words | descriptors | circle masks | circle rows
@@ -1514,7 +1516,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     const uint32_t k = (uint32_t)Ht / UPX;                                   // units of an image column
     const uint32_t total_units = (uint32_t)p.B * (uint32_t)Wt * k;
-    const uint32_t total = (total_units + U - 1) / U;                        // chunks (the last one may be short)
+    const uint32_t total = chunk_end;                                        // (the batch's last chunk may be short: total_units)
     const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
     u32x4* const out = reinterpret_cast<u32x4*>(p.top_view);
     const TopLane L = top_lane(p, lane);                                     // (only its circle table and plane-bit shift apply here)
@@ -1530,7 +1532,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
     uint32_t* const desc = ws + 512;                                         // [64 chunks][U]
     uint32_t* const circ = desc + 64 * U;
     uint32_t* const crow = circ + 64 * U;
-    for (uint32_t base = g; base < total; base += G * 64) {
+    for (uint32_t base = chunk_begin + g; base < total; base += G * 64) {
         const uint32_t id = base + (uint32_t)lane * G;
         uint32_t packed[U], cmask[U];
         int r0[U];
@@ -1716,29 +1718,33 @@ int rcw_top_split_unit(const RcwDev& p)
 size_t rcw_top_plane_bytes(const RcwDev& p) { return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4 + 64; }   // (+ a short last chunk's reach)
 size_t rcw_top_codes_bytes(const RcwDev& p) { return (size_t)p.B * p.W * ((size_t)p.H * p.pu / p.top_unit_px) * sizeof(uint2); }
 
-hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
+// agents [first, first + count): the draw kernel's workgroups / the store kernel's chunks of that run (an image is a
+// whole number of 1 KiB chunks in every geometry rcw_top_split_unit takes)
+hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
 {
-    RCW_DISPATCH(rcw_top_draw_kernel, dim3(p.B), dim3(p.top_draw_block), 4 * top_buf_words(p), p, mask_dev);
+    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(p.top_draw_block), 4 * top_buf_words(p), p, mask_dev, first);
     return hipGetLastError();
 }
-hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
+hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
 {
     const dim3 grid(p.top_store_grid), block(kBlock);
+    const uint32_t per_agent = (uint32_t)(((long long)p.H * p.pu * p.W * p.pu) >> 8);
+    const uint32_t c0 = (uint32_t)first * per_agent, c1 = (uint32_t)(first + count) * per_agent;
     if (p.top_unit_px == 128) {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 2>), grid, block, 0, s, p, mask_dev);
-        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 2>), grid, block, 0, s, p, mask_dev);
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 2>), grid, block, 0, s, p, mask_dev, c0, c1);
+        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 2>), grid, block, 0, s, p, mask_dev, c0, c1);
     } else if (p.top_unit_px == 64) {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 4>), grid, block, 0, s, p, mask_dev);
-        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 4>), grid, block, 0, s, p, mask_dev);
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 4>), grid, block, 0, s, p, mask_dev, c0, c1);
+        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 4>), grid, block, 0, s, p, mask_dev, c0, c1);
     } else if (p.top_unit_px == 32) {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 8>), grid, block, 0, s, p, mask_dev);
-        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 8>), grid, block, 0, s, p, mask_dev);
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 8>), grid, block, 0, s, p, mask_dev, c0, c1);
+        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 8>), grid, block, 0, s, p, mask_dev, c0, c1);
     } else if (p.pu < 16) {                                                  // 32 tiles in a chunk
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, true>), grid, block, 0, s, p, mask_dev);
-        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, true>), grid, block, 0, s, p, mask_dev);
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, true>), grid, block, 0, s, p, mask_dev, c0, c1);
+        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, true>), grid, block, 0, s, p, mask_dev, c0, c1);
     } else {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, false>), grid, block, 0, s, p, mask_dev);
-        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, false>), grid, block, 0, s, p, mask_dev);
+        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, false>), grid, block, 0, s, p, mask_dev, c0, c1);
+        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, false>), grid, block, 0, s, p, mask_dev, c0, c1);
     }
     return hipGetLastError();
 }

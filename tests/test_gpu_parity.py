@@ -596,6 +596,7 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
     exercises its skipped chunks; 16 px tiles put two tile rows into one lane group."""
     if env_switch:
         monkeypatch.setenv(*env_switch)
+    monkeypatch.setenv("RCW_TOP_RUNS", "3")      # (two-kernel form: the batch in three runs of agents, store of one beside the drawing of the next)
     rng = np.random.default_rng(29)
     for kw, batch in ((dict(pu_per_tu=32, **CFG2), 300), (dict(pu_per_tu=16, height_tile_map_tu=16, width_tile_map_tu=9, num_rays=100), 21),
                       (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
