@@ -72,11 +72,11 @@ def test_full_size_parity(rcw, oracle, cfg, batch, steps):
 
 
 @pytest.mark.parametrize("cfg,batch,form", [(CFG2, 4096, "two-kernels"), (dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=512), 2048, "two-kernels"),
-                                            (CFG4, 1024, "two-kernels")],
-                         ids=["cfg2_4096", "reference_default_2048", "cfg4_1024"])
+                                            (CFG4, 1024, "two-kernels"), (CFG4, 4100, "two-kernels")],
+                         ids=["cfg2_4096", "reference_default_2048", "cfg4_1024", "cfg4_4100_in_runs"])
 def test_full_size_top_view(rcw, oracle, cfg, batch, form):
     """The opt-in top view at full batch sizes (1 GiB of pixels a step: the two-kernel form's store kernel sweeps its
-    window 16 times).  State of every agent against the non-rendering oracle; both images of a sample of agents (the
+    window 16 times; 4 GiB of 512² px images: the batch goes in four runs of agents, 4100 does not divide evenly).  State of every agent against the non-rendering oracle; both images of a sample of agents (the
     first and last, around the middle, random ones) against a small rendering oracle given the same states; and over
     ALL images a size-independent property: no pixel outside the six colours update_top_view! can write (SR:288-290,
     SR:364-367) — a chunk the store kernel skipped or wrote twice with stale descriptors would show."""
