@@ -17,7 +17,12 @@
 // This is an integer/indexing + streaming-store path: no MFMA, the roofline is HBM write
 // bandwidth, and the frame (4·H_cam·N bytes per agent-step) is written exactly once.
 //
-//   rcw_top_view_kernel  (opt-in) the reference's other per-step image, update_top_view! SR:446-483.
+// (opt-in) the reference's other per-step image, update_top_view! SR:446-483, every pixel written once:
+//   rcw_top_draw_kernel + rcw_top_store_kernel / rcw_top_store_units_kernel   rays -> lines in an LDS bit plane -> the
+//            plane (1/32 of the image) to HBM, on a side stream beside the fill kernel; then the fill kernel's moving
+//            window over the image with the top view's pixel logic;
+//   rcw_top_view_kernel           the same in one persistent kernel (draw and store groups, a ring of LDS planes);
+//   rcw_top_view_inplace_kernel   images whose bit plane does not fit in LDS.
 //
 // Floating point: every operation below is a single IEEE-754 rounding in the world-unit type T
 // (Float32, or Float64 for SingleRoom(; T = Float64)), exactly as the reference (Julia never
