@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RCW_ABI_VERSION 3
+#define RCW_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define RCW_API __attribute__((visibility("default")))
@@ -355,11 +355,25 @@ RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, 
  *   RCW_TOP_VIEW_ONE_KERNEL   write-once: bit planes in LDS, draw and store groups of one persistent kernel
  *   RCW_TOP_VIEW_TWO_KERNELS  write-once, inside rcw_step / rcw_reset / rcw_set_state: draw kernel (bit planes -> HBM,
  *                             beside the camera fill), then the moving-window store kernel; rcw_update_top_view
- *                             alone takes the one-kernel form.  Geometries: H*pu a multiple of 256, 128, 64 or 32 rows,
- *                             pu_per_tu >= 8 dividing that number, player circle <= 32 rows; batches of at
- *                             least 256 MiB of top view a step (smaller ones: the one-kernel form is faster) */
+ *                             alone takes the one-kernel form (except at pixel scales that are not a multiple of 4).
+ *                             Geometries: H*pu a multiple of 256, 128 or 64 rows with pu_per_tu >= 8 dividing that
+ *                             number and a player circle of <= 32 rows (rcw_top_store_kernel / _units_kernel), or any
+ *                             pu_per_tu >= 9 with H*pu a multiple of 4 and >= 42 rows (rcw_top_store_flat_kernel);
+ *                             batches of at least 256 MiB of top view a step (smaller ones: the one-kernel form is
+ *                             faster) unless rcw_set_top_view_form asks for it */
 enum { RCW_TOP_VIEW_NONE = 0, RCW_TOP_VIEW_IN_PLACE = 1, RCW_TOP_VIEW_ONE_KERNEL = 2, RCW_TOP_VIEW_TWO_KERNELS = 3 };
 RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
+/* Choose the form instead of the rule above (all forms write the same pixels; this is a performance choice, e.g. the
+ * one-kernel form for a caller that does not want the handle's side stream, or the two-kernel form for a small batch):
+ * form = 0 restores the automatic choice, else RCW_TOP_VIEW_IN_PLACE / ONE_KERNEL / TWO_KERNELS; RCW_ERR_UNSUPPORTED when
+ * the geometry cannot take it (the handle then keeps the automatic choice).  runs = 0: automatic; 1..8: the two-kernel
+ * form draws and stores the batch in that many runs of agents.  Waits for the handle's stream; reallocates the form's
+ * scratch in HBM.  The library reads no environment variable other than RCW_RCCL_LIBRARY: what used to be development
+ * switches (RCW_TOP_SPLIT, RCW_TOP_RUNS, ...) exists only in the development build (make dev -> librcw_hip_dev.so). */
+RCW_API int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs);
+/* The kernel update_camera_view! (SR:374-444) takes for this handle's camera height and batch (what bench.py labels its
+ * roofline block with): "rcw_fill256_kernel", "rcw_fill_window_kernel", "rcw_fill_flat_kernel", ... */
+RCW_API int rcw_fill_kernel_name(rcw_handle* h, char* buf, int32_t buflen);
 
 /* Introspection */
 RCW_API int rcw_batch(rcw_handle* h, int32_t* out);

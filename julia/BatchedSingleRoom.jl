@@ -1,4 +1,4 @@
-# BatchedSingleRoom.jl — the reference-side binding of librcw_hip (include/rcw.h, ABI version 3).
+# BatchedSingleRoom.jl — the reference-side binding of librcw_hip (include/rcw.h, ABI version 4).
 #
 # This is what a RayCastWorlds.jl maintainer would add to keep the package's API
 # (`RCW.reset!`, `RCW.act!`, `RCW.cast_rays!`, `RCW.update_camera_view!`, `RCW.update_top_view!`,
@@ -35,7 +35,7 @@ import ReinforcementLearningBase as RLBase
 
 const librcw = get(ENV, "LIBRCW_HIP", "librcw_hip.so")
 
-const RCW_ABI_VERSION = 3
+const RCW_ABI_VERSION = 4
 const NUM_ACTIONS = 4   # src/single_room.jl:19
 const RCW_UNIQUE_ID_BYTES = 128
 const RCW_GATHER_COLUMNS = Int32(0)
@@ -425,6 +425,24 @@ function top_view_form(env::BatchedSingleRoom)
     f = Ref{Int32}(0)
     check(ccall((:rcw_top_view_form, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, f))
     return (:none, :in_place, :one_kernel, :two_kernels)[f[] + 1]
+end
+"""
+    set_top_view_form!(env, form = :auto; runs = 0)
+
+Choose the kernel form of `update_top_view!` instead of the library's rule (`rcw_set_top_view_form`): `:auto`,
+`:in_place`, `:one_kernel` or `:two_kernels`; `runs` = 0 (automatic) or 1..8 runs of agents for the two-kernel form.
+All forms write the same pixels.  Throws when the geometry cannot take the form (the handle keeps the automatic one).
+"""
+function set_top_view_form!(env::BatchedSingleRoom, form::Symbol = :auto; runs::Integer = 0)
+    code = Dict(:auto => 0, :in_place => 1, :one_kernel => 2, :two_kernels => 3)[form]
+    check(ccall((:rcw_set_top_view_form, librcw), Cint, (Ptr{Cvoid}, Int32, Int32), env.handle, code, runs))
+    return nothing
+end
+"The kernel `update_camera_view!` takes for this camera height and batch (`rcw_fill_kernel_name`)."
+function fill_kernel_name(env::BatchedSingleRoom)
+    buf = Vector{UInt8}(undef, 64)
+    check(ccall((:rcw_fill_kernel_name, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32), env.handle, buf, length(buf)))
+    return unsafe_string(pointer(buf))
 end
 function batch(env::BatchedSingleRoom)
     n = Ref{Int32}(0)

@@ -61,7 +61,7 @@ class RcwConfig(C.Structure):
 def default_config(**overrides) -> RcwConfig:
     """Reference defaults SR:258-272, SR:288-296 (restated, not read from the product)."""
     cfg = RcwConfig()
-    cfg.abi_version = 3
+    cfg.abi_version = 4
     cfg.height_tile_map_tu = 8
     cfg.width_tile_map_tu = 16
     cfg.num_directions = 128

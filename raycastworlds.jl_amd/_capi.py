@@ -20,12 +20,13 @@ RCW_ERR_OUT_OF_MEMORY = -4
 RCW_ERR_OUT_OF_BOUNDS = -5
 RCW_ERR_HIP = -6
 RCW_ERR_UNSUPPORTED = -7
-RCW_ABI_VERSION = 3
+RCW_ABI_VERSION = 4
 
 # R of SingleRoom(; R = ...) SR:266 (include/rcw.h RCW_REWARD_*)
 RCW_REWARD_FLOAT32, RCW_REWARD_FLOAT64, RCW_REWARD_INT32, RCW_REWARD_INT64 = 0, 1, 2, 3
 RCW_GATHER_COLUMNS, RCW_GATHER_FRAMES = 0, 1
 RCW_UNIQUE_ID_BYTES = 128
+RCW_TOP_VIEW_NONE, RCW_TOP_VIEW_IN_PLACE, RCW_TOP_VIEW_ONE_KERNEL, RCW_TOP_VIEW_TWO_KERNELS = 0, 1, 2, 3
 
 
 class RcwConfig(C.Structure):
@@ -132,6 +133,8 @@ SIGNATURES = {
     "rcw_profile": [_vp, _i32],
     "rcw_profile_read": [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)],
     "rcw_top_view_form": [_vp, C.POINTER(_i32)],
+    "rcw_set_top_view_form": [_vp, _i32, _i32],
+    "rcw_fill_kernel_name": [_vp, C.c_char_p, _i32],
     "rcw_comm_unique_id": [_vp],
     "rcw_comm_init": [_vp, _vp, _i32, _i32],
     "rcw_comm_destroy": [_vp],
@@ -194,37 +197,50 @@ def preload_rccl() -> None:
             pass
 
 
-def load() -> C.CDLL:
-    """Load librcw_hip.so; loud failure when it has not been built."""
+DEV_LIB_PATH = os.path.join(_PKG, "lib", "librcw_hip_dev.so")
+_libs = {}
+
+
+def load(library=None) -> C.CDLL:
+    """Load librcw_hip.so — the shipped library, which reads no RCW_* environment variable but RCW_RCCL_LIBRARY; loud
+    failure when it has not been built.  `library="dev"` (or a path) loads the development build instead
+    (`make dev`: -DRCW_DEV_SWITCHES, the tuning knobs and the measured-and-rejected kernel variants); development
+    tools may also point every default load at another build with RCW_LIBRARY=<path> — an explicit path, never a
+    silent switch inside the library."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if library is None:
+        library = os.environ.get("RCW_LIBRARY") or None
+    path = LIB_PATH if library is None else (DEV_LIB_PATH if library == "dev" else os.path.abspath(library))
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            f"{path} is missing: build it with `python __graft_entry__.py build` "
             f"(or `make -C raycastworlds.jl_amd/csrc`). There is no CPU fallback."
         )
     _preload_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
     if lib.rcw_abi_version() != RCW_ABI_VERSION:
         raise ImportError(f"librcw_hip ABI {lib.rcw_abi_version()} != {RCW_ABI_VERSION}: rebuild with `make -C raycastworlds.jl_amd/csrc`")
-    _lib = lib
+    _libs[path] = lib
+    if path == LIB_PATH or _lib is None:
+        _lib = lib
     return lib
 
 
-def last_error() -> str:
-    msg = load().rcw_last_error()
+def last_error(lib=None) -> str:
+    msg = (lib or load()).rcw_last_error()
     return msg.decode("utf-8", "replace") if msg else ""
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib=None) -> None:
     if rc == RCW_OK:
         return
-    msg = last_error()
+    msg = last_error(lib)
     if rc == RCW_ERR_INVALID_ACTION:
         # the reference raises AssertionError("Invalid action: ...") at SR:140
         raise AssertionError(msg or "Invalid action")

@@ -42,7 +42,7 @@ int fail(int code, const char* fmt, ...)
 
 struct rcw_handle {
     rcw_config cfg{};
-    int32_t B = 0, device = 0, nchunks = 0;
+    int32_t B = 0, device = 0, nchunks = 0, num_cus = 256;
     RcwDev dev{};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -95,8 +95,13 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
 {
     const RcwDev& d = h->dev;
     hipError_t e;
-    if (!d.top_split || !beside) {           // (nothing to hide the draw kernel behind: the one-kernel form is the faster one)
+    if (!d.top_split || (!beside && !d.top_alone_split)) {   // (nothing to hide the draw kernel behind: the one-kernel form is the faster one)
         if ((e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;
+        return between();
+    }
+    if (!beside) {                                           // stand-alone, two kernels back to back on the handle's stream
+        if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
+        if ((e = rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
         return between();
     }
     if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
@@ -105,19 +110,26 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
     // long against the camera fill): the side stream draws run after run without waiting for anything, the handle's
     // stream stores run r as soon as it is drawn — so what of the drawing does not fit beside the camera fill runs beside
     // the (HBM-bound) storing of earlier runs.
+    // From here on the side stream may hold work: whatever fails, the handle's stream joins it again (every recorded
+    // event is waited for), so that nothing runs on the side stream that the handle's stream does not wait for — a
+    // later rcw_destroy / rcw_set_stream synchronises the handle's stream only, and a capture must end joined.
     const int runs = d.top_runs > 1 ? d.top_runs : 1;
-    for (int r = 0; r < runs; ++r) {
+    int recorded = 0;
+    for (int r = 0; r < runs && e == hipSuccess; ++r) {
         const int first = (int)((long long)d.B * r / runs), count = (int)((long long)d.B * (r + 1) / runs) - first;
-        if ((e = rcw_launch_top_draw(d, mask_dev, first, count, h->top_stream)) != hipSuccess) return e;
-        if ((e = hipEventRecord(h->ev_top_join[r], h->top_stream)) != hipSuccess) return e;
+        e = rcw_launch_top_draw(d, mask_dev, first, count, h->top_stream);
+        const hipError_t rec = hipEventRecord(h->ev_top_join[r], h->top_stream);    // (also after a failed launch: earlier runs' draws are queued)
+        if (rec == hipSuccess) recorded = r + 1;
+        if (e == hipSuccess) e = rec;
     }
-    if ((e = between()) != hipSuccess) return e;
-    for (int r = 0; r < runs; ++r) {
+    if (e == hipSuccess) e = between();
+    for (int r = 0; r < recorded; ++r) {
         const int first = (int)((long long)d.B * r / runs), count = (int)((long long)d.B * (r + 1) / runs) - first;
-        if ((e = hipStreamWaitEvent(h->stream, h->ev_top_join[r], 0)) != hipSuccess) return e;
-        if ((e = rcw_launch_top_store(d, mask_dev, first, count, h->stream)) != hipSuccess) return e;
+        const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[r], 0);
+        if (e == hipSuccess) e = w;
+        if (e == hipSuccess) e = rcw_launch_top_store(d, mask_dev, first, count, h->stream);
     }
-    return hipSuccess;
+    return e;
 }
 
 // One step = cast kernel + fill kernel, back to back on the handle's stream (+ the top view when the handle renders
@@ -171,6 +183,7 @@ void free_all(rcw_handle* h)
         h->ev_actions[k] = nullptr;
     }
     for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
+    if (h->top_stream) (void)hipStreamSynchronize(h->top_stream);          // (a draw kernel of a failed step may still run)
     for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (h->ev_top_fork) (void)hipEventDestroy(h->ev_top_fork);
     for (hipEvent_t& q : h->ev_top_join) { if (q) (void)hipEventDestroy(q); q = nullptr; }
@@ -257,6 +270,107 @@ int upload_tables(rcw_handle* h)
     RCW_HIP(hipMemcpyAsync(h->d_dir_table, dirs, nd2 * h->real_size, hipMemcpyHostToDevice, h->stream));
     RCW_HIP(hipMemcpyAsync(h->d_ray_table, rays, nr * h->real_size, hipMemcpyHostToDevice, h->stream));
     RCW_HIP(hipStreamSynchronize(h->stream));
+    return RCW_OK;
+}
+
+// Development switches: only a build with -DRCW_DEV_SWITCHES (make dev -> librcw_hip_dev.so) reads them.
+#ifdef RCW_DEV_SWITCHES
+#define RCW_DEV_ENV(name) std::getenv(name)
+#else
+#define RCW_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
+// Which form update_top_view! (SR:446-483) takes for this handle, and its scratch in HBM.  want_form: 0 = the rule below,
+// or one of RCW_TOP_VIEW_IN_PLACE / ONE_KERNEL / TWO_KERNELS (rcw_set_top_view_form); want_runs: 0 = the rule, or 1..8.
+// `lenient`: a form the geometry cannot take falls back to the rule (development switches) instead of failing.
+int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
+{
+    RcwDev& d = h->dev;
+    const rcw_config* cfg = &h->cfg;
+    const int H = cfg->height_tile_map_tu, W = cfg->width_tile_map_tu, N = cfg->num_rays, Hc = cfg->height_camera_view_pu;
+    const size_t B = (size_t)h->B;
+    if (h->top_stream) RCW_HIP(hipStreamSynchronize(h->top_stream));
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr;
+    d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
+    d.top_alone_split = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256;
+    if (!cfg->render_top_view) {
+        if (want_form != 0 && !lenient) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
+        return RCW_OK;
+    }
+    // the write-once kernel keeps a ring of 1..3 agents' bit planes in LDS (160 KiB per CU): three where three
+    // workgroups per CU still fit beside each other, else two, else one; larger images take the in-place kernel
+    d.top_lds = 3;
+    if (rcw_top_view_lds_bytes(d) > 52 * 1024) d.top_lds = 2;
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1;
+    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;             // (the size depends on top_lds)
+    if ((long long)H * cfg->pu_per_tu > 16384 || (long long)W * cfg->pu_per_tu > 16384) d.top_lds = 0;   // the bit-plane kernels' line walk is exact for lines of up to 2^14 pixels
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_RING")) { const int k = std::atoi(v); if (k >= 1 && k <= 3 && d.top_lds > 0) { d.top_lds = k; if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1; } }
+    if (want_form == RCW_TOP_VIEW_IN_PLACE) d.top_lds = 0;
+    if (want_form == RCW_TOP_VIEW_ONE_KERNEL && !d.top_lds && !lenient)
+        return fail(RCW_ERR_UNSUPPORTED, "the image's bit planes do not fit in LDS: this geometry takes the in-place form only");
+    {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
+        const size_t lds = rcw_top_view_lds_bytes(d);
+        int per_cu = lds ? (int)((160 * 1024) / lds) : 4;
+        per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);   // 3 x 8 wavefronts: what the kernel's register use admits (4 measured no faster)
+        d.top_grid = per_cu * h->num_cus;
+    }
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_grid = g; }
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_store_grid = g; }
+    // The two-kernel form where the geometry allows it: the unit kernels (whole tiles in runs of 256 / 128 / 64 / 32 rows)
+    // or the flat kernel (any pixel scale from 9, any image height that is a multiple of 4 from 42 rows)
+    int unit = d.top_lds > 0 ? rcw_top_split_unit(d) : 0;
+    const int flat = d.top_lds > 0 ? rcw_top_flat_cols(d) : 0;
+    if (flat && unit && unit < 64) unit = 0;                              // (eight units a chunk: the flat kernel is the faster one)
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_FLAT")) { const int f = std::atoi(v); if (f == 1 && flat) unit = 0; if (f == 0 && rcw_top_split_unit(d) && d.top_lds > 0) unit = rcw_top_split_unit(d); }
+    const bool eligible = unit || flat;
+    d.top_unit_px = unit ? unit : 256;
+    d.top_flat = unit ? 0 : flat;
+    d.top_plane_words = d.top_flat ? rcw_top_plane_words(d) : 0;
+    // ... where the batch is big enough to pay for its two extra launches and the side-stream fork / join (≈ 13 µs a step:
+    // with 8×8 tiles of 32 px, 1 / 256 / 1024 / 4096 agents take 51 / 62 / 102 / 340 µs a step against 37 / 49 / 104 / 387 in
+    // the one-kernel form): from 256 MiB of top view a step.
+    d.top_split = eligible ? 1 : 0;
+    if (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) d.top_split = 0;
+    if (want_form == RCW_TOP_VIEW_ONE_KERNEL || want_form == RCW_TOP_VIEW_IN_PLACE) d.top_split = 0;
+    if (want_form == RCW_TOP_VIEW_TWO_KERNELS) {
+        if (eligible) d.top_split = 1;
+        else if (!lenient) return fail(RCW_ERR_UNSUPPORTED, "this geometry does not take the two-kernel form (pu_per_tu >= 8, image height a multiple of 4 and of at least 42 rows, bit plane within LDS)");
+    }
+    if (!d.top_split) { d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; }
+    // rcw_update_top_view alone has no camera fill to hide the drawing behind: the one-kernel form is the faster one
+    // (209 against 227 us at the default geometry) — except where only its generic paths apply (pixel scales that do not
+    // divide the four-pixel groups: 29 % of the roofline), i.e. the flat kernel's own geometries
+    d.top_alone_split = d.top_split && d.top_flat && (cfg->pu_per_tu & 3) != 0 ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_ALONE_SPLIT")) d.top_alone_split = d.top_split && std::atoi(v) ? 1 : 0;
+    // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on
+    // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top
+    // view in a step with 256 / 512 / 1024 threads: 512² px, 256 rays 180 / 182 / 200; 768² px 212 / 200 / 203; 1024² px, 1024 rays 357 / 265 / 216)
+    if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > 64 * 1024) { const int b = ((N + 255) / 256) * 256; d.top_draw_block = b < 512 ? 512 : (b > 1024 ? 1024 : b); }
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = b; }
+    // runs of agents: where the lines are long against the camera image's columns ((Ht + Wt) / 2 >= 1.75 H_cam) the drawing
+    // does not fit beside the camera fill; with several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside
+    // the storing of earlier runs.  Measured (µs a step with 1 / 2 / 4 / 8 runs): 16×16 map, 512 rays, 16,384 agents (16 GiB of
+    // top view) 4516 / 4409 / 4332 / 4294; 32×32 map, 1024 rays, 8192 agents (32 GiB) 8586 / 8459 / 7658 / 8068.  Runs of
+    // 256 MiB do NOT pay (four short store launches and their joins: 205 vs 181 µs at 1 GiB of 512² px images).
+    if (2ll * ((long long)H + W) * cfg->pu_per_tu >= 7ll * Hc) {
+        const size_t gib = (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)) >> 30;
+        d.top_runs = gib >= 4 ? 4 : (gib >= 2 ? 2 : 1);
+    }
+    if (want_runs >= 1) d.top_runs = want_runs <= 8 ? (want_runs <= h->B ? want_runs : h->B) : 8;
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
+    if (d.top_split) {
+        hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));
+        if (e == hipSuccess) e = hipMalloc(&h->d_top_hdr, (size_t)h->B * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc(&h->d_top_codes, rcw_top_codes_bytes(d));
+        if (e == hipSuccess && !h->top_stream) e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
+        if (e == hipSuccess && !h->ev_top_fork) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
+        for (hipEvent_t& q : h->ev_top_join) if (e == hipSuccess && !q) e = hipEventCreateWithFlags(&q, hipEventDisableTiming);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "top view planes: %s", hipGetErrorString(e));
+        d.top_plane = (uint32_t*)h->d_top_plane; d.top_hdr = (int2*)h->d_top_hdr; d.top_codes = (uint2*)h->d_top_codes;
+    }
+    hipError_t e = rcw_prepare_top_view(d, h->device);
+    if (e != hipSuccess) return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e));
     return RCW_OK;
 }
 
@@ -577,84 +691,31 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // player_radius_pu = wu_to_pu(player_radius_wu, pu_per_tu) SR:469 = floor(Int, r * pu) + 1 in T (UT:6)
     d.top_rp = h->real64 ? (int32_t)std::floor(cfg->player_radius_wu_f64 * (double)cfg->pu_per_tu) + 1
                          : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
-    // the write-once kernel keeps a ring of 1..3 agents' bit planes in LDS (160 KiB per CU): three where three
-    // workgroups per CU still fit beside each other, else two, else one; larger images take the in-place kernel
-    d.top_lds = 3;
-    if (rcw_top_view_lds_bytes(d) > 52 * 1024) d.top_lds = 2;
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1;
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;             // (the size depends on top_lds)
-    if (!cfg->render_top_view) d.top_lds = 0;
-    if ((long long)H * cfg->pu_per_tu > 16384 || (long long)W * cfg->pu_per_tu > 16384) d.top_lds = 0;   // the bit-plane kernels' line walk is exact for lines of up to 2^14 pixels
-    if (const char* v = std::getenv("RCW_TOP_RING")) { const int k = std::atoi(v); if (k >= 1 && k <= 3 && d.top_lds > 0) { d.top_lds = k; if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1; } }
-    {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
-        const size_t lds = rcw_top_view_lds_bytes(d);
-        int per_cu = lds ? (int)((160 * 1024) / lds) : 4;
-        per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);   // 3 x 8 wavefronts: what the kernel's register use admits (4 measured no faster)
-        d.top_grid = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-    }
-    d.top_debug = 0;
-    if (const char* v = std::getenv("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
-    if (const char* v = std::getenv("RCW_TOP_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_grid = g; }
-    if (const char* v = std::getenv("RCW_TOP_INPLACE")) { if (std::atoi(v)) d.top_lds = 0; }
     d.status = (int32_t*)h->d_status;
     d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // fill kernel: one workgroup per CU (256 on an MI355X in SPX mode; a partitioned device reports fewer)
-    d.fill_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; d.fill_plain = 0;
+    d.fill_grid = h->num_cus; d.fill_plain = 0; d.fill_flat = 0;
     // cast kernel: two view columns per lane (measured best at 4096 x 256), 64..256 threads per agent
     { const int lanes = (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
-    if (const char* v = std::getenv("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
-    d.cast_ballot = 0;
-    if (const char* v = std::getenv("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
-    d.cast_table_lds = 0;
-    if (const char* v = std::getenv("RCW_CAST_TABLE"))   // only where tile bytes + 5 N table values fit the default 64 KiB
+    d.cast_ballot = 0; d.cast_table_lds = 0; d.top_debug = 0;
+    // development builds (make dev: -DRCW_DEV_SWITCHES -> librcw_hip_dev.so) read tuning knobs and the measured-and-rejected
+    // kernel variants from the environment; the shipped library reads nothing but RCW_RCCL_LIBRARY
+    if (const char* v = RCW_DEV_ENV("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
+    if (const char* v = RCW_DEV_ENV("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_CAST_TABLE"))   // only where tile bytes + 5 N table values fit the default 64 KiB
         d.cast_table_lds = std::strcmp(v, "lds") == 0 && rcw_step_lds_bytes(d) + (size_t)RCW_TABLE_ROWS * N * h->real_size + 64 <= 64 * 1024 ? 1 : 0;
-    // tuning knobs for development runs only
-    if (const char* v = std::getenv("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
-    if (const char* v = std::getenv("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
-
-    // the two-kernel top view where the geometry allows it (RCW_TOP_SPLIT=0: keep the one-kernel ring form)
-    d.top_store_grid = d.fill_grid;
-    if (const char* v = std::getenv("RCW_TOP_STORE_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_store_grid = g; }
-    d.top_unit_px = cfg->render_top_view && d.top_lds > 0 ? rcw_top_split_unit(d) : 0;
-    d.top_split = d.top_unit_px ? 1 : 0;
-    // ... where the batch is big enough to pay for its two extra launches and the side-stream fork / join (≈ 13 µs a step:
-    // with 8×8 tiles of 32 px, 1 / 256 / 1024 / 4096 agents take 51 / 62 / 102 / 340 µs a step against 37 / 49 / 104 / 387 in
-    // the one-kernel form): from 256 MiB of top view a step.  RCW_TOP_SPLIT=0: never, =2: wherever the geometry allows.
-    if (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) d.top_split = 0;
-    if (const char* v = std::getenv("RCW_TOP_SPLIT")) { const int f = std::atoi(v); if (!f) d.top_split = 0; else if (f == 2 && d.top_unit_px) d.top_split = 1; }
-    if (!d.top_split) d.top_unit_px = 256;
-    // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on
-    // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top
-    // view in a step with 256 / 512 / 1024 threads: 512² px, 256 rays 180 / 182 / 200; 768² px 212 / 200 / 203; 1024² px, 1024 rays 357 / 265 / 216)
-    d.top_draw_block = 256;
-    if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > 64 * 1024) { const int b = ((N + 255) / 256) * 256; d.top_draw_block = b < 512 ? 512 : (b > 1024 ? 1024 : b); }
-    if (const char* v = std::getenv("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = b; }
-    // runs of agents: where the lines are long against the camera image's columns ((Ht + Wt) / 2 >= 1.75 H_cam) the drawing
-    // does not fit beside the camera fill; with several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside
-    // the storing of earlier runs.  Measured (µs a step with 1 / 2 / 4 / 8 runs): 16×16 map, 512 rays, 16,384 agents (16 GiB of
-    // top view) 4516 / 4409 / 4332 / 4294; 32×32 map, 1024 rays, 8192 agents (32 GiB) 8586 / 8459 / 7658 / 8068.  Runs of
-    // 256 MiB do NOT pay (four short store launches and their joins: 205 vs 181 µs at 1 GiB of 512² px images).
-    d.top_runs = 1;
-    if (2ll * ((long long)H + W) * cfg->pu_per_tu >= 7ll * Hc) {
-        const size_t gib = (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)) >> 30;
-        d.top_runs = gib >= 4 ? 4 : (gib >= 2 ? 2 : 1);
-    }
-    if (const char* v = std::getenv("RCW_TOP_RUNS")) { const int r = std::atoi(v); if (r >= 1 && r <= 8 && r <= batch) d.top_runs = r; }
-    d.top_store_plain = 0;
-    if (const char* v = std::getenv("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
-    if (d.top_split) {
-        hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));
-        if (e == hipSuccess) e = hipMalloc(&h->d_top_hdr, (size_t)batch * sizeof(int2));
-        if (e == hipSuccess) e = hipMalloc(&h->d_top_codes, rcw_top_codes_bytes(d));
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
-        for (hipEvent_t& q : h->ev_top_join) if (e == hipSuccess) e = hipEventCreateWithFlags(&q, hipEventDisableTiming);
-        if (e != hipSuccess) { free_all(h); delete h; return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "top view planes: %s", hipGetErrorString(e)); }
-        d.top_plane = (uint32_t*)h->d_top_plane; d.top_hdr = (int2*)h->d_top_hdr; d.top_codes = (uint2*)h->d_top_codes;
-    }
-    if (cfg->render_top_view) {
-        hipError_t e = rcw_prepare_top_view(d);
-        if (e != hipSuccess) { free_all(h); delete h; return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e)); }
+    if (const char* v = RCW_DEV_ENV("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
+    if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
+    {
+        int want_form = 0, want_runs = 0;
+        if (const char* v = RCW_DEV_ENV("RCW_TOP_SPLIT")) { const int f = std::atoi(v); if (!f) want_form = RCW_TOP_VIEW_ONE_KERNEL; else if (f == 2) want_form = RCW_TOP_VIEW_TWO_KERNELS; }
+        if (const char* v = RCW_DEV_ENV("RCW_TOP_INPLACE")) { if (std::atoi(v)) want_form = RCW_TOP_VIEW_IN_PLACE; }
+        if (const char* v = RCW_DEV_ENV("RCW_TOP_RUNS")) { const int r = std::atoi(v); if (r >= 1 && r <= 8 && r <= batch) want_runs = r; }
+        rc = plan_top_view(h, want_form, want_runs, /*lenient=*/true);
+        if (rc != RCW_OK) { free_all(h); delete h; return rc; }
     }
     if (rcw_step_lds_bytes(d) > 64 * 1024) {
         free_all(h); delete h;
@@ -1246,6 +1307,29 @@ int rcw_top_view_form(rcw_handle* h, int32_t* form)
     if (!h || !form) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
     const RcwDev& d = h->dev;
     *form = !d.top_view ? RCW_TOP_VIEW_NONE : d.top_split ? RCW_TOP_VIEW_TWO_KERNELS : d.top_lds ? RCW_TOP_VIEW_ONE_KERNEL : RCW_TOP_VIEW_IN_PLACE;
+    return RCW_OK;
+}
+
+int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
+    if (form != 0 && form != RCW_TOP_VIEW_IN_PLACE && form != RCW_TOP_VIEW_ONE_KERNEL && form != RCW_TOP_VIEW_TWO_KERNELS)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "form must be 0 (automatic) or RCW_TOP_VIEW_IN_PLACE / ONE_KERNEL / TWO_KERNELS (got %d)", form);
+    if (runs < 0 || runs > 8) return fail(RCW_ERR_INVALID_ARGUMENT, "runs must be 0 (automatic) or 1..8 (got %d)", runs);
+    RCW_HIP(hipStreamSynchronize(h->stream));        // the scratch of the current form may be in use
+    rc = plan_top_view(h, form, runs, /*lenient=*/false);
+    if (rc != RCW_OK) {                               // leave a usable handle behind: back to the automatic choice
+        const int rc2 = plan_top_view(h, 0, 0, true);
+        return rc2 != RCW_OK ? rc2 : rc;
+    }
+    return RCW_OK;
+}
+
+int rcw_fill_kernel_name(rcw_handle* h, char* buf, int32_t buflen)
+{
+    if (!h || !buf || buflen < 1) return fail(RCW_ERR_INVALID_ARGUMENT, "bad argument");
+    std::snprintf(buf, (size_t)buflen, "%s", rcw_fill_kernel_name(h->dev, (long long)h->dev.B * h->dev.N));
     return RCW_OK;
 }
 

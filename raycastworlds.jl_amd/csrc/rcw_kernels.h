@@ -30,6 +30,7 @@ struct RcwDev {
     int32_t oob_empty;       // RCW_OOB_TREAT_EMPTY
     int32_t fill_grid;       // workgroups of the fill kernel (the moving window = fill_grid KiB x 4)
     int32_t fill_plain;      // 1: plain stores, 0: non-temporal
+    int32_t fill_flat;       // development only (RCW_FILL_FLAT): rcw_fill_flat_kernel also where rcw_fill_window_kernel<2 / 4> applies
     int32_t cast_block;      // threads per agent in the cast kernel (multiple of 64, <= 256)
     int32_t cast_ballot;     // development only (RCW_CAST_MARCH=ballot): the ballot-bounded march instead of the exec-masked one
     int32_t cast_table_lds;  // development only (RCW_CAST_TABLE=lds): stage the heading's ray-table slice in LDS first
@@ -60,6 +61,9 @@ struct RcwDev {
     int32_t top_grid;        // workgroups of the (persistent) write-once top view kernel
     int32_t top_unit_px;     // ... its store kernel's unit: 256 rows of an image column (a whole 1 KiB chunk), 128 or 64
     int32_t top_split;       // 1: the two-kernel top view (draw kernel -> planes in HBM -> moving-window store kernel)
+    int32_t top_flat;        // ... with rcw_top_store_flat_kernel (any pixel scale >= 9): the image columns a 256-pixel chunk may touch; 0: the unit kernels
+    int32_t top_plane_words; // ... and the words of one agent's region of top_plane in that form
+    int32_t top_alone_split; // rcw_update_top_view alone (no camera fill beside it) also takes the two-kernel form, back to back
     int32_t top_runs;        // the batch is drawn and stored in this many runs of agents (store of run r beside the drawing of run r + 1)
     int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU
     int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
@@ -95,11 +99,15 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
 size_t rcw_top_view_lds_bytes(const RcwDev& p);
 // the two-kernel top view: eligibility of a geometry, its HBM scratch sizes, and the two launches
 int rcw_top_split_unit(const RcwDev& p);   // rows of a store-kernel unit (256 / 128 / 64), 0: geometry not taken
+int rcw_top_flat_cols(const RcwDev& p);    // rcw_top_store_flat_kernel: columns a chunk may touch, 0: geometry not taken
+int32_t rcw_top_plane_words(const RcwDev& p);
+int rcw_fill_flat_cols(const RcwDev& p);   // rcw_fill_flat_kernel: columns a chunk may touch at this camera height, 0: not taken
+const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // the kernel rcw_launch_fill takes
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);    // agents [first, first + count)
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
-hipError_t rcw_prepare_top_view(const RcwDev& p);
+hipError_t rcw_prepare_top_view(const RcwDev& p, int device);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos /* float2* or double2* */,
                                 const int32_t* dir, const uint8_t* mask_dev, hipStream_t s);

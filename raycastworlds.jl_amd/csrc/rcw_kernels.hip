@@ -36,9 +36,12 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace {
 
 constexpr int kBlock = 256;   // 4 wavefronts of 64
+constexpr int kFlatMaxCols = 8;   // image columns a 256-pixel chunk of the flat batch may touch (rcw_fill_flat_kernel, rcw_top_store_flat_kernel)
 
 // 16-byte store unit (a native vector, so __builtin_nontemporal_store accepts it)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -241,6 +244,7 @@ __device__ __forceinline__ RayHit<T> cast_ray(const uint8_t* tb, int H, int W, T
     return r;
 }
 
+#ifdef RCW_DEV_SWITCHES
 // The march north_star words literally: a wave-uniform loop bound resolved by ballot.  Every lane of the wavefront
 // iterates until the LAST ray of the wavefront has hit (`__ballot(still marching) != 0`), finished lanes carrying their
 // state through selects, so there is no divergent branch at all.  Same results as cast_ray, bit for bit; kept as a
@@ -288,6 +292,7 @@ __device__ __forceinline__ RayHit<T> cast_ray_ballot(const uint8_t* tb, int H, i
     r.t = t;
     return r;
 }
+#endif   // RCW_DEV_SWITCHES
 
 // ---- column height  SR:404-411 ------------------------------------------------------------
 template <typename T>
@@ -312,8 +317,13 @@ __device__ __forceinline__ uint32_t pixel(int r, int pad, int Hc, uint32_t colou
     return r < pad ? ceil_c : (r < Hc - pad ? colour : floor_c);
 }
 
-// floor(n / d) for 0 <= n < 2^23 and d >= 1 without the integer-division sequence: the Float32 quotient is off by at
-// most one, which the two corrections repair (products stay below 2^24, exact in int32)
+// floor(n / d) for n >= 0, d >= 1 without the integer-division sequence: the Float32 quotient is off by at most one,
+// which the two corrections repair.  Preconditions: (q + 1)·d fits int32, i.e. n < 2^31 - d, and the error of
+// (float)n · (1/d) stays below one — certain for n < 2^23 (everything is then exact to a rounding), and also for larger n
+// as long as the QUOTIENT is small: the relative error is ~2^-22, so n / d <= 2^13 keeps it below 2^-9.  The callers:
+// rcw_fill_flat_kernel / rcw_top_store_flat_kernel (n < 2^20 + 256), top_store (n < 2^14) and rcw_fill_frame_kernel, whose
+// flat index reaches N·H_cam < 2^25 with a quotient (the column) <= N <= 8192 — rcw_launch_fill's guard, restated here
+// because widening it would silently produce wrong columns (tests/test_host_logic.py checks the admitted range).
 __device__ __forceinline__ int fast_div(int n, int d, float inv_d)
 {
     int q = (int)((float)n * inv_d);
@@ -404,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
 
     // ---- phase 1: one lane per view column --------------------------------------------------
     const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * p.N;
+#ifdef RCW_DEV_SWITCHES
     if (p.cast_table_lds) {
         // Development switch RCW_CAST_TABLE=lds: stage the heading's table slice (5 N values) in LDS first, as
         // north_star words it, then read it back.  Every entry is used exactly once by exactly one lane, so the copy
@@ -414,12 +425,17 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         __syncthreads();
         tab = stab;
     }
+#endif
     for (int i = tid; i < p.N; i += (int)blockDim.x) {                        // SR:220, SR:401
         const T dx = tab[i], dy = tab[p.N + i];
         const T ddx = tab[2 * p.N + i], ddy = tab[3 * p.N + i];
         const T dot = tab[4 * p.N + i];
+#ifdef RCW_DEV_SWITCHES
         const RayHit<T> r = p.cast_ballot ? cast_ray_ballot<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy)
                                           : cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+#else
+        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+#endif
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu<T>(p, r.dist, dot);
         // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
@@ -539,6 +555,115 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_window_kernel(const RcwDev p,
             v.w = pixel(r0 + 3, pad, Hc, c, ceil_c, floor_c);
             __builtin_nontemporal_store(v, out + (base + (long long)l * G) * 64 + lane);
         }
+    }
+}
+
+// The moving window for ANY camera height of at least 37 rows (height_camera_view_pu is a free kwarg, SR:271): a chunk
+// is 256 consecutive pixels of the flat (H_cam, N, B) batch, whatever columns they belong to.  A chunk that starts at
+// row rem0 of its first column touches at most K = 254 / H_cam + 2 columns; lane l of the prefetch finds (first
+// column, rem0) of the wavefront's l-th next chunk — carried from group to group as (quotient, remainder), no division
+// — loads those K columns' descriptors and parks them as (padding | valid << 31, colour) pairs in wave-private LDS.  In
+// the chunk loop a lane derives its own column from its flat pixel offset (rem0 + 4 lane) with a Float32 reciprocal
+// (fast_div: the offset stays below 2^20 + 256), reads that column's pair back with one ds_read_b64 and writes its
+// four pixels with one 16-byte store, as the kernels above.  ALIGNED (H_cam % 4 == 0): the four pixels never straddle
+// a column; otherwise the lane also reads the next column's pair and picks per pixel.  Chunks at a masked agent's
+// border and the batch's last, short chunk take a per-pixel path (wave-uniform branch).
+template <bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
+                                                               const int32_t* __restrict__ col_h,
+                                                               const uint8_t* __restrict__ col_c,
+                                                               uint32_t* __restrict__ out, long long total_cols,
+                                                               const uint8_t* __restrict__ mask, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x & 63;
+    const uint32_t G = gridDim.x * (kBlock / 64);
+    const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    const int Hc = p.Hc, KS = K + 1;                                      // (one spare pair per chunk: the straddling read of the last column)
+    const float inv_hc = 1.0f / (float)Hc;
+    const unsigned long long total_px = (unsigned long long)total_cols * (unsigned)Hc;
+    const unsigned long long total_chunks = (total_px + 255) >> 8;
+    uint2* const desc = reinterpret_cast<uint2*>(lds) + (size_t)(threadIdx.x >> 6) * 64 * KS;   // [64 chunks][KS]
+    // this lane's chunk of the first group, as (first column, row in it); every group moves all lanes by the same pixels
+    const unsigned long long id0 = (unsigned long long)g + (unsigned long long)lane * G;
+    const unsigned long long step_px = (unsigned long long)G * 64 * 256;
+    const uint32_t dq = (uint32_t)(step_px / (unsigned)Hc), dr = (uint32_t)(step_px - (unsigned long long)dq * (unsigned)Hc);
+    uint32_t col = (uint32_t)((id0 * 256) / (unsigned)Hc);
+    uint32_t rem = (uint32_t)(id0 * 256 - (unsigned long long)col * (unsigned)Hc);
+    u32x4* const out4 = reinterpret_cast<u32x4*>(out);
+    for (unsigned long long base = g; base < total_chunks; base += (unsigned long long)G * 64) {
+        const unsigned long long id = base + (unsigned long long)lane * G;
+        const bool exists = id < total_chunks;
+        const int touched = exists ? (int)((rem + 255u) / (unsigned)Hc) : -1;         // last column of the chunk, relative
+        bool all_valid = exists && (id + 1) * 256 <= total_px;
+        // (all loads first, then everything that uses one: K round trips one after the other would cost a third of a group's time)
+        int32_t hh[kFlatMaxCols + 1];
+        uint32_t cc[kFlatMaxCols + 1], mm[kFlatMaxCols + 1];
+#pragma unroll
+        for (int j = 0; j <= kFlatMaxCols; ++j) {
+            const unsigned long long c = (unsigned long long)col + (unsigned)j;
+            const bool in = j <= touched && c < (unsigned long long)total_cols;
+            hh[j] = in ? col_h[c] : 0;
+            cc[j] = in ? (uint32_t)col_c[c] : 0u;
+            mm[j] = in ? (mask != nullptr ? (uint32_t)mask[c / (unsigned)p.N] : 1u) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j <= kFlatMaxCols; ++j) {
+            if (j >= KS) break;                                              // wave-uniform
+            const bool valid = mm[j] != 0u;
+            const uint32_t pad = valid ? ((uint32_t)column_padding(Hc, hh[j]) | 0x80000000u) : 0u;
+            const uint32_t colour = valid ? p.colour[cc[j] & 3] : 0u;
+            if (j <= touched && !valid) all_valid = false;
+            desc[lane * KS + j] = make_uint2(pad, colour);
+        }
+        const int state_l = (exists ? 1 : 0) | (all_valid ? 2 : 0);
+        const int rem_l = (int)rem;
+        col += dq; rem += dr;
+        if (rem >= (unsigned)Hc) { rem -= (unsigned)Hc; col += 1; }
+        __builtin_amdgcn_wave_barrier();                                     // (the lanes of a wavefront exchange through LDS: no reordering across)
+        const unsigned long long dstep = (unsigned long long)G * 64;
+        u32x4* dst = out4 + base * 64;                                       // wave-uniform
+#pragma unroll 2
+        for (int t = 0; t < 64; ++t, dst += dstep) {
+            const int s_state = __builtin_amdgcn_readlane(state_l, t);
+            if (!(s_state & 1)) continue;                                    // wave-uniform: past the end
+            const int p0 = __builtin_amdgcn_readlane(rem_l, t) + 4 * lane;   // flat offset from the start of the chunk's first column
+            const int rel = fast_div(p0, Hc, inv_hc), r = p0 - rel * Hc;
+            const uint2 d0 = desc[t * KS + rel];
+            const int pad0 = (int)(d0.x & 0x7FFFFFFFu);
+            u32x4 v;
+            bool ok[4];
+            if (ALIGNED) {
+                v.x = pixel(r + 0, pad0, Hc, d0.y, ceil_c, floor_c);
+                v.y = pixel(r + 1, pad0, Hc, d0.y, ceil_c, floor_c);
+                v.z = pixel(r + 2, pad0, Hc, d0.y, ceil_c, floor_c);
+                v.w = pixel(r + 3, pad0, Hc, d0.y, ceil_c, floor_c);
+                ok[0] = ok[1] = ok[2] = ok[3] = (d0.x >> 31) != 0u;
+            } else {
+                const uint2 d1 = desc[t * KS + rel + 1];
+                const int pad1 = (int)(d1.x & 0x7FFFFFFFu);
+                uint32_t px[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool next = r + e >= Hc;                           // this pixel is in the following column
+                    px[e] = pixel(next ? r + e - Hc : r + e, next ? pad1 : pad0, Hc, next ? d1.y : d0.y, ceil_c, floor_c);
+                    ok[e] = ((next ? d1.x : d0.x) >> 31) != 0u;
+                }
+                v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
+            }
+            if (s_state & 2) {
+                __builtin_nontemporal_store(v, dst + lane);
+            } else {                                                         // a masked agent's border / the batch's last chunk
+                const unsigned long long px0 = ((base + (unsigned long long)t * G) << 8) + 4u * (unsigned)lane;
+                uint32_t* const o = out + px0;
+                if (px0 + 0 < total_px && ok[0]) o[0] = v.x;
+                if (px0 + 1 < total_px && ok[1]) o[1] = v.y;
+                if (px0 + 2 < total_px && ok[2]) o[2] = v.z;
+                if (px0 + 3 < total_px && ok[3]) o[3] = v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1078,7 +1203,7 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
         const int vpc = Ht >> 2;
         const int wpc = top_col_bits(p) >> 5;                               // plane words per (padded) column
         const int step = kTopGroup / 64;                                    // columns between two of this wavefront's
-        const int ncols = (c_hi - c_lo - wave + step - 1) / step;           // wave-uniform trip count
+        [[maybe_unused]] const int ncols = (c_hi - c_lo - wave + step - 1) / step;           // wave-uniform trip count (development path below)
         auto overlay = [](uint32_t bits, int e, uint32_t colour, uint32_t under) {
             const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, e, 1);   // 0 or ~0
             return (m & colour) | (~m & under);                             // v_bfi_b32
@@ -1096,10 +1221,12 @@ __device__ __forceinline__ void top_store(const RcwDev& p, int a, const TopBuf& 
             int jp0 = wave;                                                  // this wavefront's columns: wave, wave + 4, ...
             const uint32_t* lp = b.line + jp0 * wpc + (ip0 >> 5);
             u32x4* dst = out + (size_t)jp0 * vpc + (ip0 >> 2);
+#ifdef RCW_DEV_SWITCHES
             if (p.top_debug & 8) {      // development: the bare store stream of this path (no pixel logic, no LDS reads)
                 for (int c = 0; c < ncols; ++c) { const u32x4 o = {grid_c, grid_c, grid_c, grid_c}; if (active) *dst = o; dst += dstep; }
                 continue;
             }
+#endif
             // Tile columns outermost: step = 4 divides pu, so every tile column holds cpt = pu / 4 of this wavefront's
             // columns, the tile's colour is read once (the next tile's byte is already on its way), and a frame
             // column (SR:366-367) can only be the first one (wavefront 0) or the last one (wavefront 3) of a tile.
@@ -1242,7 +1369,10 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
                 top_prepare(p, a, b, tid);
                 prepared += 1;
                 lds_signal(c_prepared); lds_wait(c_prepared, 4 * prepared);  // planes cleared by all four wavefronts
-                if (!(p.top_debug & 1)) top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
+#ifdef RCW_DEV_SWITCHES
+                if (!(p.top_debug & 1))
+#endif
+                top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid);
             }
             lds_signal(c_drawn);
         }
@@ -1251,7 +1381,10 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
             const int a = blockIdx.x + q * G;
             const bool on = mask == nullptr || mask[a] != 0;
             lds_wait(c_drawn, 4 * (q + 1));
-            if (on && !(p.top_debug & 2)) top_store(p, a, top_buf(p, bufs + (size_t)(q % K) * bw), tid);
+#ifdef RCW_DEV_SWITCHES
+            if (p.top_debug & 2) { lds_signal(c_stored); continue; }
+#endif
+            if (on) top_store(p, a, top_buf(p, bufs + (size_t)(q % K) * bw), tid);
             lds_signal(c_stored);
         }
     }
@@ -1284,6 +1417,39 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
     top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid, false, group);
     __syncthreads();
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu;
+    if (tid == 0) p.top_hdr[a] = make_int2(b.hdr[0], b.hdr[1]);
+    if (p.top_flat) {
+        // rcw_top_store_flat_kernel's plane: the bit of agent pixel q = (j-1)·Ht + (i-1) sits at bit s + q of the agent's
+        // region of p.top_plane_words words, s = (a · Ht·Wt) mod 256 — where the agent's image starts inside its first
+        // 256-pixel chunk of the flat batch — so a chunk's plane bits are 8 whole words of the region, and the bits
+        // that belong to the neighbouring agents' pixels (in front of s, behind the image) are zero: a chunk that
+        // straddles two agents ORs the two regions' words.  An image column is at least 42 rows here, so a word holds
+        // bits of at most two columns.
+        const unsigned px_agent = (unsigned)Ht * (unsigned)Wt;
+        const int s_a = (int)(((unsigned long long)a * px_agent) & 255ull);
+        const unsigned cb = (unsigned)top_col_bits(p), PW = (unsigned)p.top_plane_words;
+        uint32_t* const out = p.top_plane + (size_t)a * PW;
+        for (unsigned w = tid; w < PW; w += group) {
+            const int q_start = (int)(32u * w) - s_a;                        // the agent pixel of the word's bit 0
+            uint32_t word = 0u;
+            if (q_start > -32 && q_start < (int)px_agent) {
+                const int lead = q_start < 0 ? -q_start : 0;
+                const unsigned q = (unsigned)(q_start + lead);
+                const unsigned j = q / (unsigned)Ht, i = q - j * (unsigned)Ht;
+                const unsigned A = j * cb + i;
+                const unsigned long long two = (unsigned long long)b.line[A >> 5] | ((unsigned long long)b.line[(A >> 5) + 1] << 32);
+                uint32_t bits = (uint32_t)(two >> (A & 31u));
+                const unsigned n1 = (unsigned)Ht - i;                        // bits left in column j
+                if (n1 < 32u) {
+                    bits &= (1u << n1) - 1u;
+                    if (j + 1 < (unsigned)Wt) bits |= b.line[((j + 1) * cb) >> 5] << n1;
+                }
+                word = bits << lead;
+            }
+            out[w] = word;
+        }
+        return;
+    }
     const int wpc = top_col_bits(p) >> 5, wpu = Ht >> 5, k = Ht / p.top_unit_px, tpc = p.top_unit_px / pu;   // (unit: 256 rows, or 128 / 64: rcw_top_store_units_kernel)
     uint32_t* const out = p.top_plane + (size_t)a * Wt * wpu;
     const int total = Wt * wpu, qstep = group / wpu, rstep = group - qstep * wpu;
@@ -1293,7 +1459,6 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
         j += qstep; w += rstep;
         if (w >= wpu) { w -= wpu; j += 1; }
     }
-    if (tid == 0) p.top_hdr[a] = make_int2(b.hdr[0], b.hdr[1]);
     for (int e = tid; e < p.W * k; e += group) {
         const int tj = e / k, rb = e - tj * k;
         const uint8_t* const tiles = b.tb + rb * tpc + p.H * tj;
@@ -1612,6 +1777,186 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
     }
 }
 
+
+// The moving-window store for ANY pixel scale from 9 pixels a tile and any image of at least 42 rows whose height is a
+// multiple of 4 (pu_per_tu and the map size are free kwargs, SR:260-261, SR:269): a chunk is 256 consecutive pixels of
+// the flat (H·pu, W·pu, B) batch, whatever image columns — of one agent or two — they belong to, so every wavefront
+// store is an aligned 1 KiB.  As in rcw_fill_flat_kernel, lane l of the prefetch finds (first column, row in it) of
+// the wavefront's l-th next chunk and parks one 16-byte descriptor per touched column in wave-private LDS:
+//   x: bit 31 valid | 30 frame column (SR:366-367) | 29 a column of the player's circle | 28..16 its distance from the
+//      player's column | 15..0 the tile row of the code window's first tile
+//   y, z: the 2-bit tile_map entries (bit 0 WALL, bit 1 GOAL: BitArray{3}(2, H, W) read as it lies in HBM, SR:54) of
+//      the 32 tiles of this image column from that tile row on — more than a 256-row run can touch from 9 pixels a tile
+//   w: the image row of the circle mask's bit 0 (ip - 1 - rp)
+// In the chunk loop a lane finds its column (flat offset / H·pu) and tile row (row / pu) with Float32 reciprocals,
+// reads its column's descriptor with one ds_read_b128 and its plane word, resolves circle > ray line > tile frame >
+// tile fill (SR:362-367, SR:473-477, SR:480) for its four pixels and writes them with one 16-byte store.  STRADDLE
+// (pu % 4 != 0): the four pixels may lie in two tiles.  The circle of any radius: SD.Circle's rows at column distance c
+// are the same for every agent (midpoint circle, assumed); the workgroup tabulates them in LDS once, as bit rows.
+template <bool PLAIN, bool STRADDLE>
+__global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev p, const uint8_t* __restrict__ mask,
+                                                                    uint32_t chunk_begin, uint32_t chunk_end,
+                                                                    int agent_lo, int agent_hi, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t G = gridDim.x * (kBlock / 64);
+    const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp, KS = K;
+    const float inv_ht = 1.0f / (float)Ht, inv_pu = 1.0f / (float)pu;
+    const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
+    const unsigned px_agent = (unsigned)Ht * (unsigned)Wt;
+    const unsigned long long total_px = (unsigned long long)p.B * px_agent;
+    const unsigned PW = (unsigned)p.top_plane_words;
+    // LDS: [4 wavefronts][512 plane words] | [4 wavefronts][64 chunks][KS] descriptors | the circle's bit rows
+    uint32_t* const lw = lds + wave * 512;
+    uint32_t* const lw_write = lw + lane;
+    const uint32_t* const lw_read = lw + (lane >> 3);
+    uint4* const desc = reinterpret_cast<uint4*>(lds + (kBlock / 64) * 512) + (size_t)wave * 64 * KS;
+    uint32_t* const ctab = lds + (kBlock / 64) * 512 + (size_t)(kBlock / 64) * 64 * KS * 4;
+    const int cnw = (2 * rp + 1 + 31) / 32, cwt = cnw + 2;                 // a row: [zero word | 2 rp + 1 mask bits | zero word]
+    for (int k = threadIdx.x; k < (rp + 1) * cwt; k += kBlock) ctab[k] = 0u;
+    __syncthreads();
+    for (int c = threadIdx.x; c <= rp; c += kBlock) {                      // SD.Circle SR:480 (midpoint circle, assumed)
+        uint32_t* const row = ctab + c * cwt + 1;
+        auto set = [&](int off) { const int q = rp + off; row[q >> 5] |= 1u << (q & 31); };
+        int x = 0, y = rp, dd = 1 - rp;
+        while (x <= y) {
+            if (y == c) { set(x); set(-x); }
+            if (x == c) { set(y); set(-y); }
+            x += 1;
+            if (dd < 0) dd += 2 * x + 1;
+            else { y -= 1; dd += 2 * (x - y) + 1; }
+        }
+    }
+    __syncthreads();
+    // this lane's chunk of the first group as (image column of the flat batch, row in it); every group moves all lanes alike
+    const unsigned long long id0 = (unsigned long long)chunk_begin + g + (unsigned long long)lane * G;
+    const unsigned long long step_px = (unsigned long long)G * 64 * 256;
+    const uint32_t dq = (uint32_t)(step_px / (unsigned)Ht), dr = (uint32_t)(step_px - (unsigned long long)dq * (unsigned)Ht);
+    uint32_t col = (uint32_t)((id0 * 256) / (unsigned)Ht);
+    uint32_t rem = (uint32_t)(id0 * 256 - (unsigned long long)col * (unsigned)Ht);
+    u32x4* const out4 = reinterpret_cast<u32x4*>(p.top_view);
+    const size_t dstep = (size_t)G * 64;
+    for (uint32_t base = chunk_begin + g; base < chunk_end; base += G * 64) {
+        const uint32_t id = base + (uint32_t)lane * G;
+        const bool exists = id < chunk_end;
+        const int touched = exists ? fast_div((int)rem + 255, Ht, inv_ht) : -1;      // the chunk's last column, relative
+        const uint32_t a0 = col / (unsigned)Wt, j0 = col - a0 * (unsigned)Wt;
+        const int ti_first = fast_div((int)rem, pu, inv_pu);                         // tile row of the chunk's first pixel
+        // ---- loads (all issued before any is used) ----
+        int2 hd[kFlatMaxCols];
+        uint32_t tw[kFlatMaxCols][3], mk[kFlatMaxCols];
+        uint32_t aa[kFlatMaxCols], jj[kFlatMaxCols];
+#pragma unroll
+        for (int j = 0; j < kFlatMaxCols; ++j) {
+            uint32_t jx = j0 + (unsigned)j, a = a0;
+            if (jx >= (unsigned)Wt) { jx -= (unsigned)Wt; a += 1; }
+            aa[j] = a; jj[j] = jx;
+            const bool in = j <= touched && (int)a >= agent_lo && (int)a < agent_hi;
+            const int tj = fast_div((int)jx, pu, inv_pu);
+            const int t0 = p.H * tj + (j == 0 ? ti_first : 0);                       // first tile of the code window (linear, 0-based)
+            const int wi = t0 >> 4;
+            const uint32_t* const tm = p.tile_map + (size_t)(in ? a : 0u) * p.nwords;
+            mk[j] = in ? (mask != nullptr ? (uint32_t)mask[a] : 1u) : 0u;
+            hd[j] = in ? p.top_hdr[a] : make_int2(0, 0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tw[j][k] = (in && wi + k < p.nwords) ? tm[wi + k] : 0u;
+        }
+        // the chunk's 8 plane words, of the first pixel's agent and (a chunk that straddles two agents) of the last pixel's
+        int woff_a = -1, woff_b = -1;
+        if (exists) {
+            const uint32_t a_last = touched >= 0 ? aa[0] + ((j0 + (unsigned)touched >= (unsigned)Wt) ? 1u : 0u) : a0;
+            if (a0 < (unsigned)p.B) woff_a = (int)(a0 * PW + (id - (uint32_t)(((unsigned long long)a0 * px_agent) >> 8)) * 8u);
+            if (a_last != a0 && a_last < (unsigned)p.B) woff_b = (int)(a_last * PW);
+        }
+        uint32_t pw[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int wa = __shfl(woff_a, 8 * m + (lane >> 3), 64), wb = __shfl(woff_b, 8 * m + (lane >> 3), 64);
+            const uint32_t x = wa >= 0 ? p.top_plane[(size_t)wa + (lane & 7)] : 0u;
+            const uint32_t y = wb >= 0 ? p.top_plane[(size_t)wb + (lane & 7)] : 0u;
+            pw[m] = x | y;
+        }
+        // ---- descriptors ----
+        bool all_valid = exists && ((unsigned long long)id + 1) * 256 <= total_px, any_circle = false;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < kFlatMaxCols; ++j) {
+            if (j >= KS) break;                                              // wave-uniform
+            const bool valid = mk[j] != 0u;
+            if (j <= touched && !valid) all_valid = false;
+            const int tj = fast_div((int)jj[j], pu, inv_pu), rj = (int)jj[j] - tj * pu;
+            const int ti_lo = j == 0 ? ti_first : 0;
+            const int sh = ((p.H * tj + ti_lo) & 15) * 2;
+            const uint32_t lo = (uint32_t)((((unsigned long long)tw[j][1] << 32) | tw[j][0]) >> sh);
+            const uint32_t hi = (uint32_t)((((unsigned long long)tw[j][2] << 32) | tw[j][1]) >> sh);
+            const int dist = abs((int)jj[j] + 1 - hd[j].y), r0 = hd[j].x - 1 - rp;
+            const bool circle = valid && dist <= rp;
+            any_circle = any_circle || circle;
+            const uint32_t x = (valid ? 0x80000000u : 0u) | ((rj == 0 || rj == pu - 1) ? 0x40000000u : 0u) |
+                               (circle ? 0x20000000u : 0u) | ((uint32_t)(circle ? dist : 0) << 16) | (uint32_t)ti_lo;
+            desc[lane * KS + j] = make_uint4(x, lo, hi, (uint32_t)r0);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) lw_write[64 * m] = pw[m];
+        const int state_l = (exists ? 1 : 0) | (all_valid ? 2 : 0) | (any_circle ? 4 : 0);
+        const int rem_l = (int)rem;
+        col += dq; rem += dr;
+        if (rem >= (unsigned)Ht) { rem -= (unsigned)Ht; col += 1; }
+        __builtin_amdgcn_wave_barrier();
+        u32x4* dst = out4 + (size_t)base * 64;                               // wave-uniform
+#pragma unroll 2
+        for (int t = 0; t < 64; ++t, dst += dstep) {
+            const int s_state = __builtin_amdgcn_readlane(state_l, t);
+            if (!(s_state & 1)) continue;                                    // wave-uniform: past the end
+            const int p0 = __builtin_amdgcn_readlane(rem_l, t) + 4 * lane;   // flat offset from the start of the chunk's first column
+            const int rel = fast_div(p0, Ht, inv_ht), r = p0 - rel * Ht;
+            const uint4 d = desc[t * KS + rel];
+            const uint32_t w = lw_read[8 * t];
+            const int ti = fast_div(r, pu, inv_pu), ri = r - ti * pu;
+            const int trel = ti - (int)(d.x & 0xFFFFu);
+            const uint32_t c4 = (uint32_t)((((unsigned long long)d.z << 32) | d.y) >> (2 * trel));   // this tile's 2 bits, then the next one's
+            const uint32_t fill0 = bfi(bit_to_mask(c4, 0), 0x00FFFFFFu, bit_to_mask(c4, 1) & 0x00FF0000u);   // wall before goal SR:355-360, colours SR:288
+            u32x4 o;
+            if (STRADDLE) {
+                const uint32_t fill1 = bfi(bit_to_mask(c4, 2), 0x00FFFFFFu, bit_to_mask(c4, 3) & 0x00FF0000u);
+                uint32_t px[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool next = ri + e >= pu;                          // this pixel is in the following tile
+                    const int rie = next ? ri + e - pu : ri + e;
+                    px[e] = (rie == 0 || rie == pu - 1) ? grid_c : (next ? fill1 : fill0);   // SR:364-365
+                }
+                o.x = px[0]; o.y = px[1]; o.z = px[2]; o.w = px[3];
+            } else {
+                o.x = ri == 0 ? grid_c : fill0;                              // SR:364-365: the tile's frame rows
+                o.y = fill0; o.z = fill0;
+                o.w = ri + 3 == pu - 1 ? grid_c : fill0;
+            }
+            const uint32_t frame = bit_to_mask(d.x, 30);                     // SR:366-367: the tile's frame columns
+            o.x = bfi(frame, grid_c, o.x); o.y = bfi(frame, grid_c, o.y); o.z = bfi(frame, grid_c, o.z); o.w = bfi(frame, grid_c, o.w);
+            const uint32_t sh = (uint32_t)(4 * lane) & 31u;
+            o.x = bfi(bit_to_mask(w, sh), ray_c, o.x);     o.y = bfi(bit_to_mask(w, sh + 1), ray_c, o.y);
+            o.z = bfi(bit_to_mask(w, sh + 2), ray_c, o.z); o.w = bfi(bit_to_mask(w, sh + 3), ray_c, o.w);
+            if (s_state & 4) {                                               // some column of the chunk crosses the player's circle
+                const int q0 = r - (int)d.w;                                 // mask bit of this lane's first pixel
+                if ((d.x & 0x20000000u) && q0 > -4 && q0 <= 2 * rp) {
+                    const int bidx = q0 + 32;                                // (the row's leading zero word absorbs q0 < 0)
+                    const uint32_t* const row = ctab + ((d.x >> 16) & 0x1FFFu) * cwt + (bidx >> 5);
+                    const uint32_t cb = (uint32_t)((((unsigned long long)row[1] << 32) | row[0]) >> (bidx & 31));
+                    o.x = bfi(bit_to_mask(cb, 0), player_c, o.x); o.y = bfi(bit_to_mask(cb, 1), player_c, o.y);
+                    o.z = bfi(bit_to_mask(cb, 2), player_c, o.z); o.w = bfi(bit_to_mask(cb, 3), player_c, o.w);
+                }
+            }
+            if (s_state & 2) store16<PLAIN>(dst + lane, o);                  // every pixel of the chunk is written
+            else if ((d.x >> 31) && (((unsigned long long)(base + (uint32_t)t * G)) << 8) + 4u * (unsigned)lane < total_px)
+                store16<PLAIN>(dst + lane, o);                               // a chunk at a masked agent's / a run's border, the batch's last chunk
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -1622,45 +1967,80 @@ size_t rcw_step_lds_bytes(const RcwDev& p)
 // the cast kernel's LDS: the tile bytes (+ the heading's table slice under the RCW_CAST_TABLE=lds development switch)
 static size_t rcw_cast_lds_bytes(const RcwDev& p)
 {
-    return rcw_step_lds_bytes(p) + (p.cast_table_lds ? (size_t)RCW_TABLE_ROWS * p.N * (p.real64 ? 8 : 4) : 0);
+#ifdef RCW_DEV_SWITCHES
+    if (p.cast_table_lds) return rcw_step_lds_bytes(p) + (size_t)RCW_TABLE_ROWS * p.N * (p.real64 ? 8 : 4);
+#endif
+    return rcw_step_lds_bytes(p);
+}
+
+// rcw_fill_flat_kernel: the image columns a 256-pixel chunk can touch at this camera height; 0: the kernel does not take it
+int rcw_fill_flat_cols(const RcwDev& p)
+{
+    const int K = 254 / p.Hc + 2;
+    return K <= kFlatMaxCols ? K : 0;
+}
+
+// which kernel fills the frames of this geometry
+enum FillKernel { kFill256, kFillWindow1, kFillWindow2, kFillWindow4, kFillFlat, kFillFrame, kFillAny };
+static FillKernel fill_choice(const RcwDev& p, long long total_cols)
+{
+    if (p.Hc == 256) return kFill256;
+    if ((p.Hc & 255) == 0) return kFillWindow1;                             // a 1 KiB chunk is a row block of one column
+    if ((p.Hc == 128 || p.Hc == 64) && ((long long)p.N * p.Hc) % 256 == 0 && !p.fill_flat) return p.Hc == 128 ? kFillWindow2 : kFillWindow4;   // 2 / 4 whole columns
+    if (rcw_fill_flat_cols(p) && total_cols < (1ll << 31) - 16) return kFillFlat;   // any other height of at least 37 rows
+    if (p.N <= 8192 && (long long)p.N * p.Hc < (1ll << 25)) return kFillFrame;
+    return kFillAny;
+}
+const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols)
+{
+    switch (fill_choice(p, total_cols)) {
+    case kFill256: return "rcw_fill256_kernel";
+    case kFillWindow1: case kFillWindow2: case kFillWindow4: return "rcw_fill_window_kernel";
+    case kFillFlat: return "rcw_fill_flat_kernel";
+    case kFillFrame: return "rcw_fill_frame_kernel";
+    default: return "rcw_fill_any_kernel";
+    }
 }
 
 hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
                            long long total_cols, const uint8_t* mask_dev, hipStream_t s)
 {
     const int grid = p.fill_grid;
-    if (p.Hc == 256) {
-        if (p.fill_plain)
-            hipLaunchKernelGGL(rcw_fill256_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
-                               reinterpret_cast<u32x4*>(frames), total_cols, mask_dev);
-        else
-            hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
-                               reinterpret_cast<u32x4*>(frames), total_cols, mask_dev);
-    } else if ((p.Hc & 255) == 0 || ((p.Hc == 128 || p.Hc == 64) && ((long long)p.N * p.Hc) % 256 == 0)) {
-        // the moving window again: 1 KiB chunks that are a row block of one column, or 2 / 4 whole columns
-        const long long chunks = total_cols * p.Hc / 256;
-        if ((p.Hc & 255) == 0)
-            hipLaunchKernelGGL(rcw_fill_window_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
-                               reinterpret_cast<u32x4*>(frames), chunks, mask_dev);
-        else if (p.Hc == 128)
-            hipLaunchKernelGGL(rcw_fill_window_kernel<2>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
-                               reinterpret_cast<u32x4*>(frames), chunks, mask_dev);
-        else
-            hipLaunchKernelGGL(rcw_fill_window_kernel<4>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c,
-                               reinterpret_cast<u32x4*>(frames), chunks, mask_dev);
-    } else if (p.N <= 8192 && (long long)p.N * p.Hc < (1ll << 25)) {
+    const long long chunks = total_cols * p.Hc / 256;
+    u32x4* const frames4 = reinterpret_cast<u32x4*>(frames);
+    switch (fill_choice(p, total_cols)) {
+    case kFill256:
+        if (p.fill_plain) hipLaunchKernelGGL(rcw_fill256_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
+        else              hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
+        break;
+    case kFillWindow1:
+        hipLaunchKernelGGL(rcw_fill_window_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, chunks, mask_dev);
+        break;
+    case kFillWindow2:
+        hipLaunchKernelGGL(rcw_fill_window_kernel<2>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, chunks, mask_dev);
+        break;
+    case kFillWindow4:
+        hipLaunchKernelGGL(rcw_fill_window_kernel<4>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, chunks, mask_dev);
+        break;
+    case kFillFlat: {
+        // the moving window over 256-pixel chunks of the flat batch
+        const int K = rcw_fill_flat_cols(p);
+        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint2);
+        if ((p.Hc & 3) == 0) hipLaunchKernelGGL(rcw_fill_flat_kernel<true>, dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev, K);
+        else                 hipLaunchKernelGGL(rcw_fill_flat_kernel<false>, dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev, K);
+        break;
+    }
+    case kFillFrame: {
         const int agents = (int)(total_cols / p.N);
         const size_t lds = (size_t)p.N * 8;
-        if ((p.Hc & 3) == 0)
-            hipLaunchKernelGGL(rcw_fill_frame_kernel<true>, dim3(agents), dim3(kBlock), lds, s, p, col_h, col_c, frames, mask_dev);
-        else
-            hipLaunchKernelGGL(rcw_fill_frame_kernel<false>, dim3(agents), dim3(kBlock), lds, s, p, col_h, col_c, frames, mask_dev);
-    } else if ((p.Hc & 3) == 0) {
-        hipLaunchKernelGGL(rcw_fill_any_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames,
-                           total_cols, mask_dev);
-    } else {
-        hipLaunchKernelGGL(rcw_fill_any_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames,
-                           total_cols, mask_dev);
+        if ((p.Hc & 3) == 0) hipLaunchKernelGGL(rcw_fill_frame_kernel<true>, dim3(agents), dim3(kBlock), lds, s, p, col_h, col_c, frames, mask_dev);
+        else                 hipLaunchKernelGGL(rcw_fill_frame_kernel<false>, dim3(agents), dim3(kBlock), lds, s, p, col_h, col_c, frames, mask_dev);
+        break;
+    }
+    default:
+        if ((p.Hc & 3) == 0) hipLaunchKernelGGL(rcw_fill_any_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames, total_cols, mask_dev);
+        else                 hipLaunchKernelGGL(rcw_fill_any_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames, total_cols, mask_dev);
+        break;
     }
     return hipGetLastError();
 }
@@ -1722,8 +2102,38 @@ int rcw_top_split_unit(const RcwDev& p)
     if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31) - 64) return 0;                                               // plane word offsets
     return 4 * top_buf_words(p) <= 156 * 1024 ? unit : 0;
 }
-size_t rcw_top_plane_bytes(const RcwDev& p) { return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4 + 64; }   // (+ a short last chunk's reach)
-size_t rcw_top_codes_bytes(const RcwDev& p) { return (size_t)p.B * p.W * ((size_t)p.H * p.pu / p.top_unit_px) * sizeof(uint2); }
+// rcw_top_store_flat_kernel: the image columns a 256-pixel chunk can touch in this geometry; 0: the kernel does not take it
+static size_t top_circle_table_bytes(const RcwDev& p) { return (size_t)(p.top_rp + 1) * ((2 * p.top_rp + 1 + 31) / 32 + 2) * 4; }
+static size_t top_flat_plane_words(const RcwDev& p) { return (((size_t)p.H * p.pu * p.W * p.pu + 255 + 255) / 256) * 8; }
+int rcw_top_flat_cols(const RcwDev& p)
+{
+    const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
+    if (p.pu < 9 || (Ht & 3) != 0 || Ht > 16384 || Wt > 16384 || p.H > 65535 || p.top_rp > 8191) return 0;
+    const int K = (int)(251 / Ht) + 2;
+    if (K > kFlatMaxCols) return 0;
+    if (top_circle_table_bytes(p) > 16 * 1024) return 0;
+    if (4 * top_buf_words(p) > 156 * 1024) return 0;                                          // the draw kernel's LDS plane
+    const long long chunks = ((long long)p.B * Ht * Wt + 255) / 256;
+    if ((long long)p.B * Wt >= (1ll << 31) - 64) return 0;                                    // image columns of the flat batch in 32 bits
+    if (chunks + 64ll * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;            // chunk ids
+    if ((long long)p.B * (long long)top_flat_plane_words(p) >= (1ll << 31) - 64) return 0;    // plane word offsets
+    return K;
+}
+size_t rcw_top_plane_bytes(const RcwDev& p)
+{
+    if (p.top_flat) return (size_t)p.B * top_flat_plane_words(p) * 4 + 64;
+    return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4 + 64;                     // (+ a short last chunk's reach)
+}
+int32_t rcw_top_plane_words(const RcwDev& p) { return (int32_t)top_flat_plane_words(p); }
+static size_t top_store_flat_lds_bytes(const RcwDev& p)
+{
+    return (size_t)(kBlock / 64) * 512 * 4 + (size_t)(kBlock / 64) * 64 * p.top_flat * 16 + top_circle_table_bytes(p);
+}
+size_t rcw_top_codes_bytes(const RcwDev& p)
+{
+    if (p.top_flat) return 64;                                              // (the flat store kernel reads tile_map itself)
+    return (size_t)p.B * p.W * ((size_t)p.H * p.pu / p.top_unit_px) * sizeof(uint2);
+}
 
 // agents [first, first + count): the draw kernel's workgroups / the store kernel's chunks of that run (an image is a
 // whole number of 1 KiB chunks in every geometry rcw_top_split_unit takes)
@@ -1735,6 +2145,18 @@ hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int fir
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
 {
     const dim3 grid(p.top_store_grid), block(kBlock);
+    if (p.top_flat) {
+        // the chunks of the flat batch that hold a pixel of agents [first, first + count)
+        const unsigned long long px = (unsigned long long)p.H * p.pu * p.W * p.pu;
+        const uint32_t c0 = (uint32_t)((px * (unsigned)first) >> 8), c1 = (uint32_t)((px * (unsigned)(first + count) + 255) >> 8);
+        const size_t lds = top_store_flat_lds_bytes(p);
+        const bool straddle = (p.pu & 3) != 0;
+#define RCW_FLAT(PL, ST) hipLaunchKernelGGL((rcw_top_store_flat_kernel<PL, ST>), grid, block, lds, s, p, mask_dev, c0, c1, first, first + count, p.top_flat)
+        if (p.top_store_plain) { if (straddle) RCW_FLAT(true, true); else RCW_FLAT(true, false); }
+        else                   { if (straddle) RCW_FLAT(false, true); else RCW_FLAT(false, false); }
+#undef RCW_FLAT
+        return hipGetLastError();
+    }
     const uint32_t per_agent = (uint32_t)(((long long)p.H * p.pu * p.W * p.pu) >> 8);
     const uint32_t c0 = (uint32_t)first * per_agent, c1 = (uint32_t)(first + count) * per_agent;
     if (p.top_unit_px == 128) {
@@ -1756,22 +2178,30 @@ hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int fi
     return hipGetLastError();
 }
 
-// Above 64 KiB of dynamic LDS a kernel has to be told so once (the CU has 160 KiB).
-hipError_t rcw_prepare_top_view(const RcwDev& p)
+// Above 64 KiB of dynamic LDS a kernel has to be told so once (the CU has 160 KiB).  The attribute belongs to the
+// FUNCTION, i.e. to every handle on the device: it is set once per device, to the fixed cap the geometry selection
+// works with (16 B + 156 KiB for the ring kernel, 156 KiB for the draw kernel), never to one handle's own need — a
+// second handle with a smaller image must not lower the limit under a first one's feet.
+hipError_t rcw_prepare_top_view(const RcwDev& p, int device)
 {
-    const size_t need = rcw_top_view_lds_bytes(p);
-    if (!p.top_lds || need <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static bool done[64] = {};
+    if (!p.top_view) return hipSuccess;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && device < 64 && done[device]) return hipSuccess;
+    const int cap = 160 * 1024;
     hipError_t e = hipSuccess;
 #define RCW_TOP_ATTR(TT, A, B_)                                                                                         \
     if (e == hipSuccess)                                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rcw_top_view_kernel<TT, A, B_>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);                                \
-    if (e == hipSuccess && p.top_split)                                                                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cap);                                      \
+    if (e == hipSuccess)                                                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rcw_top_draw_kernel<TT, A, B_>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * top_buf_words(p)))
-    if (p.real64) { RCW_TOP_ATTR(double, false, false); RCW_TOP_ATTR(double, false, true); RCW_TOP_ATTR(double, true, false); RCW_TOP_ATTR(double, true, true); }
-    else          { RCW_TOP_ATTR(float, false, false); RCW_TOP_ATTR(float, false, true); RCW_TOP_ATTR(float, true, false); RCW_TOP_ATTR(float, true, true); }
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cap)
+    RCW_TOP_ATTR(double, false, false); RCW_TOP_ATTR(double, false, true); RCW_TOP_ATTR(double, true, false); RCW_TOP_ATTR(double, true, true);
+    RCW_TOP_ATTR(float, false, false); RCW_TOP_ATTR(float, false, true); RCW_TOP_ATTR(float, true, false); RCW_TOP_ATTR(float, true, true);
 #undef RCW_TOP_ATTR
+    if (e == hipSuccess && device >= 0 && device < 64) done[device] = true;
     return e;
 }
 

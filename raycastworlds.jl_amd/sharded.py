@@ -184,7 +184,7 @@ class ShardedSingleRoom:
         lib = self.env._lib
         uid = (C.c_uint8 * _capi.RCW_UNIQUE_ID_BYTES)()
         if self.rank == 0:
-            _capi.check(lib.rcw_comm_unique_id(uid))
+            self.env._check(lib.rcw_comm_unique_id(uid))
         if self.world > 1:
             t = torch.tensor(list(uid), dtype=torch.uint8)
             backend = self._dist.get_backend(self.group)
@@ -192,7 +192,7 @@ class ShardedSingleRoom:
                 t = t.cuda(self.env.device)
             self._dist.broadcast(t, src=0, group=self.group)
             uid = (C.c_uint8 * _capi.RCW_UNIQUE_ID_BYTES)(*t.cpu().tolist())
-        _capi.check(lib.rcw_comm_init(self.env._h, uid, self.rank, self.world))
+        self.env._check(lib.rcw_comm_init(self.env._h, uid, self.rank, self.world))
         self._abi_comm = True
 
     def gather_columns_abi(self):
@@ -208,7 +208,7 @@ class ShardedSingleRoom:
         cross = env._order_behind_torch()
         from . import _capi
 
-        _capi.check(env._lib.rcw_gather_columns(env._h, C.c_void_p(gh.data_ptr()), C.c_void_p(gc.data_ptr())))
+        env._check(env._lib.rcw_gather_columns(env._h, C.c_void_p(gh.data_ptr()), C.c_void_p(gc.data_ptr())))
         if cross:
             env._release_after_use(gh, gc)
         return gh, gc
@@ -229,7 +229,7 @@ class ShardedSingleRoom:
             out = torch.empty((self.global_batch, env.cfg.num_rays, env.cfg.height_camera_view_pu), dtype=torch.uint32,
                               device=f"cuda:{env.device}")
         cross = env._order_behind_torch()
-        _capi.check(env._lib.rcw_gather_observations(env._h, modes[mode], C.c_void_p(out.data_ptr())))
+        env._check(env._lib.rcw_gather_observations(env._h, modes[mode], C.c_void_p(out.data_ptr())))
         if cross:
             env._release_after_use(out)
         return out

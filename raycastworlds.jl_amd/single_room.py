@@ -103,7 +103,7 @@ class SingleRoomWorld:
 
     def _get(self, fn, dtype, shape):
         out = np.empty(shape, dtype=dtype)
-        _capi.check(fn(self._env._h, _as_ptr(out)))
+        self._env._check(fn(self._env._h, _as_ptr(out)))
         return out
 
     @property
@@ -165,14 +165,14 @@ class SingleRoomWorld:
     def directions_wu(self) -> np.ndarray:             # SR:28, (nd, 2)
         out = np.empty((self.num_directions, 2), dtype=self._env.T)
         fn = self._env._lib.rcw_direction_table64 if self._env.T is np.float64 else self._env._lib.rcw_direction_table
-        _capi.check(fn(self._env._h, _as_ptr(out)))
+        self._env._check(fn(self._env._h, _as_ptr(out)))
         return out
 
     @property
     def tile_map_chunks(self) -> np.ndarray:
         """BitArray{3}(2, H, W).chunks per agent: uint64 (B, nchunks)  SR:22."""
         n = C.c_int32()
-        _capi.check(self._env._lib.rcw_tile_map_num_chunks(self._env._h, C.byref(n)))
+        self._env._check(self._env._lib.rcw_tile_map_num_chunks(self._env._h, C.byref(n)))
         return self._get(self._env._lib.rcw_tile_map_chunks, np.uint64, (self._env.batch, n.value))
 
     @property
@@ -192,7 +192,7 @@ class SingleRoomWorld:
         dist = np.empty((n, N), dtype=env.T)
         dirs = np.empty((n, N, 2), dtype=env.T)
         fn = env._lib.rcw_rays64 if env.T is np.float64 else env._lib.rcw_rays
-        _capi.check(fn(env._h, first, n, _as_ptr(stop), _as_ptr(dim), _as_ptr(dist), _as_ptr(dirs)))
+        env._check(fn(env._h, first, n, _as_ptr(stop), _as_ptr(dim), _as_ptr(dist), _as_ptr(dirs)))
         return stop, dim, dist, dirs
 
 
@@ -230,6 +230,7 @@ class SingleRoom:
         normalize_mode: int = 0,
         out_of_bounds: int = 0,
         render_top_view: bool = False,
+        library: Optional[str] = None,
     ):
         f32_names = ("Float32", "float32", "<class 'numpy.float32'>")
         f64_names = ("Float64", "float64", "<class 'numpy.float64'>", "<class 'float'>")
@@ -244,8 +245,11 @@ class SingleRoom:
             raise NotImplementedError(f"reward type R = {R!r}: Float32, Float64, Int32 and Int64 are built")
         self.T = np.float64 if str(T) in f64_names else np.float32
         self.R, reward_type = r_names[str(R)]
-        self._lib = _capi.load()
-        cfg = _capi.default_config()
+        # `library`: None = the shipped librcw_hip.so; "dev" (or a path) = the development build, which also reads the
+        # RCW_* tuning knobs and carries the measured-and-rejected kernel variants (csrc/Makefile `dev`)
+        self._lib = _capi.load(library)
+        cfg = _capi.RcwConfig()
+        _capi.check(self._lib.rcw_config_default(C.byref(cfg)), self._lib)
         cfg.height_tile_map_tu = height_tile_map_tu
         cfg.width_tile_map_tu = width_tile_map_tu
         cfg.num_directions = num_directions
@@ -277,7 +281,7 @@ class SingleRoom:
         self.device = int(device)
         self.seed = int(seed)
         self._h = C.c_void_p()
-        _capi.check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
+        self._check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
         self.world = SingleRoomWorld(self)
         self._held = []          # (event, tensors): torch tensors the engine's stream may still be reading
         self._free_events = []
@@ -290,6 +294,9 @@ class SingleRoom:
         self.goal_dim_2_color = cfg.goal_dim_2_color
         self.camera_height_tile_wu = cfg.camera_height_tile_wu
         self.height_camera_view_pu = cfg.height_camera_view_pu
+
+    def _check(self, rc: int) -> None:
+        _capi.check(rc, self._lib)
 
     # ---- lifetime -------------------------------------------------------------------
     def close(self):
@@ -312,7 +319,7 @@ class SingleRoom:
 
     # ---- device views ---------------------------------------------------------------
     def _sync(self):
-        _capi.check(self._lib.rcw_sync(self._h))
+        self._check(self._lib.rcw_sync(self._h))
 
     def sync(self):
         self._sync()
@@ -320,7 +327,7 @@ class SingleRoom:
     def _copy_device_array(self, arr: DeviceArray) -> np.ndarray:
         if arr.ptr == self._obs_ptr():
             out = np.empty(arr.shape, dtype=arr.dtype)
-            _capi.check(self._lib.rcw_obs_copy(self._h, _as_ptr(out), 0, self.batch))
+            self._check(self._lib.rcw_obs_copy(self._h, _as_ptr(out), 0, self.batch))
             return out
         import torch
 
@@ -328,7 +335,7 @@ class SingleRoom:
 
     def _obs_ptr(self) -> int:
         p = C.c_void_p()
-        _capi.check(self._lib.rcw_obs_device_ptr(self._h, C.byref(p)))
+        self._check(self._lib.rcw_obs_device_ptr(self._h, C.byref(p)))
         return int(p.value)
 
     @property
@@ -342,7 +349,7 @@ class SingleRoom:
         """`env.top_view` (SR:302, needs render_top_view=True): uint32 (B, W*pu, H*pu) in C order ==
         Julia (H*pu, W*pu, B)."""
         p = C.c_void_p()
-        _capi.check(self._lib.rcw_top_view_device_ptr(self._h, C.byref(p)))
+        self._check(self._lib.rcw_top_view_device_ptr(self._h, C.byref(p)))
         pu = self.cfg.pu_per_tu
         return DeviceArray(p.value, (self.batch, self.cfg.width_tile_map_tu * pu, self.cfg.height_tile_map_tu * pu),
                            np.uint32, self, self._sync)
@@ -351,13 +358,13 @@ class SingleRoom:
         n = self.batch - first if count is None else count
         pu = self.cfg.pu_per_tu
         out = np.empty((n, self.cfg.width_tile_map_tu * pu, self.cfg.height_tile_map_tu * pu), dtype=np.uint32)
-        _capi.check(self._lib.rcw_top_view_copy(self._h, _as_ptr(out), first, n))
+        self._check(self._lib.rcw_top_view_copy(self._h, _as_ptr(out), first, n))
         return out
 
     def camera_view_host(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         n = self.batch - first if count is None else count
         out = np.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=np.uint32)
-        _capi.check(self._lib.rcw_obs_copy(self._h, _as_ptr(out), first, n))
+        self._check(self._lib.rcw_obs_copy(self._h, _as_ptr(out), first, n))
         return out
 
     def columns(self, first: int = 0, count: Optional[int] = None):
@@ -365,12 +372,12 @@ class SingleRoom:
         n = self.batch - first if count is None else count
         h = np.empty((n, self.cfg.num_rays), dtype=np.int32)
         c = np.empty((n, self.cfg.num_rays), dtype=np.uint8)
-        _capi.check(self._lib.rcw_columns(self._h, first, n, _as_ptr(h), _as_ptr(c)))
+        self._check(self._lib.rcw_columns(self._h, first, n, _as_ptr(h), _as_ptr(c)))
         return h, c
 
     def columns_device(self):
         hp, cp = C.c_void_p(), C.c_void_p()
-        _capi.check(self._lib.rcw_columns_device_ptr(self._h, C.byref(hp), C.byref(cp)))
+        self._check(self._lib.rcw_columns_device_ptr(self._h, C.byref(hp), C.byref(cp)))
         shape = (self.batch, self.cfg.num_rays)
         return (DeviceArray(hp.value, shape, np.int32, self, self._sync),
                 DeviceArray(cp.value, shape, np.uint8, self, self._sync))
@@ -393,7 +400,7 @@ class SingleRoom:
             out = torch.empty((n, self.cfg.num_rays, self.cfg.height_camera_view_pu), dtype=torch.uint32,
                               device=f"cuda:{self.device}")
         cross = self._order_behind_torch()
-        _capi.check(self._lib.rcw_expand_columns(self._h, C.c_void_p(h.data_ptr()), C.c_void_p(c.data_ptr()), n,
+        self._check(self._lib.rcw_expand_columns(self._h, C.c_void_p(h.data_ptr()), C.c_void_p(c.data_ptr()), n,
                                                  C.c_void_p(out.data_ptr())))
         if cross:
             self._release_after_use(h, c, out)
@@ -430,24 +437,24 @@ class SingleRoom:
 
     def reward_device(self) -> DeviceArray:
         p = C.c_void_p()
-        _capi.check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
+        self._check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
         return DeviceArray(p.value, (self.batch,), self.R, self, self._sync)
 
     def done_device(self) -> DeviceArray:
         p = C.c_void_p()
-        _capi.check(self._lib.rcw_done_device_ptr(self._h, C.byref(p)))
+        self._check(self._lib.rcw_done_device_ptr(self._h, C.byref(p)))
         return DeviceArray(p.value, (self.batch,), np.uint8, self, self._sync)
 
     def ray_table(self) -> np.ndarray:
         """(nd, 5, N) float32: per heading [dx | dy | |1/dx| | |1/dy| | dir·ray]."""
         out = np.empty((self.cfg.num_directions, 5, self.cfg.num_rays), dtype=self.T)
         fn = self._lib.rcw_ray_table64 if self.T is np.float64 else self._lib.rcw_ray_table
-        _capi.check(fn(self._h, _as_ptr(out)))
+        self._check(fn(self._h, _as_ptr(out)))
         return out
 
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)
-        _capi.check(self._lib.rcw_device_name(self._h, buf, 256))
+        self._check(self._lib.rcw_device_name(self._h, buf, 256))
         return buf.value.decode()
 
     # ---- state injection (how "identical seeds" is realised, SURVEY.md §8c) ---------
@@ -457,17 +464,17 @@ class SingleRoom:
         d = np.ascontiguousarray(player_direction_au, dtype=np.int32).reshape(self.batch)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.batch)
         fn = self._lib.rcw_set_state64 if self.T is np.float64 else self._lib.rcw_set_state
-        _capi.check(fn(self._h, _as_ptr(g), _as_ptr(p), _as_ptr(d), _as_ptr(m)))
+        self._check(fn(self._h, _as_ptr(g), _as_ptr(p), _as_ptr(d), _as_ptr(m)))
 
     def set_direction_table(self, directions_wu):
         d = np.ascontiguousarray(directions_wu, dtype=self.T).reshape(self.cfg.num_directions, 2)
         fn = self._lib.rcw_set_direction_table64 if self.T is np.float64 else self._lib.rcw_set_direction_table
-        _capi.check(fn(self._h, _as_ptr(d)))
+        self._check(fn(self._h, _as_ptr(d)))
 
     def stream_ptr(self) -> int:
         """The hipStream_t (as an int) the engine's work is ordered on."""
         p = C.c_void_p()
-        _capi.check(self._lib.rcw_get_stream(self._h, C.byref(p)))
+        self._check(self._lib.rcw_get_stream(self._h, C.byref(p)))
         return int(p.value or 0)
 
     def torch_stream(self):
@@ -477,37 +484,53 @@ class SingleRoom:
         return torch.cuda.ExternalStream(self.stream_ptr(), device=f"cuda:{self.device}")
 
     def set_stream(self, hip_stream: Optional[int]):
-        _capi.check(self._lib.rcw_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+        self._check(self._lib.rcw_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def bind_obs(self, device_ptr: Optional[int]):
-        _capi.check(self._lib.rcw_bind_obs(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+        self._check(self._lib.rcw_bind_obs(self._h, C.c_void_p(device_ptr) if device_ptr else None))
 
     def clear_error(self):
-        _capi.check(self._lib.rcw_clear_error(self._h))
+        self._check(self._lib.rcw_clear_error(self._h))
 
     def profile(self, enable: bool):
         """Bracket the cast and fill kernels of every step with HIP events (<= 256 steps)."""
-        _capi.check(self._lib.rcw_profile(self._h, 1 if enable else 0))
+        self._check(self._lib.rcw_profile(self._h, 1 if enable else 0))
 
     def profile_read(self):
         """(mean cast kernel ms, mean top view kernel ms (0 without it), mean fill kernel ms, steps recorded).
         With the two-kernel top view the second is its store kernel; its draw kernel runs beside the fill."""
         c, t, f, n = C.c_float(), C.c_float(), C.c_float(), C.c_int32()
-        _capi.check(self._lib.rcw_profile_read(self._h, C.byref(c), C.byref(t), C.byref(f), C.byref(n)))
+        self._check(self._lib.rcw_profile_read(self._h, C.byref(c), C.byref(t), C.byref(f), C.byref(n)))
         return float(c.value), float(t.value), float(f.value), int(n.value)
+
+    def set_top_view_form(self, form: Optional[str] = None, runs: int = 0) -> None:
+        """Choose the form update_top_view! takes instead of the library's rule (rcw_set_top_view_form): None = automatic,
+        "in-place", "one-kernel" or "two-kernels"; `runs` = 0 (automatic) or 1..8 runs of agents for the two-kernel form.
+        All forms write the same pixels.  Raises RcwError (unsupported) when the geometry cannot take the form."""
+        forms = {None: 0, "auto": 0, "in-place": _capi.RCW_TOP_VIEW_IN_PLACE, "one-kernel": _capi.RCW_TOP_VIEW_ONE_KERNEL,
+                 "two-kernels": _capi.RCW_TOP_VIEW_TWO_KERNELS}
+        if form not in forms:
+            raise ValueError(f"unknown top view form {form!r}")
+        self._check(self._lib.rcw_set_top_view_form(self._h, forms[form], int(runs)))
+
+    def fill_kernel_name(self) -> str:
+        """The kernel update_camera_view! takes for this camera height (rcw_fill_kernel_name)."""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.rcw_fill_kernel_name(self._h, buf, 64))
+        return buf.value.decode()
 
     def top_view_form(self) -> str:
         """Which kernel form update_top_view! takes for this geometry: "none", "in-place", "one-kernel", "two-kernels"."""
         f = C.c_int32()
-        _capi.check(self._lib.rcw_top_view_form(self._h, C.byref(f)))
+        self._check(self._lib.rcw_top_view_form(self._h, C.byref(f)))
         return ("none", "in-place", "one-kernel", "two-kernels")[f.value]
 
     def timer_start(self):
-        _capi.check(self._lib.rcw_timer_start(self._h))
+        self._check(self._lib.rcw_timer_start(self._h))
 
     def timer_stop(self) -> float:
         ms = C.c_float()
-        _capi.check(self._lib.rcw_timer_stop(self._h, C.byref(ms)))
+        self._check(self._lib.rcw_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
 
 
@@ -517,7 +540,7 @@ def reset_(env: SingleRoom, mask=None, seed: Optional[int] = None) -> None:
     if seed is not None:
         env.seed = int(seed)
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(env.batch)
-    _capi.check(env._lib.rcw_reset(env._h, _as_ptr(m), env.seed))
+    env._check(env._lib.rcw_reset(env._h, _as_ptr(m), env.seed))
     return None
 
 
@@ -569,12 +592,12 @@ def act_(env: SingleRoom, action) -> None:
             # stream, make the engine's stream wait for them (an event record + wait, no host sync) and
             # hold the tensor until the cast kernel has read it (the caller may drop a temporary at once).
             cross = env._order_behind_torch()
-            _capi.check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
+            env._check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
             if cross:
                 env._release_after_use(action)
             return None
     a = host_actions(env.batch, action)
-    _capi.check(env._lib.rcw_step(env._h, _as_ptr(a)))
+    env._check(env._lib.rcw_step(env._h, _as_ptr(a)))
     return None
 
 
@@ -582,19 +605,19 @@ def cast_rays_(env: SingleRoom, first: int = 0, count: Optional[int] = None):
     """`RCW.cast_rays!(world)` SR:195-231: recasts every agent's rays from the current state (rcw_cast_rays:
     the compact column descriptors are refreshed, no pixel is written) and returns the ray buffers
     (stop tile, hit dimension, distance, direction) of agents [first, first+count)."""
-    _capi.check(env._lib.rcw_cast_rays(env._h))
+    env._check(env._lib.rcw_cast_rays(env._h))
     return env.world.rays(first, count)
 
 
 def update_camera_view_(env: SingleRoom) -> None:
     """`RCW.update_camera_view!(env)` SR:374-444: refills `camera_view` from the stored ray results without
     casting, as the reference's does (rcw_update_camera_view: the fill kernel alone)."""
-    _capi.check(env._lib.rcw_update_camera_view(env._h))
+    env._check(env._lib.rcw_update_camera_view(env._h))
 
 
 def update_top_view_(env: SingleRoom) -> None:
     """`RCW.update_top_view!(env)` SR:446-483 (env built with render_top_view=True): redraws `top_view`."""
-    _capi.check(env._lib.rcw_update_top_view(env._h))
+    env._check(env._lib.rcw_update_top_view(env._h))
 
 
 def get_action_names(env: SingleRoom):

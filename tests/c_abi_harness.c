@@ -97,7 +97,11 @@ int main(int argc, char** argv)
         rcw_handle* ht = NULL;
         CHECK(rcw_create(&cfg, B, 0, 2024, &ht));
         int32_t form = -1;
+        CHECK(rcw_set_top_view_form(ht, RCW_TOP_VIEW_TWO_KERNELS, 0));   /* (64 agents: the two-kernel form only when asked for) */
         CHECK(rcw_top_view_form(ht, &form));
+        char kname[64];
+        CHECK(rcw_fill_kernel_name(ht, kname, (int32_t)sizeof kname));
+        printf("fill_kernel=%s\n", kname);
         seed = 99;
         for (int s = 0; s < STEPS; ++s) {
             for (int a = 0; a < B; ++a) actions[a] = (uint8_t)(1 + lcg(&seed) % 4);

@@ -74,3 +74,22 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
                 text = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "oracle" not in text.lower(), (dirpath, fn)
+
+
+def test_shipped_library_reads_no_development_switch(rcw):
+    """The shipped librcw_hip.so names exactly one environment variable, RCW_RCCL_LIBRARY (where to find RCCL): the
+    tuning knobs and measured-and-rejected kernel variants of development live in librcw_hip_dev.so only, so a stray
+    RCW_* variable in a user's shell cannot change results or performance."""
+    from raycastworlds_jl_amd import _capi
+
+    def env_names(path):
+        data = open(path, "rb").read()
+        return sorted(set(m.decode() for m in re.findall(rb"(?<![A-Z_0-9])RCW_[A-Z0-9_]{3,}(?=\x00)", data)))
+
+    assert env_names(_capi.LIB_PATH) == ["RCW_RCCL_LIBRARY"]
+    if os.path.exists(_capi.DEV_LIB_PATH):
+        dev = env_names(_capi.DEV_LIB_PATH)
+        assert "RCW_CAST_MARCH" in dev and "RCW_TOP_DEBUG" in dev and "RCW_RCCL_LIBRARY" in dev
+        # the development build exports the same ABI
+        lib = C.CDLL(_capi.DEV_LIB_PATH)
+        assert not [n for n in _declared() if not hasattr(lib, n)]

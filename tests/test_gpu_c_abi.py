@@ -28,8 +28,7 @@ def test_plain_c_caller(oracle, tmp_path):
     subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_harness.c"),
                     "-o", exe, "-L", lib, "-lrcw_hip", f"-Wl,-rpath,{lib}"], check=True)
     steps = 120
-    res = subprocess.run([exe, str(steps)], capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, RCW_TOP_SPLIT="2"))             # (64 agents: the two-kernel top view only when asked for)
+    res = subprocess.run([exe, str(steps)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     m = re.search(r"terminal_events=(\d+) checksum=([0-9a-f]{16}) pos0=([-\d.e+]+),([-\d.e+]+) dir0=(\d+)", res.stdout)
     assert m, res.stdout
@@ -53,6 +52,7 @@ def test_plain_c_caller(oracle, tmp_path):
     mt = re.search(r"top_view_form=(\d+) top_checksum=([0-9a-f]{16})", res.stdout)
     assert mt, res.stdout
     assert int(mt.group(1)) == 3
+    assert "fill_kernel=rcw_fill256_kernel" in res.stdout
     ort = oracle.OracleBatch(64, seed=2024, out_of_bounds=1, render_top_view=1, pu_per_tu=32,
                              height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
     for t in range(steps):

@@ -81,8 +81,7 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form):
     ALL images a size-independent property: no pixel outside the six colours update_top_view! can write (SR:288-290,
     SR:364-367) — a chunk the store kernel skipped or wrote twice with stale descriptors would show."""
     env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=77, out_of_bounds=1, render_top_view=True, pu_per_tu=32, **cfg)
-    if "RCW_TOP_SPLIT" not in os.environ:                                   # (a developer may force a form for the whole run)
-        assert env.top_view_form() == form
+    assert env.top_view_form() == form
     orc = oracle.OracleBatch(batch, seed=77, render=False, out_of_bounds=1, **cfg)
     rng = np.random.default_rng(3)
     for s in range(5):

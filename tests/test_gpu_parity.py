@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _make(rcw, oracle, batch, seed=0, **kw):
     env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=seed, **kw)
-    okw = {k: v for k, v in kw.items() if k not in ("auto_reset", "T")}
+    okw = {k: v for k, v in kw.items() if k not in ("auto_reset", "T", "library")}
     if kw.get("auto_reset"):
         okw["auto_reset"] = 1
     if kw.get("T") == "Float64":
@@ -585,33 +585,49 @@ def test_top_view_in_place_fallback(rcw, oracle):
         env.close()
 
 
-@pytest.mark.parametrize("env_switch, form", [(("RCW_TOP_SPLIT", "2"), "two-kernels"), (("RCW_TOP_SPLIT", "0"), "one-kernel"),
-                                              (("RCW_TOP_INPLACE", "1"), "in-place")])
-def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_switch, form):
+# geometries of the top view: (kwargs, batch).  The first ten are the unit kernels' (whole tiles in runs of 256 / 128 / 64 /
+# 32 rows); the rest only the flat store kernel takes in the two-kernel form (rcw_top_store_flat_kernel: any pixel scale
+# from 9, image height a multiple of 4): pixel scales that do not divide the four-pixel lane groups (13, 10 with an odd
+# tile count...), images that are not a whole number of 1 KiB chunks (chunks straddle agents), circles wider than 32 rows.
+TOP_GEOMETRIES = (
+    (dict(pu_per_tu=32, **CFG2), 300), (dict(pu_per_tu=16, height_tile_map_tu=16, width_tile_map_tu=9, num_rays=100), 21),
+    (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
+    (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=20, num_rays=33, player_radius_wu=0.3, position_increment_wu=0.2), 9),
+    # heights of 128 m, 64 m and 32 m rows: two / four / eight units (runs of rows of one column) to a 1 KiB chunk
+    (dict(pu_per_tu=32, height_tile_map_tu=12, width_tile_map_tu=7, num_rays=128), 37),     # 384 rows
+    (dict(pu_per_tu=16, **CFG2), 130),                                                     # 128 rows
+    (dict(pu_per_tu=32, height_tile_map_tu=10, width_tile_map_tu=9, num_rays=200), 11),     # 320 rows
+    (dict(pu_per_tu=8, height_tile_map_tu=8, width_tile_map_tu=5, num_rays=64, player_radius_wu=0.3, position_increment_wu=0.2), 260),   # 64 rows
+    (dict(pu_per_tu=32, height_tile_map_tu=9, width_tile_map_tu=11, num_rays=150), 23),     # 288 rows: eight units of 32 (now the flat kernel)
+    (dict(pu_per_tu=16, height_tile_map_tu=10, width_tile_map_tu=6, num_rays=90), 50),      # 160 rows
+    # ---- the flat kernel's own
+    (dict(pu_per_tu=13, **CFG2), 300),                                                     # 104 x 104 px: 42.25 chunks an image, four pixels straddle tiles
+    (dict(pu_per_tu=10, **CFG2), 130),                                                     # 80 rows: a chunk touches five columns
+    (dict(pu_per_tu=12, height_tile_map_tu=16, width_tile_map_tu=8, num_rays=96), 40),      # 192 rows of 12-pixel tiles
+    (dict(pu_per_tu=20, height_tile_map_tu=9, width_tile_map_tu=7, num_rays=70), 33),       # 180 x 140 px
+    (dict(pu_per_tu=24, height_tile_map_tu=8, width_tile_map_tu=16, num_rays=512), 19),     # the reference default map at 24 px a tile
+    (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), 70),     # a circle of 33 rows
+    (dict(pu_per_tu=100, height_tile_map_tu=5, width_tile_map_tu=4, num_rays=40, player_radius_wu=0.45, position_increment_wu=0.3), 5),   # 500 x 400 px, circle of 93 rows
+    (dict(pu_per_tu=9, height_tile_map_tu=8, width_tile_map_tu=3, num_rays=20), 77),        # 72 x 27 px: the smallest tiles, seven columns a chunk
+    (dict(pu_per_tu=11, height_tile_map_tu=4, width_tile_map_tu=9, num_rays=50), 65),       # 44 rows: the shortest image
+    (dict(pu_per_tu=17, height_tile_map_tu=32, width_tile_map_tu=6, num_rays=64, T="Float64"), 6),   # 544 rows, Float64 world units
+)
+
+
+@pytest.mark.parametrize("form", ["two-kernels", "one-kernel", "in-place"])
+def test_top_view_forms_write_the_same_pixels(rcw, oracle, form):
     """The three kernel forms of update_top_view! (rcw.h: rcw_top_view_form) against the oracle on the same states:
     the two-kernel form (draw kernel beside the camera fill, moving-window store kernel) is what an eligible geometry
-    takes from 256 MiB of top view a step (RCW_TOP_SPLIT=2 takes it at these small batches too; at full size:
-    test_gpu_full_size.py); the development switches force the other two.  300 agents x 256 columns of 256 px = 76,800 chunks: more
+    takes from 256 MiB of top view a step (rcw_set_top_view_form takes it at these small batches too; at full size:
+    test_gpu_full_size.py) and asks for the other two.  300 agents x 256 columns of 256 px = 76,800 chunks: more
     than one sweep of the store kernel's window (65,536), so its last group is a partial one; the masked reset
     exercises its skipped chunks; 16 px tiles put two tile rows into one lane group."""
-    if env_switch:
-        monkeypatch.setenv(*env_switch)
-    monkeypatch.setenv("RCW_TOP_RUNS", "3")      # (two-kernel form: the batch in three runs of agents, store of one beside the drawing of the next)
     rng = np.random.default_rng(29)
-    for kw, batch in ((dict(pu_per_tu=32, **CFG2), 300), (dict(pu_per_tu=16, height_tile_map_tu=16, width_tile_map_tu=9, num_rays=100), 21),
-                      (dict(pu_per_tu=64, height_tile_map_tu=12, width_tile_map_tu=5, num_rays=64), 7),
-                      (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=20, num_rays=33, player_radius_wu=0.3,
-                            position_increment_wu=0.2), 9),
-                      # heights of 128 m, 64 m and 32 m rows: two / four / eight units (runs of rows of one column) to a 1 KiB chunk
-                      (dict(pu_per_tu=32, height_tile_map_tu=12, width_tile_map_tu=7, num_rays=128), 37),     # 384 rows
-                      (dict(pu_per_tu=16, **CFG2), 130),                                                     # 128 rows
-                      (dict(pu_per_tu=32, height_tile_map_tu=10, width_tile_map_tu=9, num_rays=200), 11),     # 320 rows
-                      (dict(pu_per_tu=8, height_tile_map_tu=8, width_tile_map_tu=5, num_rays=64, player_radius_wu=0.3,
-                            position_increment_wu=0.2), 260),                                                # 64 rows
-                      (dict(pu_per_tu=32, height_tile_map_tu=9, width_tile_map_tu=11, num_rays=150), 23),     # 288 rows: eight units of 32
-                      (dict(pu_per_tu=16, height_tile_map_tu=10, width_tile_map_tu=6, num_rays=90), 50)):     # 160 rows
+    for kw, batch in TOP_GEOMETRIES:
         env, orc = _make(rcw, oracle, batch, seed=23, render_top_view=1, **kw)
+        env.set_top_view_form(form, runs=3)   # (two-kernel form: the batch in three runs of agents, store of one beside the drawing of the next)
         assert env.top_view_form() == form, kw
+        rcw.reset_(env, seed=23); orc.reset(seed=23)                         # (rendered in the chosen form)
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after reset {kw}")
         for s in range(12):
             a = rng.integers(1, 5, batch).astype(np.uint8)
@@ -624,42 +640,85 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, monkeypatch, env_swit
         mask = (rng.random(batch) < 0.4).astype(np.uint8)
         rcw.reset_(env, mask=mask, seed=8); orc.reset(mask=mask, seed=8)
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after masked reset {kw}")
-        rcw.update_top_view_(env)                                            # the stand-alone call (always the one-kernel form)
+        rcw.update_top_view_(env)                                            # the stand-alone call
         np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"after update_top_view! {kw}")
         assert_state_equal(env, orc, where=f"camera path unaffected {kw}")
         env.close()
 
 
-def test_top_view_form_of_other_geometries(rcw, monkeypatch):
+def test_top_view_form_of_other_geometries(rcw):
     """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form — and so
-    does a batch too small to pay for two more launches and a stream fork / join (below 256 MiB of top view a step)."""
+    does a batch too small to pay for two more launches and a stream fork / join (below 256 MiB of top view a step),
+    unless rcw_set_top_view_form asks for it; a form the geometry cannot take is refused and the handle stays usable."""
+    from raycastworlds_jl_amd import _capi
+
     env = rcw.SingleRoomModule.SingleRoom(batch=512, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)     # 128 MiB
     assert env.top_view_form() == "one-kernel"
     env.close()
     env = rcw.SingleRoomModule.SingleRoom(batch=1024, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)    # 256 MiB
     assert env.top_view_form() == "two-kernels"
+    env.set_top_view_form("one-kernel"); assert env.top_view_form() == "one-kernel"
+    env.set_top_view_form(None); assert env.top_view_form() == "two-kernels"
     env.close()
-    monkeypatch.setenv("RCW_TOP_SPLIT", "2")                                 # (geometry alone, whatever the batch)
-    for kw, form in ((dict(pu_per_tu=10, **CFG2), "one-kernel"),                      # 10 does not divide 256
-                     (dict(pu_per_tu=12, height_tile_map_tu=16, width_tile_map_tu=8), "one-kernel"),   # 192 rows of 12-pixel tiles
-                     (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), "one-kernel"),   # circle of 33 rows
+    for kw, form in ((dict(pu_per_tu=10, **CFG2), "two-kernels"),                     # 10 does not divide 256: the flat store kernel
+                     (dict(pu_per_tu=12, height_tile_map_tu=16, width_tile_map_tu=8), "two-kernels"),   # 192 rows of 12-pixel tiles
+                     (dict(pu_per_tu=32, player_radius_wu=0.49, position_increment_wu=0.1, **CFG2), "two-kernels"),   # circle of 33 rows
                      (dict(pu_per_tu=32, **CFG4), "two-kernels"),
-                     (dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), "in-place")):
+                     (dict(pu_per_tu=13, height_tile_map_tu=9, width_tile_map_tu=9, num_rays=64), None),    # 117 rows: not a multiple of 4
+                     (dict(pu_per_tu=6, height_tile_map_tu=10, width_tile_map_tu=9, num_rays=64), None),    # 6-pixel tiles, 60 rows
+                     (dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), None)):   # bit plane beyond LDS
         env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, render_top_view=True, **kw)
-        assert env.top_view_form() == form, kw
+        auto = env.top_view_form()
+        if form is None:
+            with pytest.raises(_capi.RcwError) as ei:
+                env.set_top_view_form("two-kernels")
+            assert ei.value.code == _capi.RCW_ERR_UNSUPPORTED
+            assert env.top_view_form() == auto                               # the refused request changed nothing
+        else:
+            env.set_top_view_form("two-kernels")
+            assert env.top_view_form() == form, kw
+        rcw.act_(env, 1); env.sync()
         env.close()
+    env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, render_top_view=True, pu_per_tu=32, height_tile_map_tu=50,
+                                          width_tile_map_tu=40, num_rays=128)
+    assert env.top_view_form() == "in-place"
+    with pytest.raises(_capi.RcwError):
+        env.set_top_view_form("one-kernel")
+    env.close()
     env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, **CFG2)
     assert env.top_view_form() == "none"
+    with pytest.raises(_capi.RcwError):
+        env.set_top_view_form("one-kernel")
     env.close()
 
 
-def test_captured_step_with_top_view_replays(rcw, oracle, monkeypatch):
+def test_two_top_view_handles_with_large_planes_alive_together(rcw, oracle):
+    """Two render_top_view handles whose bit planes need more than 64 KiB of LDS (768² and 1024² px), created in the order
+    that used to lower the first one's kernel limit, stepped alternately: the raised dynamic-LDS limit belongs to the
+    kernel function, i.e. to every handle on the device, and is set once to the fixed cap."""
+    big = dict(pu_per_tu=32, height_tile_map_tu=32, width_tile_map_tu=32, num_rays=128)
+    small = dict(pu_per_tu=32, height_tile_map_tu=24, width_tile_map_tu=24, num_rays=128)
+    e1, o1 = _make(rcw, oracle, 3, seed=5, render_top_view=1, out_of_bounds=1, **big)
+    e2, o2 = _make(rcw, oracle, 3, seed=6, render_top_view=1, out_of_bounds=1, **small)
+    rng = np.random.default_rng(4)
+    for form in (None, "two-kernels"):
+        e1.set_top_view_form(form); e2.set_top_view_form(form)
+        for s in range(4):
+            a = rng.integers(1, 5, 3).astype(np.uint8)
+            rcw.act_(e1, a); o1.step(a)
+            rcw.act_(e2, a); o2.step(a)
+        np.testing.assert_array_equal(e1.top_view_host(), o1.top_view)
+        np.testing.assert_array_equal(e2.top_view_host(), o2.top_view)
+    e1.close(); e2.close()
+
+
+def test_captured_step_with_top_view_replays(rcw, oracle):
     """A step is capturable into a HIP graph (torch.cuda.CUDAGraph on the stream the engine shares), including the
     two-kernel top view's fork to the handle's side stream and the join back: eight replays with the same device
     actions equal eight oracle steps, both images."""
     torch = pytest.importorskip("torch")
-    monkeypatch.setenv("RCW_TOP_SPLIT", "2")                                 # (48 agents would take the one-kernel form)
     env, orc = _make(rcw, oracle, 48, seed=31, render_top_view=1, pu_per_tu=32, out_of_bounds=1, **CFG2)
+    env.set_top_view_form("two-kernels")                                     # (48 agents would take the one-kernel form)
     assert env.top_view_form() == "two-kernels"
     stream = torch.cuda.Stream()
     env.set_stream(stream.cuda_stream)
@@ -683,31 +742,31 @@ def test_captured_step_with_top_view_replays(rcw, oracle, monkeypatch):
 
 
 def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
-    """The ballot-bounded march (the form north_star words; development switch RCW_CAST_MARCH=ballot, measured against
-    the shipped exec-masked march in profiles/) is the same function: bit-exact at the deep-march config and under
-    every unpinned switch."""
+    """The ballot-bounded march (the form north_star words; development switch RCW_CAST_MARCH=ballot of the development
+    build librcw_hip_dev.so, measured against the shipped exec-masked march in profiles/) is the same function: bit-exact
+    at the deep-march config and under every unpinned switch."""
     monkeypatch.setenv("RCW_CAST_MARCH", "ballot")
     rng = np.random.default_rng(12)
-    env, orc = _make(rcw, oracle, 16, seed=9, **CFG5)
+    env, orc = _make(rcw, oracle, 16, seed=9, library="dev", **CFG5)
     _rollout(rcw, env, orc, 30, rng, check_every=10, rays_every=10)
     env.close()
     for tie in (0, 1):
         for dist in (0, 1):
-            env, orc = _make(rcw, oracle, 16, seed=5, dda_tie_break=tie, dda_distance=dist, **CFG1)
+            env, orc = _make(rcw, oracle, 16, seed=5, dda_tie_break=tie, dda_distance=dist, library="dev", **CFG1)
             _rollout(rcw, env, orc, 30, rng, check_every=10, rays_every=10)
             env.close()
-    env, orc = _make(rcw, oracle, 8, seed=3, T="Float64", **CFG2)
+    env, orc = _make(rcw, oracle, 8, seed=3, T="Float64", library="dev", **CFG2)
     _rollout(rcw, env, orc, 20, rng, check_every=10, rays_every=10)
     env.close()
 
 
 def test_lds_staged_ray_table_gives_the_same_rays(rcw, oracle, monkeypatch):
-    """Development switch RCW_CAST_TABLE=lds (the heading's ray-table slice copied to LDS before use, as north_star
-    words it; measured against the shipped direct L2 read in profiles/): same results."""
+    """Development switch RCW_CAST_TABLE=lds of the development build (the heading's ray-table slice copied to LDS before
+    use, as north_star words it; measured against the shipped direct L2 read in profiles/): same results."""
     monkeypatch.setenv("RCW_CAST_TABLE", "lds")
     rng = np.random.default_rng(14)
     for kw in (CFG2, CFG5, dict(T="Float64", **CFG1), dict(num_rays=100, height_tile_map_tu=9, width_tile_map_tu=7)):
-        env, orc = _make(rcw, oracle, 12, seed=4, auto_reset=True, **kw)
+        env, orc = _make(rcw, oracle, 12, seed=4, auto_reset=True, library="dev", **kw)
         _rollout(rcw, env, orc, 25, rng, check_every=5, rays_every=5)
         env.close()
 

@@ -186,3 +186,62 @@ def test_frame_buffer_blit_is_the_reference_transpose(rcw):
     got = rcw.frame_buffer_of(engine_layout, width_image, height_image)
     # Julia's (width_image, height_image) column-major buffer is numpy (height_image, width_image) in C order
     np.testing.assert_array_equal(got, frame_buffer.T)
+
+
+def _fast_div(n, d):
+    """rcw_kernels.hip `fast_div`, operation for operation in Float32 / int32 (numpy, vectorised over n)."""
+    inv = np.float32(1.0) / np.float32(d)
+    q = (n.astype(np.float32) * inv).astype(np.int64)          # v_cvt_f32_i32, v_mul_f32, v_cvt_i32_f32 (truncation)
+    q = q - (q * d > n)
+    q = q + ((q + 1) * d <= n)
+    return q
+
+
+def test_fast_div_is_exact_where_the_kernels_use_it():
+    """`fast_div(n, d, 1/d)` replaces the integer division in the store kernels.  Its argument — the Float32 quotient is
+    off by at most one, which the two corrections repair — needs n < 2^31 / d (the products stay in int32) and a quotient
+    whose Float32 error stays below one: n·2^-23 < 1 is sufficient but not necessary.  The uses: rcw_fill_flat_kernel /
+    rcw_top_store_flat_kernel (n < H_cam + 256 or H·pu + 256 <= 2^20 + 256, every d from 37 resp. 9), and
+    rcw_fill_frame_kernel, whose flat index runs to N·H_cam < 2^25 with d = H_cam or H_cam / 4 — beyond 2^23, where
+    (float)n is no longer exact: checked here over the whole launcher-admitted range (N <= 8192, N·H_cam < 2^25)."""
+    rng = np.random.default_rng(5)
+    for d in list(range(1, 70)) + [84, 100, 117, 250, 255, 256, 257, 1000, 4095, 4096, 16383, 16384, (1 << 20) - 1, 1 << 20]:
+        hi = min(d + 256, 1 << 21) if d >= 37 else 70000
+        n = np.arange(0, hi + 1, dtype=np.int64)
+        np.testing.assert_array_equal(_fast_div(n, d), n // d, err_msg=f"d={d}")
+    # the frame kernel: v < N * vpc (VEC, vpc = H_cam / 4) or N * H_cam, N <= 8192, below 2^25
+    for hc in (1, 2, 3, 5, 7, 21, 25, 33, 35, 36, 84 // 4, 100 // 4, 999, 4093, 4097):
+        top = min(8192 * hc, 1 << 25)
+        n = np.unique(np.concatenate([np.arange(max(0, top - 200000), top, dtype=np.int64),
+                                      rng.integers(0, top, 200000), (np.arange(1, 8193, dtype=np.int64) * hc - 1) % top,
+                                      (np.arange(0, 8192, dtype=np.int64) * hc) % top]))
+        np.testing.assert_array_equal(_fast_div(n, hc), n // hc, err_msg=f"frame kernel, d={hc}")
+
+
+def test_flat_plane_layout_makes_chunks_whole_words():
+    """The draw kernel's plane for rcw_top_store_flat_kernel: agent a's pixel q sits at bit s_a + q of its region,
+    s_a = (a · Ht·Wt) mod 256.  Then chunk c of the flat batch (pixels 256 c .. 256 c + 255) finds its bits in 8 whole
+    words of the region of the first pixel's agent, OR the region of the last pixel's agent — checked against a direct
+    flat bit array for images that are not a whole number of chunks."""
+    rng = np.random.default_rng(9)
+    for Ht, Wt, B in ((104, 104, 5), (44, 99, 7), (180, 140, 3), (72, 27, 11)):
+        px = Ht * Wt
+        PW = ((px + 255 + 255) // 256) * 8
+        bits = rng.integers(0, 2, (B, px)).astype(np.uint8)
+        region = np.zeros((B, PW * 32), dtype=np.uint8)
+        for a in range(B):
+            s = (a * px) % 256
+            region[a, s:s + px] = bits[a]
+        flat = bits.reshape(-1)
+        total_chunks = (B * px + 255) // 256
+        for c in range(total_chunks):
+            a0 = (256 * c) // px
+            a1 = min((256 * c + 255) // px, B - 1) if (256 * c + 255) // px < B else None
+            off0 = (c - (a0 * px) // 256) * 256
+            got = region[a0, off0:off0 + 256].copy()
+            if a1 is not None and a1 != a0:
+                got |= region[a1, 0:256]
+            want = np.zeros(256, dtype=np.uint8)
+            seg = flat[256 * c:256 * c + 256]
+            want[:seg.size] = seg
+            np.testing.assert_array_equal(got, want, err_msg=f"{Ht}x{Wt} chunk {c}")
