@@ -629,7 +629,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     RCW_TRY(hipMalloc(&h->d_reward, B * h->reward_size));
     RCW_TRY(hipMalloc(&h->d_done, B));
     RCW_TRY(hipMalloc(&h->d_episode, B * sizeof(uint32_t)));
-    RCW_TRY(hipMalloc(&h->d_tile_map, B * (size_t)h->nchunks * sizeof(uint64_t)));
+    RCW_TRY(hipMalloc(&h->d_tile_map, B * (size_t)h->nchunks * sizeof(uint64_t) + 16));   // (+ 2 words: the flat top store kernel reads three words from any word of a map)
     RCW_TRY(hipMalloc(&h->d_dir_table, (size_t)nd * 2 * h->real_size));
     RCW_TRY(hipMalloc(&h->d_ray_table, (size_t)nd * RCW_TABLE_ROWS * N * h->real_size));
     RCW_TRY(hipMalloc(&h->d_obs, B * (size_t)N * Hc * sizeof(uint32_t)));

@@ -38,6 +38,13 @@
 
 #include <mutex>
 
+#ifndef RCW_EXP_UNROLL
+#define RCW_EXP_UNROLL 2
+#endif
+#ifndef RCW_EXP
+#define RCW_EXP 0   // (temporary: compile-time timing experiments, tools/_build/variants)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;   // 4 wavefronts of 64
@@ -563,11 +570,56 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_window_kernel(const RcwDev p,
 // row rem0 of its first column touches at most K = 254 / H_cam + 2 columns; lane l of the prefetch finds (first
 // column, rem0) of the wavefront's l-th next chunk — carried from group to group as (quotient, remainder), no division
 // — loads those K columns' descriptors and parks them as (padding | valid << 31, colour) pairs in wave-private LDS.  In
-// the chunk loop a lane derives its own column from its flat pixel offset (rem0 + 4 lane) with a Float32 reciprocal
-// (fast_div: the offset stays below 2^20 + 256), reads that column's pair back with one ds_read_b64 and writes its
-// four pixels with one 16-byte store, as the kernels above.  ALIGNED (H_cam % 4 == 0): the four pixels never straddle
-// a column; otherwise the lane also reads the next column's pair and picks per pixel.  Chunks at a masked agent's
-// border and the batch's last, short chunk take a per-pixel path (wave-uniform branch).
+// the chunk loop a lane derives its own column from its flat pixel offset rem0 + 4 lane WITHOUT a division: with
+// 4 lane = qv·H_cam + rv fixed per lane and rem0 < H_cam, the column is qv + (rem0 + rv >= H_cam) and the row
+// rem0 + rv less H_cam in that case — an add, a subtract, an unsigned min, a compare and an add-with-carry.  It then
+// reads that column's pair back with one ds_read_b64 and writes its four pixels with one 16-byte store, as the kernels
+// above.  ALIGNED (H_cam % 4 == 0): the four pixels never straddle a column; otherwise the lane also reads the next
+// column's pair and picks per pixel.  A group whose 64 chunks are all whole and unmasked (nearly every one) runs a
+// loop without branches that fetches the next chunk's pair while it computes this one's pixels — one wavefront per
+// SIMD has nobody else to hide the LDS round trip behind; chunks at a masked agent's border and the batch's last,
+// short chunk take the general loop with its per-pixel path.
+struct FlatLane { int qv, rv; };          // 4 lane = qv · height + rv
+__device__ __forceinline__ FlatLane flat_lane(int lane, int height)
+{
+    FlatLane L;
+    L.qv = (4 * lane) / height;
+    L.rv = 4 * lane - L.qv * height;
+    return L;
+}
+// (column relative to the chunk's first, row in it) of this lane's first pixel, for a chunk that starts at row rem0
+__device__ __forceinline__ void flat_locate(const FlatLane& L, int rem0, int height, int& rel, int& r)
+{
+    const uint32_t t = (uint32_t)(rem0 + L.rv), u = t - (uint32_t)height;
+    r = (int)(t < u ? t : u);                                              // v_min_u32: u wraps when t < height
+    rel = L.qv + (t >= (uint32_t)height ? 1 : 0);
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ u32x4 flat_fill_pixels(int r, int Hc, uint2 d0, uint2 d1, uint32_t ceil_c, uint32_t floor_c, bool* ok)
+{
+    const int pad0 = (int)(d0.x & 0x7FFFFFFFu);
+    u32x4 v;
+    if (ALIGNED) {
+        v.x = pixel(r + 0, pad0, Hc, d0.y, ceil_c, floor_c);
+        v.y = pixel(r + 1, pad0, Hc, d0.y, ceil_c, floor_c);
+        v.z = pixel(r + 2, pad0, Hc, d0.y, ceil_c, floor_c);
+        v.w = pixel(r + 3, pad0, Hc, d0.y, ceil_c, floor_c);
+        ok[0] = ok[1] = ok[2] = ok[3] = (d0.x >> 31) != 0u;
+    } else {
+        const int pad1 = (int)(d1.x & 0x7FFFFFFFu);
+        uint32_t px[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool next = r + e >= Hc;                                 // this pixel is in the following column
+            px[e] = pixel(next ? r + e - Hc : r + e, next ? pad1 : pad0, Hc, next ? d1.y : d0.y, ceil_c, floor_c);
+            ok[e] = ((next ? d1.x : d0.x) >> 31) != 0u;
+        }
+        v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
+    }
+    return v;
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
                                                                const int32_t* __restrict__ col_h,
@@ -581,10 +633,10 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
     const int Hc = p.Hc, KS = K + 1;                                      // (one spare pair per chunk: the straddling read of the last column)
-    const float inv_hc = 1.0f / (float)Hc;
     const unsigned long long total_px = (unsigned long long)total_cols * (unsigned)Hc;
     const unsigned long long total_chunks = (total_px + 255) >> 8;
     uint2* const desc = reinterpret_cast<uint2*>(lds) + (size_t)(threadIdx.x >> 6) * 64 * KS;   // [64 chunks][KS]
+    const FlatLane L = flat_lane(lane, Hc);
     // this lane's chunk of the first group, as (first column, row in it); every group moves all lanes by the same pixels
     const unsigned long long id0 = (unsigned long long)g + (unsigned long long)lane * G;
     const unsigned long long step_px = (unsigned long long)G * 64 * 256;
@@ -592,6 +644,7 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
     uint32_t col = (uint32_t)((id0 * 256) / (unsigned)Hc);
     uint32_t rem = (uint32_t)(id0 * 256 - (unsigned long long)col * (unsigned)Hc);
     u32x4* const out4 = reinterpret_cast<u32x4*>(out);
+    const unsigned long long dstep = (unsigned long long)G * 64;
     for (unsigned long long base = g; base < total_chunks; base += (unsigned long long)G * 64) {
         const unsigned long long id = base + (unsigned long long)lane * G;
         const bool exists = id < total_chunks;
@@ -622,45 +675,42 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
         col += dq; rem += dr;
         if (rem >= (unsigned)Hc) { rem -= (unsigned)Hc; col += 1; }
         __builtin_amdgcn_wave_barrier();                                     // (the lanes of a wavefront exchange through LDS: no reordering across)
-        const unsigned long long dstep = (unsigned long long)G * 64;
         u32x4* dst = out4 + base * 64;                                       // wave-uniform
-#pragma unroll 2
-        for (int t = 0; t < 64; ++t, dst += dstep) {
-            const int s_state = __builtin_amdgcn_readlane(state_l, t);
-            if (!(s_state & 1)) continue;                                    // wave-uniform: past the end
-            const int p0 = __builtin_amdgcn_readlane(rem_l, t) + 4 * lane;   // flat offset from the start of the chunk's first column
-            const int rel = fast_div(p0, Hc, inv_hc), r = p0 - rel * Hc;
-            const uint2 d0 = desc[t * KS + rel];
-            const int pad0 = (int)(d0.x & 0x7FFFFFFFu);
-            u32x4 v;
-            bool ok[4];
-            if (ALIGNED) {
-                v.x = pixel(r + 0, pad0, Hc, d0.y, ceil_c, floor_c);
-                v.y = pixel(r + 1, pad0, Hc, d0.y, ceil_c, floor_c);
-                v.z = pixel(r + 2, pad0, Hc, d0.y, ceil_c, floor_c);
-                v.w = pixel(r + 3, pad0, Hc, d0.y, ceil_c, floor_c);
-                ok[0] = ok[1] = ok[2] = ok[3] = (d0.x >> 31) != 0u;
-            } else {
-                const uint2 d1 = desc[t * KS + rel + 1];
-                const int pad1 = (int)(d1.x & 0x7FFFFFFFu);
-                uint32_t px[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool next = r + e >= Hc;                           // this pixel is in the following column
-                    px[e] = pixel(next ? r + e - Hc : r + e, next ? pad1 : pad0, Hc, next ? d1.y : d0.y, ceil_c, floor_c);
-                    ok[e] = ((next ? d1.x : d0.x) >> 31) != 0u;
-                }
-                v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
-            }
-            if (s_state & 2) {
+        if (__ballot(state_l == 3) == ~0ull) {
+            // every chunk of the group is whole and unmasked: no branch in the loop, the next chunk's pair(s) on their way
+            int rel, r, rel_n, r_n;
+            flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Hc, rel, r);
+            uint2 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
+#pragma unroll 4
+            for (int t = 0; t < 64; ++t, dst += dstep) {
+                const int tn = t < 63 ? t + 1 : 63;
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, tn), Hc, rel_n, r_n);
+                const uint2 n0 = desc[tn * KS + rel_n], n1 = ALIGNED ? n0 : desc[tn * KS + rel_n + 1];
+                bool ok[4];
+                const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
                 __builtin_nontemporal_store(v, dst + lane);
-            } else {                                                         // a masked agent's border / the batch's last chunk
-                const unsigned long long px0 = ((base + (unsigned long long)t * G) << 8) + 4u * (unsigned)lane;
-                uint32_t* const o = out + px0;
-                if (px0 + 0 < total_px && ok[0]) o[0] = v.x;
-                if (px0 + 1 < total_px && ok[1]) o[1] = v.y;
-                if (px0 + 2 < total_px && ok[2]) o[2] = v.z;
-                if (px0 + 3 < total_px && ok[3]) o[3] = v.w;
+                d0 = n0; d1 = n1; r = r_n;
+            }
+        } else {
+#pragma unroll 2
+            for (int t = 0; t < 64; ++t, dst += dstep) {
+                const int s_state = __builtin_amdgcn_readlane(state_l, t);
+                if (!(s_state & 1)) continue;                                // wave-uniform: past the end
+                int rel, r;
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, t), Hc, rel, r);
+                const uint2 d0 = desc[t * KS + rel], d1 = ALIGNED ? d0 : desc[t * KS + rel + 1];
+                bool ok[4];
+                const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
+                if (s_state & 2) {
+                    __builtin_nontemporal_store(v, dst + lane);
+                } else {                                                     // a masked agent's border / the batch's last chunk
+                    const unsigned long long px0 = ((base + (unsigned long long)t * G) << 8) + 4u * (unsigned)lane;
+                    uint32_t* const o = out + px0;
+                    if (px0 + 0 < total_px && ok[0]) o[0] = v.x;
+                    if (px0 + 1 < total_px && ok[1]) o[1] = v.y;
+                    if (px0 + 2 < total_px && ok[2]) o[2] = v.z;
+                    if (px0 + 3 < total_px && ok[3]) o[3] = v.w;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1641,6 +1691,9 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
         TopGroup cur;
         top_group_issue(p, mask, base, G, total, lane, cur);
         top_group_finish(p, L, cur);
+#if RCW_EXP == 11      // experiment: ~1 us of extra arithmetic per group in the prefetch phase (does the pause matter?)
+        { uint32_t acc = cur.code_lo; for (int q = 0; q < 600; ++q) asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(acc)); cur.code_lo ^= (acc & 0u); }
+#endif
         // the plane words go through a wave-private 2 KiB of LDS (index 8 t + word: lane l's register m is entry
         // 64 m + l), so that ONE loop over the 64 chunks can fetch them (a register per eight chunks would need eight
         // copies of the loop — and the compiler then carries all their store pointers through every one of them)
@@ -1656,11 +1709,18 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
                 const int s_flags = __builtin_amdgcn_readlane(cur.flags, t);
                 if (!(s_flags & 1)) continue;                                // wave-uniform: past the end / masked out
                 const uint32_t w = lw_read[8 * t];
+#if RCW_EXP == 12      // experiment: 20 extra dependent VALU instructions per chunk (does the chunk loop's arithmetic matter?)
+                uint32_t w2 = w; for (int q = 0; q < 20; ++q) asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(w2)); const uint32_t wx = w | (w2 & 0u);
+#define w wx
+#endif
                 const u32x4 o = top_chunk_pixels<WIDE>(L, w, (uint32_t)__builtin_amdgcn_readlane((int)cur.code_lo, t),
                                                        WIDE ? (uint32_t)__builtin_amdgcn_readlane((int)cur.code_hi, t) : 0u, s_flags,
                                                        (uint32_t)__builtin_amdgcn_readlane((int)cur.cmask, t),
                                                        __builtin_amdgcn_readlane(cur.r0, t));
                 store16<PLAIN>(dst + lane, o);
+#if RCW_EXP == 12
+#undef w
+#endif
             }
         }
     }
@@ -1788,34 +1848,156 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
 //   y, z: the 2-bit tile_map entries (bit 0 WALL, bit 1 GOAL: BitArray{3}(2, H, W) read as it lies in HBM, SR:54) of
 //      the 32 tiles of this image column from that tile row on — more than a 256-row run can touch from 9 pixels a tile
 //   w: the image row of the circle mask's bit 0 (ip - 1 - rp)
-// In the chunk loop a lane finds its column (flat offset / H·pu) and tile row (row / pu) with Float32 reciprocals,
+// In the chunk loop a lane finds its column without a division (flat_locate), and what depends on its row alone — the
+// tile row, which of its four pixels lie on a tile's frame rows (SR:364-365) and which in the following tile (pixel
+// scales that are not a multiple of 4) — in a table the workgroup builds once in LDS (one word per four rows).  It
 // reads its column's descriptor with one ds_read_b128 and its plane word, resolves circle > ray line > tile frame >
-// tile fill (SR:362-367, SR:473-477, SR:480) for its four pixels and writes them with one 16-byte store.  STRADDLE
-// (pu % 4 != 0): the four pixels may lie in two tiles.  The circle of any radius: SD.Circle's rows at column distance c
-// are the same for every agent (midpoint circle, assumed); the workgroup tabulates them in LDS once, as bit rows.
-template <bool PLAIN, bool STRADDLE>
+// tile fill (SR:362-367, SR:473-477, SR:480) with bit-field extracts and inserts, no compare, and writes its four
+// pixels with one 16-byte store.  A group whose 64 chunks are all whole and unmasked fetches the next chunk's three LDS
+// values while it computes this one's pixels.  The circle of any radius: SD.Circle's rows at column distance c are the
+// same for every agent (midpoint circle, assumed); the workgroup tabulates them in LDS once, as bit rows.
+template <int POS>
+__device__ __forceinline__ uint32_t bit_to_mask_c(uint32_t bits)                     // v_bfe_i32 with an inline-constant position
+{
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(POS));
+    return m;
+}
+// The row table (one entry per four image rows, i.e. per lane group): the tile row of the group's first pixel, and as
+// BYTE masks (0xFF / 0x00 in byte e for pixel e) which of the four pixels lie in the following tile and which on a
+// tile's first or last row (SR:364-365).
+__device__ __forceinline__ void top_row_entry(int r, int pu, uint32_t& ti_out, uint32_t& next_bytes, uint32_t& grid_bytes)
+{
+    const int ti = r / pu, ri = r - ti * pu;
+    ti_out = (uint32_t)ti; next_bytes = 0u; grid_bytes = 0u;
+    for (int e = 0; e < 4; ++e) {
+        const bool next = ri + e >= pu;
+        const int rie = next ? ri + e - pu : ri + e;
+        if (next) next_bytes |= 0xFFu << (8 * e);
+        if (rie == 0 || rie == pu - 1) grid_bytes |= 0xFFu << (8 * e);
+    }
+}
+// (four bits -> four byte masks: n · 0x204081 puts bit e at bit 8 e — the four shifted copies do not overlap — and
+// v_perm_b32's selector 0x0C yields the byte 0x00, 0x0D the byte 0xFF: nibble_to_bytes below)
+// All the top view's colours but one are greys (SR:288-290, SR:364-367: black, white, 0xcccccc grid, 0x808080 ray,
+// 0xc0c0c0 player) and the goal tile's red is 0xFF0000: a lane carries its four pixels as two packed words, R (the red
+// byte of each pixel) and GB (the byte that is both green and blue), so that every overlay is two v_bfi_b32 for all
+// four pixels — colour = circle > ray line > tile frame > tile fill (SR:362-367, SR:473-477, SR:480) — and one
+// v_perm_b32 per pixel unpacks them at the end.
+struct TopFlatConst { uint32_t sh0; int rp, cwt; const uint32_t* ctab; uint32_t k01, k0c; };
+// four bits -> four byte masks with the two constants in registers (v_mul_u32_u24, v_and_or_b32, v_perm_b32)
+__device__ __forceinline__ uint32_t nibble_to_bytes(const TopFlatConst& C, uint32_t n)
+{
+    return __builtin_amdgcn_perm(0u, 0u, (__umul24(n, 0x00204081u) & C.k01) | C.k0c);
+}
+// NARROW: a 256-row run touches at most 16 tiles (pu >= 19): the code window is one word (d.y) and d.z is the frame-column
+// word (0 / ~0); else the window is d.y | d.z << 32 and the frame column is bit 30 of d.x.
+template <bool STRADDLE, bool NARROW>
+__device__ __forceinline__ u32x4 top_flat_pixels(const TopFlatConst& C, int r, uint4 d, uint32_t w, uint32_t ti, uint32_t next_bytes,
+                                                 uint32_t grid_bytes, bool circle_chunk)
+{
+    const int trel = (int)ti - (int)(d.x & 0xFFFFu);
+    // this tile's 2 bits, then the next one's
+    const uint32_t c4 = NARROW ? d.y >> (2 * trel) : (uint32_t)((((unsigned long long)d.z << 32) | d.y) >> (2 * trel));
+    // tile fill: WALL (bit 0) white before GOAL (bit 1) red, else black  SR:355-360, colours SR:288
+    uint32_t GB = bit_to_mask_c<0>(c4);                                      // all four bytes alike: 0xFF where white
+    uint32_t R = GB | bit_to_mask_c<1>(c4);
+    if (STRADDLE) {
+        const uint32_t GB1 = bit_to_mask_c<2>(c4), R1 = GB1 | bit_to_mask_c<3>(c4);
+        GB = bfi(next_bytes, GB1, GB); R = bfi(next_bytes, R1, R);
+    }
+    const uint32_t gm = grid_bytes | (NARROW ? d.z : bit_to_mask_c<30>(d.x));   // frame rows SR:364-365 | the tile's frame columns SR:366-367
+    GB = bfi(gm, 0xCCCCCCCCu, GB); R = bfi(gm, 0xCCCCCCCCu, R);
+    const uint32_t rm = nibble_to_bytes(C, __builtin_amdgcn_ubfe(w, C.sh0, 4));   // ray lines SR:473-477
+    GB = bfi(rm, 0x80808080u, GB); R = bfi(rm, 0x80808080u, R);
+    if (circle_chunk) {                                                      // wave-uniform: some column of the chunk crosses the player's circle
+        const int q0 = r - (int)d.w;                                         // mask bit of this lane's first pixel
+        if ((d.x & 0x20000000u) && q0 > -4 && q0 <= 2 * C.rp) {
+            const int bidx = q0 + 32;                                        // (the row's leading zero word absorbs q0 < 0)
+            const uint32_t* const row = C.ctab + ((d.x >> 16) & 0x1FFFu) * C.cwt + (bidx >> 5);
+            const uint32_t cb = (uint32_t)((((unsigned long long)row[1] << 32) | row[0]) >> (bidx & 31));
+            const uint32_t cm = nibble_to_bytes(C, cb & 15u);
+            GB = bfi(cm, 0xC0C0C0C0u, GB); R = bfi(cm, 0xC0C0C0C0u, R);
+        }
+    }
+    u32x4 o;                                                                 // pixel e = 0x00 | R[e] | GB[e] | GB[e]
+    o.x = __builtin_amdgcn_perm(R, GB, 0x0C040000u); o.y = __builtin_amdgcn_perm(R, GB, 0x0C050101u);
+    o.z = __builtin_amdgcn_perm(R, GB, 0x0C060202u); o.w = __builtin_amdgcn_perm(R, GB, 0x0C070303u);
+    return o;
+}
+
+// Global loads whose completion the COMPILER does not track (the store kernels' descriptor prefetch).  gfx9 counts loads
+// and stores in one in-order counter (vmcnt): the wait the compiler inserts before the first use of a loaded value that
+// was issued ahead of a loop of stores is vmcnt(0..few) — it waits for the loads AND drains every store behind them,
+// and the descriptor arithmetic that follows then runs with nothing of this wavefront in flight; all wavefronts do so
+// at the same moments (they run in lockstep, which the moving window needs), so the memory system idles through it.
+// Issued like this and awaited with flat_wait_loads<63>() — "at most 63 operations outstanding" = everything older
+// than the 63 newest, i.e. all loads that were followed by at least 63 stores — the stores stay in flight while the
+// descriptors are made.  The destination registers must not be read or copied between the load and the wait: they are
+// written and awaited inside ONE loop iteration (no loop-carried copies), and the wait names them as in/out operands.
+__device__ __forceinline__ void flat_load_b32(uint32_t& dst, const uint32_t* addr) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void flat_load_u8(uint32_t& dst, const uint8_t* addr) { asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void flat_load_b64(unsigned long long& dst, const void* addr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void flat_load_b96(u32x3& dst, const void* addr) { asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void flat_load_b128(u32x4& dst, const void* addr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
+// floor(n / d) as fast_div, for n, d < 2^15: the products fit v_mul_u32_u24 (full rate; v_mul_lo_u32 takes four passes)
+__device__ __forceinline__ int fast_div24(int n, int d, float inv_d)
+{
+    int q = (int)((float)n * inv_d);
+    q -= ((int)__umul24((uint32_t)q, (uint32_t)d) > n) ? 1 : 0;
+    q += ((int)__umul24((uint32_t)(q + 1), (uint32_t)d) <= n) ? 1 : 0;
+    return q;
+}
+
+// what a lane holds of the wavefront's l-th next chunk between the loads and their use (one group ahead); K = the image
+// columns a chunk may touch (a template parameter: every load below is unconditional straight-line code, see flat_load_b32)
+template <int K>
+struct TopFlatPre {
+    uint32_t rem, j0, a0;                // the chunk's first pixel: row in its image column, that column, its agent
+    int touched, ti_first;               // its last column (relative; -1: no such chunk), the tile row of its first pixel
+    bool full, two;                      // all 256 pixels lie inside the batch; they belong to two agents
+    unsigned long long hd[2]; uint32_t mk[2];   // player pixel (ip | jp << 32) / mask byte of the first pixel's agent and of the following one
+    u32x3 tw[K];                         // three tile_map words from each touched column's code window on
+    u32x4 pa[2], pb[2];                  // the chunk's 8 plane words in the first pixel's agent's region and in the following agent's
+};
+// wait until at most N vector-memory operations are outstanding; names every loaded register as in/out
+template <int N, int K>
+__device__ __forceinline__ void flat_wait_loads(TopFlatPre<K>& P)
+{
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(P.hd[0]), "+v"(P.hd[1]), "+v"(P.mk[0]), "+v"(P.mk[1]), "+v"(P.pa[0]), "+v"(P.pa[1]), "+v"(P.pb[0]), "+v"(P.pb[1])
+                 : "n"(N) : "memory");
+#pragma unroll
+    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(P.tw[j]) :: "memory");
+}
+
+template <bool STRADDLE, bool NARROW, int K>
 __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev p, const uint8_t* __restrict__ mask,
                                                                     uint32_t chunk_begin, uint32_t chunk_end,
-                                                                    int agent_lo, int agent_hi, int K)
+                                                                    int agent_lo, int agent_hi)
 {
+    constexpr bool PLAIN = false;                                          // (non-temporal stores, as every window kernel)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t G = gridDim.x * (kBlock / 64);
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(wave);
-    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp, KS = K;
+    const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
+    constexpr int KS = K;
     const float inv_ht = 1.0f / (float)Ht, inv_pu = 1.0f / (float)pu;
-    const uint32_t ray_c = 0x00808080u, player_c = 0x00c0c0c0u, grid_c = 0x00ccccccu;   // SR:289-290, SR:364-367
     const unsigned px_agent = (unsigned)Ht * (unsigned)Wt;
     const unsigned long long total_px = (unsigned long long)p.B * px_agent;
     const unsigned PW = (unsigned)p.top_plane_words;
-    // LDS: [4 wavefronts][512 plane words] | [4 wavefronts][64 chunks][KS] descriptors | the circle's bit rows
+    // LDS: [4 wavefronts][512 plane words] | [4 wavefronts][64 chunks][KS] descriptors | the circle's bit rows | the row table
     uint32_t* const lw = lds + wave * 512;
-    uint32_t* const lw_write = lw + lane;
     const uint32_t* const lw_read = lw + (lane >> 3);
     uint4* const desc = reinterpret_cast<uint4*>(lds + (kBlock / 64) * 512) + (size_t)wave * 64 * KS;
     uint32_t* const ctab = lds + (kBlock / 64) * 512 + (size_t)(kBlock / 64) * 64 * KS * 4;
     const int cnw = (2 * rp + 1 + 31) / 32, cwt = cnw + 2;                 // a row: [zero word | 2 rp + 1 mask bits | zero word]
+    // the row table: one 16-byte entry per four rows (tile row | next-tile bytes | frame-row bytes | -), behind the circle rows
+    uint4* const rtab = reinterpret_cast<uint4*>(ctab + (((rp + 1) * cwt + 3) & ~3));
     for (int k = threadIdx.x; k < (rp + 1) * cwt; k += kBlock) ctab[k] = 0u;
+    for (int k = threadIdx.x; k < (Ht >> 2); k += kBlock) { uint4 e; e.w = 0u; top_row_entry(4 * k, pu, e.x, e.y, e.z); rtab[k] = e; }
     __syncthreads();
     for (int c = threadIdx.x; c <= rp; c += kBlock) {                      // SD.Circle SR:480 (midpoint circle, assumed)
         uint32_t* const row = ctab + c * cwt + 1;
@@ -1830,6 +2012,11 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
         }
     }
     __syncthreads();
+    const FlatLane L = flat_lane(lane, Ht);
+    TopFlatConst C;
+    C.sh0 = (uint32_t)(4 * lane) & 31u; C.rp = rp; C.cwt = cwt; C.ctab = ctab; C.k01 = 0x01010101u; C.k0c = 0x0C0C0C0Cu;
+    asm volatile("" : "+v"(C.k01), "+v"(C.k0c));                             // (in registers: two literals do not fit one v_and_or_b32)
+    const uint32_t lane16 = (uint32_t)lane * 16u;                            // the store's address: uniform chunk base + this
     // this lane's chunk of the first group as (image column of the flat batch, row in it); every group moves all lanes alike
     const unsigned long long id0 = (unsigned long long)chunk_begin + g + (unsigned long long)lane * G;
     const unsigned long long step_px = (unsigned long long)G * 64 * 256;
@@ -1838,123 +2025,163 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     uint32_t rem = (uint32_t)(id0 * 256 - (unsigned long long)col * (unsigned)Ht);
     u32x4* const out4 = reinterpret_cast<u32x4*>(p.top_view);
     const size_t dstep = (size_t)G * 64;
-    for (uint32_t base = chunk_begin + g; base < chunk_end; base += G * 64) {
+    const uint32_t last_agent = (uint32_t)p.B - 1u, last_word = (uint32_t)p.nwords - 1u;
+
+    // The loads of a group: every address is clamped into its array instead of the load being predicated (a predicated
+    // load is a branch around it), nothing here waits.  They are issued ONE GROUP AHEAD — before the 64 stores of the
+    // current group — so that their latency passes while the wavefront stores, and awaited with flat_wait_loads.  What a
+    // wavefront does between two groups' stores is time the whole chip spends not storing (the wavefronts run in lockstep):
+    // (column, agent) of a lane's next chunk are carried from group to group, tile rows come from the row table, the three
+    // tile_map words of a column are one 12-byte load, a chunk's plane words two 16-byte loads by the chunk's own lane.
+    uint32_t a_cur = col / (unsigned)Wt, j_cur = col - a_cur * (unsigned)Wt;      // (agent, image column) of this lane's next chunk
+    const uint32_t dqa = dq / (unsigned)Wt, dqj = dq - dqa * (unsigned)Wt;        // ... move by this much a group (+ 1 column on a row wrap)
+    const uint32_t chunks_agent_lo = (uint32_t)(px_agent >> 8);                   // (floor of an image's chunks; the exact first chunk: 64-bit product)
+    auto issue = [&](uint32_t base, TopFlatPre<K>& P) {
         const uint32_t id = base + (uint32_t)lane * G;
         const bool exists = id < chunk_end;
-        const int touched = exists ? fast_div((int)rem + 255, Ht, inv_ht) : -1;      // the chunk's last column, relative
-        const uint32_t a0 = col / (unsigned)Wt, j0 = col - a0 * (unsigned)Wt;
-        const int ti_first = fast_div((int)rem, pu, inv_pu);                         // tile row of the chunk's first pixel
-        // ---- loads (all issued before any is used) ----
-        int2 hd[kFlatMaxCols];
-        uint32_t tw[kFlatMaxCols][3], mk[kFlatMaxCols];
-        uint32_t aa[kFlatMaxCols], jj[kFlatMaxCols];
+        P.rem = rem; P.a0 = a_cur; P.j0 = j_cur;
+        int touched = 0;
 #pragma unroll
-        for (int j = 0; j < kFlatMaxCols; ++j) {
-            uint32_t jx = j0 + (unsigned)j, a = a0;
-            if (jx >= (unsigned)Wt) { jx -= (unsigned)Wt; a += 1; }
-            aa[j] = a; jj[j] = jx;
-            const bool in = j <= touched && (int)a >= agent_lo && (int)a < agent_hi;
-            const int tj = fast_div((int)jx, pu, inv_pu);
-            const int t0 = p.H * tj + (j == 0 ? ti_first : 0);                       // first tile of the code window (linear, 0-based)
-            const int wi = t0 >> 4;
-            const uint32_t* const tm = p.tile_map + (size_t)(in ? a : 0u) * p.nwords;
-            mk[j] = in ? (mask != nullptr ? (uint32_t)mask[a] : 1u) : 0u;
-            hd[j] = in ? p.top_hdr[a] : make_int2(0, 0);
+        for (int k = 1; k < K; ++k) touched += (rem + 255u >= (unsigned)(k * Ht)) ? 1 : 0;
+        P.touched = exists ? touched : -1;
+        P.ti_first = (int)rtab[rem >> 2].x;                                  // (rem is a multiple of 4)
+        P.full = ((unsigned long long)id + 1) * 256 <= total_px;
+        P.two = P.j0 + (unsigned)touched >= (unsigned)Wt;
+        const uint32_t a0c = min(P.a0, last_agent), a1c = min(P.a0 + 1u, last_agent);
+        flat_load_b64(P.hd[0], p.top_hdr + a0c); flat_load_b64(P.hd[1], p.top_hdr + a1c);
+        P.mk[0] = P.mk[1] = 1u;
+        if (mask != nullptr) { flat_load_u8(P.mk[0], mask + a0c); flat_load_u8(P.mk[1], mask + a1c); }   // wave-uniform
+        const uint32_t* const tm0 = p.tile_map + (size_t)a0c * p.nwords;
+        const uint32_t* const tm1 = p.tile_map + (size_t)a1c * p.nwords;
+        int tj = fast_div24((int)P.j0, pu, inv_pu), rj = (int)P.j0 - (int)__umul24((uint32_t)tj, (uint32_t)pu);
+        uint32_t jx = P.j0;
+        const uint32_t* tm = tm0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) tw[j][k] = (in && wi + k < p.nwords) ? tm[wi + k] : 0u;
+        for (int j = 0; j < K; ++j) {
+            const uint32_t wi = (__umul24((uint32_t)p.H, (uint32_t)tj) + (j == 0 ? (uint32_t)P.ti_first : 0u)) >> 4;   // word of the code window's first tile
+            flat_load_b96(P.tw[j], tm + min(wi, last_word));                 // (two words of slack lie behind the last agent's map)
+            jx += 1; rj += 1;
+            if (rj == pu) { rj = 0; tj += 1; }
+            if (jx == (unsigned)Wt) { jx = 0; tj = 0; rj = 0; tm = tm1; }   // the following agent's first column
         }
-        // the chunk's 8 plane words, of the first pixel's agent and (a chunk that straddles two agents) of the last pixel's
-        int woff_a = -1, woff_b = -1;
-        if (exists) {
-            const uint32_t a_last = touched >= 0 ? aa[0] + ((j0 + (unsigned)touched >= (unsigned)Wt) ? 1u : 0u) : a0;
-            if (a0 < (unsigned)p.B) woff_a = (int)(a0 * PW + (id - (uint32_t)(((unsigned long long)a0 * px_agent) >> 8)) * 8u);
-            if (a_last != a0 && a_last < (unsigned)p.B) woff_b = (int)(a_last * PW);
-        }
-        uint32_t pw[8];
+        // the chunk's 8 plane words in the region of the first pixel's agent, and (read as zero unless the chunk straddles
+        // two agents) the first 8 of the following agent's region
+        const uint32_t c0 = (uint32_t)(((unsigned long long)a0c * px_agent) >> 8);
+        const uint32_t* const pwa = p.top_plane + (size_t)a0c * PW + (size_t)(exists ? id - c0 : 0u) * 8u;
+        const uint32_t* const pwb = p.top_plane + (size_t)a1c * PW;
+        flat_load_b128(P.pa[0], pwa); flat_load_b128(P.pa[1], pwa + 4);
+        flat_load_b128(P.pb[0], pwb); flat_load_b128(P.pb[1], pwb + 4);
+        // this lane's chunk of the next group
+        col += dq; rem += dr;
+        uint32_t jn = j_cur + dqj;
+        if (rem >= (unsigned)Ht) { rem -= (unsigned)Ht; col += 1; jn += 1; }
+        a_cur += dqa;
+        if (jn >= (unsigned)Wt) { jn -= (unsigned)Wt; a_cur += 1; }
+        j_cur = jn;
+    };
+    // ... and their use: the descriptors and plane words of the group into wave-private LDS
+    auto finish = [&](const TopFlatPre<K>& P, int& state_l, int& rem_l) {
+        bool all_valid = P.touched >= 0 && P.full, any_circle = false;
+        int tj = fast_div24((int)P.j0, pu, inv_pu), rj = (int)P.j0 - (int)__umul24((uint32_t)tj, (uint32_t)pu);
+        uint32_t jx = P.j0, a = P.a0;
+        int second = 0;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int wa = __shfl(woff_a, 8 * m + (lane >> 3), 64), wb = __shfl(woff_b, 8 * m + (lane >> 3), 64);
-            const uint32_t x = wa >= 0 ? p.top_plane[(size_t)wa + (lane & 7)] : 0u;
-            const uint32_t y = wb >= 0 ? p.top_plane[(size_t)wb + (lane & 7)] : 0u;
-            pw[m] = x | y;
-        }
-        // ---- descriptors ----
-        bool all_valid = exists && ((unsigned long long)id + 1) * 256 <= total_px, any_circle = false;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < kFlatMaxCols; ++j) {
-            if (j >= KS) break;                                              // wave-uniform
-            const bool valid = mk[j] != 0u;
-            if (j <= touched && !valid) all_valid = false;
-            const int tj = fast_div((int)jj[j], pu, inv_pu), rj = (int)jj[j] - tj * pu;
-            const int ti_lo = j == 0 ? ti_first : 0;
-            const int sh = ((p.H * tj + ti_lo) & 15) * 2;
-            const uint32_t lo = (uint32_t)((((unsigned long long)tw[j][1] << 32) | tw[j][0]) >> sh);
-            const uint32_t hi = (uint32_t)((((unsigned long long)tw[j][2] << 32) | tw[j][1]) >> sh);
-            const int dist = abs((int)jj[j] + 1 - hd[j].y), r0 = hd[j].x - 1 - rp;
+        for (int j = 0; j < K; ++j) {
+            const bool valid = j <= P.touched && (int)a >= agent_lo && (int)a < agent_hi && (second ? P.mk[1] : P.mk[0]) != 0u;
+            if (j <= P.touched && !valid) all_valid = false;
+            const int ti_lo = j == 0 ? P.ti_first : 0;
+            const int sh = (int)((__umul24((uint32_t)p.H, (uint32_t)tj) + (uint32_t)ti_lo) & 15u) * 2;
+            // ({w1, w0} >> sh) and ({w2, w1} >> sh), sh < 32: v_alignbit_b32 by name (written as 64-bit shifts the compiler
+            // pairs the words up in registers where they are LOADED, with a copy of w1 in between)
+            uint32_t lo, hi = 0u;
+            asm("v_alignbit_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(P.tw[j].y), "v"(P.tw[j].x), "v"(sh));
+            if (!NARROW) asm("v_alignbit_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(P.tw[j].z), "v"(P.tw[j].y), "v"(sh));
+            const unsigned long long hd = second ? P.hd[1] : P.hd[0];
+            const int dist = abs((int)jx + 1 - (int)(hd >> 32)), r0 = (int)(uint32_t)hd - 1 - rp;
             const bool circle = valid && dist <= rp;
             any_circle = any_circle || circle;
-            const uint32_t x = (valid ? 0x80000000u : 0u) | ((rj == 0 || rj == pu - 1) ? 0x40000000u : 0u) |
+            const bool frame = rj == 0 || rj == pu - 1;
+            const uint32_t x = (valid ? 0x80000000u : 0u) | (frame ? 0x40000000u : 0u) |
                                (circle ? 0x20000000u : 0u) | ((uint32_t)(circle ? dist : 0) << 16) | (uint32_t)ti_lo;
-            desc[lane * KS + j] = make_uint4(x, lo, hi, (uint32_t)r0);
+            desc[lane * KS + j] = make_uint4(x, lo, NARROW ? (frame ? 0xFFFFFFFFu : 0u) : hi, (uint32_t)r0);
+            jx += 1; rj += 1;
+            if (rj == pu) { rj = 0; tj += 1; }
+            if (jx == (unsigned)Wt) { jx = 0; tj = 0; rj = 0; a += 1; second = 1; }
         }
-#pragma unroll
-        for (int m = 0; m < 8; ++m) lw_write[64 * m] = pw[m];
-        const int state_l = (exists ? 1 : 0) | (all_valid ? 2 : 0) | (any_circle ? 4 : 0);
-        const int rem_l = (int)rem;
-        col += dq; rem += dr;
-        if (rem >= (unsigned)Ht) { rem -= (unsigned)Ht; col += 1; }
-        __builtin_amdgcn_wave_barrier();
-        u32x4* dst = out4 + (size_t)base * 64;                               // wave-uniform
+        const uint32_t mb = (P.two && P.a0 + 1u <= last_agent) ? 0xFFFFFFFFu : 0u;
+        u32x4* const lw4 = reinterpret_cast<u32x4*>(lw + lane * 8);          // plane word w of the wavefront's chunk c: lw[8 c + w]
+        lw4[0] = P.pa[0] | (P.pb[0] & mb); lw4[1] = P.pa[1] | (P.pb[1] & mb);
+        state_l = (P.touched >= 0 ? 1 : 0) | (all_valid ? 2 : 0) | (any_circle ? 4 : 0);
+        rem_l = (int)P.rem;
+    };
+
+    // the 64 chunks of a group: descriptors, plane words and the row table from LDS -> pixels -> stores.  Returns whether
+    // exactly 64 stores went out (the branch-free loop), which is what flat_wait_loads<63> may rely on.
+    auto store_group = [&](uint32_t base, int state_l, int rem_l) -> bool {
+        char* dst = reinterpret_cast<char*>(out4) + (size_t)base * 1024;     // wave-uniform: the chunk's first byte
+        const size_t dstep_b = dstep * 16;
+        auto put = [&](const u32x4& o) { store16<PLAIN>(reinterpret_cast<u32x4*>(dst + lane16), o); };
+        if (__ballot((state_l & 3) == 3) == ~0ull) {
+            // every chunk of the group is whole and unmasked: the next chunk's LDS values on their way while this one's pixels are made
+            const unsigned long long circle_chunks = __ballot((state_l & 4) != 0);   // bit t: chunk t crosses a player's circle
+            int rel, r, rel_n, r_n;
+            flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Ht, rel, r);
+            uint4 d = desc[rel];
+            uint32_t w = lw_read[0];
+            uint4 re = rtab[r >> 2];
+#pragma unroll RCW_EXP_UNROLL
+            for (int t = 0; t < 64; ++t, dst += dstep_b) {
+                // (the last trip fetches a 65th chunk's values: lane 0's row again — v_readlane takes the lane number modulo
+                // 64 — and whatever lies behind this wavefront's descriptors and plane words in the workgroup's LDS; unused)
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Ht, rel_n, r_n);
+#if RCW_EXP == 9       // experiment: 4-byte instead of 16-byte LDS reads (wrong pixels, timing only): is it the LDS return traffic?
+                const uint32_t dx_ = desc[(t + 1) * KS + rel_n].x, rx_ = rtab[r_n >> 2].x;
+                const uint4 d_n = make_uint4(dx_, dx_, dx_, dx_), re_n = make_uint4(rx_ & 0xFFFFu, rx_, rx_, 0u);
+#else
+                const uint4 d_n = desc[(t + 1) * KS + rel_n];
+                const uint4 re_n = rtab[r_n >> 2];
+#endif
+                const uint32_t w_n = lw_read[8 * (t + 1)];
+                put(top_flat_pixels<STRADDLE, NARROW>(C, r, d, w, re.x, re.y, re.z, ((circle_chunks >> t) & 1ull) != 0));
+                d = d_n; w = w_n; re = re_n; r = r_n;
+            }
+            return true;
+        }
 #pragma unroll 2
-        for (int t = 0; t < 64; ++t, dst += dstep) {
+        for (int t = 0; t < 64; ++t, dst += dstep_b) {
             const int s_state = __builtin_amdgcn_readlane(state_l, t);
             if (!(s_state & 1)) continue;                                    // wave-uniform: past the end
-            const int p0 = __builtin_amdgcn_readlane(rem_l, t) + 4 * lane;   // flat offset from the start of the chunk's first column
-            const int rel = fast_div(p0, Ht, inv_ht), r = p0 - rel * Ht;
+            int rel, r;
+            flat_locate(L, __builtin_amdgcn_readlane(rem_l, t), Ht, rel, r);
             const uint4 d = desc[t * KS + rel];
-            const uint32_t w = lw_read[8 * t];
-            const int ti = fast_div(r, pu, inv_pu), ri = r - ti * pu;
-            const int trel = ti - (int)(d.x & 0xFFFFu);
-            const uint32_t c4 = (uint32_t)((((unsigned long long)d.z << 32) | d.y) >> (2 * trel));   // this tile's 2 bits, then the next one's
-            const uint32_t fill0 = bfi(bit_to_mask(c4, 0), 0x00FFFFFFu, bit_to_mask(c4, 1) & 0x00FF0000u);   // wall before goal SR:355-360, colours SR:288
-            u32x4 o;
-            if (STRADDLE) {
-                const uint32_t fill1 = bfi(bit_to_mask(c4, 2), 0x00FFFFFFu, bit_to_mask(c4, 3) & 0x00FF0000u);
-                uint32_t px[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool next = ri + e >= pu;                          // this pixel is in the following tile
-                    const int rie = next ? ri + e - pu : ri + e;
-                    px[e] = (rie == 0 || rie == pu - 1) ? grid_c : (next ? fill1 : fill0);   // SR:364-365
-                }
-                o.x = px[0]; o.y = px[1]; o.z = px[2]; o.w = px[3];
-            } else {
-                o.x = ri == 0 ? grid_c : fill0;                              // SR:364-365: the tile's frame rows
-                o.y = fill0; o.z = fill0;
-                o.w = ri + 3 == pu - 1 ? grid_c : fill0;
-            }
-            const uint32_t frame = bit_to_mask(d.x, 30);                     // SR:366-367: the tile's frame columns
-            o.x = bfi(frame, grid_c, o.x); o.y = bfi(frame, grid_c, o.y); o.z = bfi(frame, grid_c, o.z); o.w = bfi(frame, grid_c, o.w);
-            const uint32_t sh = (uint32_t)(4 * lane) & 31u;
-            o.x = bfi(bit_to_mask(w, sh), ray_c, o.x);     o.y = bfi(bit_to_mask(w, sh + 1), ray_c, o.y);
-            o.z = bfi(bit_to_mask(w, sh + 2), ray_c, o.z); o.w = bfi(bit_to_mask(w, sh + 3), ray_c, o.w);
-            if (s_state & 4) {                                               // some column of the chunk crosses the player's circle
-                const int q0 = r - (int)d.w;                                 // mask bit of this lane's first pixel
-                if ((d.x & 0x20000000u) && q0 > -4 && q0 <= 2 * rp) {
-                    const int bidx = q0 + 32;                                // (the row's leading zero word absorbs q0 < 0)
-                    const uint32_t* const row = ctab + ((d.x >> 16) & 0x1FFFu) * cwt + (bidx >> 5);
-                    const uint32_t cb = (uint32_t)((((unsigned long long)row[1] << 32) | row[0]) >> (bidx & 31));
-                    o.x = bfi(bit_to_mask(cb, 0), player_c, o.x); o.y = bfi(bit_to_mask(cb, 1), player_c, o.y);
-                    o.z = bfi(bit_to_mask(cb, 2), player_c, o.z); o.w = bfi(bit_to_mask(cb, 3), player_c, o.w);
-                }
-            }
-            if (s_state & 2) store16<PLAIN>(dst + lane, o);                  // every pixel of the chunk is written
+            const uint4 re = rtab[r >> 2];
+            const u32x4 o = top_flat_pixels<STRADDLE, NARROW>(C, r, d, lw_read[8 * t], re.x, re.y, re.z, (s_state & 4) != 0);
+            if (s_state & 2) put(o);                                         // every pixel of the chunk is written
             else if ((d.x >> 31) && (((unsigned long long)(base + (uint32_t)t * G)) << 8) + 4u * (unsigned)lane < total_px)
-                store16<PLAIN>(dst + lane, o);                               // a chunk at a masked agent's / a run's border, the batch's last chunk
+                put(o);                                                      // a chunk at a masked agent's / a run's border, the batch's last chunk
         }
+        return false;
+    };
+
+    uint32_t base = chunk_begin + g;
+    if (base >= chunk_end) return;
+    TopFlatPre<K> P = {};
+    int state_l = 0, rem_l = 0;
+    issue(base, P); flat_wait_loads<0, K>(P); finish(P, state_l, rem_l);
+    while (base + G * 64 < chunk_end) {                                      // (wave-uniform) there is a next group:
+        // its loads go out now, ahead of this group's stores, and are awaited behind them — in one straight line, every
+        // iteration, so that no register copy can come between a load and its wait (tools/check_async_loads.py)
         __builtin_amdgcn_wave_barrier();
+        issue(base + G * 64, P);
+        const bool stored_64 = store_group(base, state_l, rem_l);
+        __builtin_amdgcn_wave_barrier();
+        if (!stored_64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (fewer than 64 stores behind the loads: wait for everything; names no register)
+        flat_wait_loads<63, K>(P);
+        finish(P, state_l, rem_l);                                           // ... while this group's stores drain
+        base += G * 64;
     }
+    __builtin_amdgcn_wave_barrier();
+    store_group(base, state_l, rem_l);
 }
 
 }  // namespace
@@ -2105,13 +2332,18 @@ int rcw_top_split_unit(const RcwDev& p)
 // rcw_top_store_flat_kernel: the image columns a 256-pixel chunk can touch in this geometry; 0: the kernel does not take it
 static size_t top_circle_table_bytes(const RcwDev& p) { return (size_t)(p.top_rp + 1) * ((2 * p.top_rp + 1 + 31) / 32 + 2) * 4; }
 static size_t top_flat_plane_words(const RcwDev& p) { return (((size_t)p.H * p.pu * p.W * p.pu + 255 + 255) / 256) * 8; }
+static size_t top_store_flat_lds_bytes(const RcwDev& p, int K)             // plane words | descriptors | circle rows | row table
+{
+    return (size_t)(kBlock / 64) * 512 * 4 + (size_t)(kBlock / 64) * 64 * K * 16 + ((top_circle_table_bytes(p) + 15) & ~(size_t)15) + (size_t)4 * p.H * p.pu;
+}
 int rcw_top_flat_cols(const RcwDev& p)
 {
     const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
     if (p.pu < 9 || (Ht & 3) != 0 || Ht > 16384 || Wt > 16384 || p.H > 65535 || p.top_rp > 8191) return 0;
     const int K = (int)(251 / Ht) + 2;
-    if (K > kFlatMaxCols) return 0;
+    if (K > 7) return 0;                                                              // (the store kernel is instantiated for 2..7)
     if (top_circle_table_bytes(p) > 16 * 1024) return 0;
+    if (top_store_flat_lds_bytes(p, K) > 64 * 1024) return 0;                                 // (plane words, descriptors, circle rows, row table: the default limit is kept)
     if (4 * top_buf_words(p) > 156 * 1024) return 0;                                          // the draw kernel's LDS plane
     const long long chunks = ((long long)p.B * Ht * Wt + 255) / 256;
     if ((long long)p.B * Wt >= (1ll << 31) - 64) return 0;                                    // image columns of the flat batch in 32 bits
@@ -2125,10 +2357,6 @@ size_t rcw_top_plane_bytes(const RcwDev& p)
     return (size_t)p.B * p.W * p.pu * ((size_t)p.H * p.pu / 32) * 4 + 64;                     // (+ a short last chunk's reach)
 }
 int32_t rcw_top_plane_words(const RcwDev& p) { return (int32_t)top_flat_plane_words(p); }
-static size_t top_store_flat_lds_bytes(const RcwDev& p)
-{
-    return (size_t)(kBlock / 64) * 512 * 4 + (size_t)(kBlock / 64) * 64 * p.top_flat * 16 + top_circle_table_bytes(p);
-}
 size_t rcw_top_codes_bytes(const RcwDev& p)
 {
     if (p.top_flat) return 64;                                              // (the flat store kernel reads tile_map itself)
@@ -2149,11 +2377,14 @@ hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int fi
         // the chunks of the flat batch that hold a pixel of agents [first, first + count)
         const unsigned long long px = (unsigned long long)p.H * p.pu * p.W * p.pu;
         const uint32_t c0 = (uint32_t)((px * (unsigned)first) >> 8), c1 = (uint32_t)((px * (unsigned)(first + count) + 255) >> 8);
-        const size_t lds = top_store_flat_lds_bytes(p);
+        const size_t lds = top_store_flat_lds_bytes(p, p.top_flat);
         const bool straddle = (p.pu & 3) != 0;
-#define RCW_FLAT(PL, ST) hipLaunchKernelGGL((rcw_top_store_flat_kernel<PL, ST>), grid, block, lds, s, p, mask_dev, c0, c1, first, first + count, p.top_flat)
-        if (p.top_store_plain) { if (straddle) RCW_FLAT(true, true); else RCW_FLAT(true, false); }
-        else                   { if (straddle) RCW_FLAT(false, true); else RCW_FLAT(false, false); }
+        const bool narrow = p.pu >= 19;                                      // 255 / pu + 2 <= 16 tiles in a 256-row run: one word of codes
+#define RCW_FLAT(ST, NA, KK) hipLaunchKernelGGL((rcw_top_store_flat_kernel<ST, NA, KK>), grid, block, lds, s, p, mask_dev, c0, c1, first, first + count)
+#define RCW_FLAT_K(KK) case KK: if (straddle) { if (narrow) RCW_FLAT(true, true, KK); else RCW_FLAT(true, false, KK); } \
+                                else          { if (narrow) RCW_FLAT(false, true, KK); else RCW_FLAT(false, false, KK); } break
+        switch (p.top_flat) { RCW_FLAT_K(2); RCW_FLAT_K(3); RCW_FLAT_K(4); RCW_FLAT_K(5); RCW_FLAT_K(6); RCW_FLAT_K(7); default: return hipErrorInvalidValue; }
+#undef RCW_FLAT_K
 #undef RCW_FLAT
         return hipGetLastError();
     }

@@ -168,14 +168,25 @@ def test_expand_columns_reproduces_frames(rcw, oracle):
 
 
 def test_odd_camera_heights(rcw, oracle):
-    """H_cam other than 256: the moving-window kernel for 64 / 128 / 512 / 768 (chunks of whole columns or row blocks),
-    the frame-per-workgroup kernel for the rest (250: 16-byte stores; 37: 4-byte stores; 64 with N % 4 != 0), with a
-    masked reset in between (the mask path of each kernel)."""
+    """H_cam other than 256 (height_camera_view_pu, SR:271): the moving-window kernel for 64 / 128 / 512 / 768 (chunks of
+    whole columns or row blocks); rcw_fill_flat_kernel — 256-pixel chunks of the flat batch, each lane finding its own
+    column — for every other height from 37 rows (84, 100, 300: 16-byte groups inside one column; 250, 37, 99, 257: groups
+    that straddle two columns; batches whose pixel count is not a multiple of 256 or of 4: a short last chunk); the
+    frame-per-workgroup kernel below 37 rows (36: 16-byte stores; 21: 4-byte stores); with a masked reset in between
+    (the mask path of each kernel: chunks at a masked agent's border are written pixel by pixel)."""
     rng = np.random.default_rng(1)
-    for hc, cfg in ((64, CFG1), (128, CFG1), (512, CFG1), (768, CFG1), (250, CFG1), (37, CFG1), (84, CFG2),
+    want = {64: "rcw_fill_window_kernel", 128: "rcw_fill_window_kernel", 512: "rcw_fill_window_kernel", 768: "rcw_fill_window_kernel",
+            36: "rcw_fill_frame_kernel", 21: "rcw_fill_frame_kernel"}
+    for hc, cfg in ((64, CFG1), (128, CFG1), (512, CFG1), (768, CFG1), (250, CFG1), (37, CFG1), (84, CFG2), (100, CFG2), (300, CFG1),
+                    (99, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=33)),     # 9 x 33 x 99 pixels: not a multiple of 4
+                    (257, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=65)),
+                    (1000, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=31)),
+                    (36, CFG1), (21, CFG1),
                     (64, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=66)),
                     (128, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=33))):
         env, orc = _make(rcw, oracle, 9, seed=3, height_camera_view_pu=hc, **cfg)
+        if (hc * cfg["num_rays"]) % 256 == 0 or hc not in (64, 128):
+            assert env.fill_kernel_name() == want.get(hc, "rcw_fill_flat_kernel"), (hc, env.fill_kernel_name())
         _rollout(rcw, env, orc, 12, rng, check_every=4)
         mask = np.array([1, 0, 0, 1, 1, 0, 1, 0, 1], dtype=np.uint8)
         rcw.reset_(env, mask=mask, seed=8); orc.reset(mask=mask, seed=8)

@@ -9,20 +9,22 @@ import torch
 import raycastworlds_jl_amd as RCW
 
 SHAPES = ((8, 8, 32, 256), (8, 16, 32, 512), (16, 16, 32, 256), (8, 8, 16, 256), (12, 12, 32, 256), (8, 8, 13, 256),
-                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64), (32, 32, 8, 256), (24, 24, 32, 256), (9, 9, 32, 256), (9, 12, 32, 256))
+                    (8, 8, 64, 256), (32, 32, 32, 1024), (8, 8, 32, 64), (32, 32, 8, 256), (24, 24, 32, 256), (9, 9, 32, 256), (9, 12, 32, 256),
+                    (8, 8, 10, 256), (8, 8, 12, 256), (8, 8, 20, 256), (8, 8, 24, 256), (8, 16, 24, 512), (16, 16, 20, 256))
 if len(sys.argv) > 1:                                    # one shape: H,W,pu,N
     SHAPES = (tuple(int(v) for v in sys.argv[1].split(",")),)
 for H, W, pu, N in SHAPES:
     px = H * pu * W * pu
-    B = max(64, min(8192, (1 << 30) // (4 * px)))
+    B = max(64, min(16384, (1 << 30) // (4 * px)))
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
                                           width_tile_map_tu=W, num_rays=N, pu_per_tu=pu, render_top_view=True)
     st = torch.cuda.Stream(); env.set_stream(st.cuda_stream); torch.cuda.set_stream(st)
     a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
-    for _ in range(3):
+    STEPS = int(os.environ.get("TOPSHAPES_STEPS", "20"))
+    for _ in range(max(3, STEPS // 4)):
         RCW.act_(env, a)
     env.profile(True)
-    for _ in range(20):
+    for _ in range(STEPS):
         RCW.act_(env, a)
     c, t, f, n = env.profile_read(); env.profile(False)
     by = 4 * px * B
