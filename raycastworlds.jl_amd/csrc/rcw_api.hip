@@ -321,7 +321,9 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     // or the flat kernel (any pixel scale from 9, any image height that is a multiple of 4 from 42 rows)
     int unit = d.top_lds > 0 ? rcw_top_split_unit(d) : 0;
     const int flat = d.top_lds > 0 ? rcw_top_flat_cols(d) : 0;
-    if (flat && unit && unit < 64) unit = 0;                              // (eight units a chunk: the flat kernel is the faster one)
+    // (several units a chunk: the flat kernel is the faster one — 384² / 320² / 288² px images, µs per GiB: 181 / 194 / 207 with
+    // 2 / 4 / 8 units against 176 / 175 / 173; whole 256-row chunks keep rcw_top_store_kernel: 159 against 179)
+    if (flat && unit && unit < 256) unit = 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_FLAT")) { const int f = std::atoi(v); if (f == 1 && flat) unit = 0; if (f == 0 && rcw_top_split_unit(d) && d.top_lds > 0) unit = rcw_top_split_unit(d); }
     const bool eligible = unit || flat;
     d.top_unit_px = unit ? unit : 256;

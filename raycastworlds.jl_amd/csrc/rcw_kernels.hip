@@ -38,12 +38,6 @@
 
 #include <mutex>
 
-#ifndef RCW_EXP_UNROLL
-#define RCW_EXP_UNROLL 2
-#endif
-#ifndef RCW_EXP
-#define RCW_EXP 0   // (temporary: compile-time timing experiments, tools/_build/variants)
-#endif
 
 namespace {
 
@@ -620,19 +614,20 @@ __device__ __forceinline__ u32x4 flat_fill_pixels(int r, int Hc, uint2 d0, uint2
     return v;
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, int K>                                           // K = the columns a chunk may touch (254 / H_cam + 2)
 __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
                                                                const int32_t* __restrict__ col_h,
                                                                const uint8_t* __restrict__ col_c,
                                                                uint32_t* __restrict__ out, long long total_cols,
-                                                               const uint8_t* __restrict__ mask, int K)
+                                                               const uint8_t* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63;
     const uint32_t G = gridDim.x * (kBlock / 64);
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
-    const int Hc = p.Hc, KS = K + 1;                                      // (one spare pair per chunk: the straddling read of the last column)
+    const int Hc = p.Hc;
+    constexpr int KS = K + 1;                                             // (one spare pair per chunk: the straddling read of the last column)
     const unsigned long long total_px = (unsigned long long)total_cols * (unsigned)Hc;
     const unsigned long long total_chunks = (total_px + 255) >> 8;
     uint2* const desc = reinterpret_cast<uint2*>(lds) + (size_t)(threadIdx.x >> 6) * 64 * KS;   // [64 chunks][KS]
@@ -645,26 +640,28 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
     uint32_t rem = (uint32_t)(id0 * 256 - (unsigned long long)col * (unsigned)Hc);
     u32x4* const out4 = reinterpret_cast<u32x4*>(out);
     const unsigned long long dstep = (unsigned long long)G * 64;
+    const uint32_t last_col = (uint32_t)total_cols - 1u;
     for (unsigned long long base = g; base < total_chunks; base += (unsigned long long)G * 64) {
         const unsigned long long id = base + (unsigned long long)lane * G;
         const bool exists = id < total_chunks;
-        const int touched = exists ? (int)((rem + 255u) / (unsigned)Hc) : -1;         // last column of the chunk, relative
-        bool all_valid = exists && (id + 1) * 256 <= total_px;
-        // (all loads first, then everything that uses one: K round trips one after the other would cost a third of a group's time)
-        int32_t hh[kFlatMaxCols + 1];
-        uint32_t cc[kFlatMaxCols + 1], mm[kFlatMaxCols + 1];
+        int touched = 0;                                                     // last column of the chunk, relative
 #pragma unroll
-        for (int j = 0; j <= kFlatMaxCols; ++j) {
-            const unsigned long long c = (unsigned long long)col + (unsigned)j;
-            const bool in = j <= touched && c < (unsigned long long)total_cols;
-            hh[j] = in ? col_h[c] : 0;
-            cc[j] = in ? (uint32_t)col_c[c] : 0u;
-            mm[j] = in ? (mask != nullptr ? (uint32_t)mask[c / (unsigned)p.N] : 1u) : 0u;
+        for (int k = 1; k < K; ++k) touched += (rem + 255u >= (unsigned)(k * Hc)) ? 1 : 0;
+        if (!exists) touched = -1;
+        bool all_valid = exists && (id + 1) * 256 <= total_px;
+        // (all loads first — addresses clamped into the arrays, not predicated —, then everything that uses one)
+        int32_t hh[KS];
+        uint32_t cc[KS], mm[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const uint32_t c = min(col + (unsigned)j, last_col);
+            hh[j] = col_h[c];
+            cc[j] = (uint32_t)col_c[c];
+            mm[j] = mask != nullptr ? (uint32_t)mask[c / (unsigned)p.N] : 1u;   // (wave-uniform branch; the division only with a mask)
         }
 #pragma unroll
-        for (int j = 0; j <= kFlatMaxCols; ++j) {
-            if (j >= KS) break;                                              // wave-uniform
-            const bool valid = mm[j] != 0u;
+        for (int j = 0; j < KS; ++j) {
+            const bool valid = j <= touched && col + (unsigned)j <= last_col && mm[j] != 0u;
             const uint32_t pad = valid ? ((uint32_t)column_padding(Hc, hh[j]) | 0x80000000u) : 0u;
             const uint32_t colour = valid ? p.colour[cc[j] & 3] : 0u;
             if (j <= touched && !valid) all_valid = false;
@@ -681,11 +678,14 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
             int rel, r, rel_n, r_n;
             flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Hc, rel, r);
             uint2 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
-#pragma unroll 4
+            // (measured, µs per GiB: four-pixel groups inside one column 162 / 163 / 173 / 182 unrolled by 1 / 2 / 4 / 8 — unrolled, the
+            // compiler bunches the stores of several chunks together, and the memory system takes evenly spaced stores best —;
+            // groups that straddle columns, with their longer arithmetic, 182 / 177 / 171 / 171)
+#pragma unroll (ALIGNED ? 1 : 4)
             for (int t = 0; t < 64; ++t, dst += dstep) {
-                const int tn = t < 63 ? t + 1 : 63;
-                flat_locate(L, __builtin_amdgcn_readlane(rem_l, tn), Hc, rel_n, r_n);
-                const uint2 n0 = desc[tn * KS + rel_n], n1 = ALIGNED ? n0 : desc[tn * KS + rel_n + 1];
+                // (the last trip fetches a 65th chunk's pair: lane 0's row again, and whatever lies behind in LDS; unused)
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Hc, rel_n, r_n);
+                const uint2 n0 = desc[(t + 1) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + 1) * KS + rel_n + 1];
                 bool ok[4];
                 const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
                 __builtin_nontemporal_store(v, dst + lane);
@@ -1691,9 +1691,6 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
         TopGroup cur;
         top_group_issue(p, mask, base, G, total, lane, cur);
         top_group_finish(p, L, cur);
-#if RCW_EXP == 11      // experiment: ~1 us of extra arithmetic per group in the prefetch phase (does the pause matter?)
-        { uint32_t acc = cur.code_lo; for (int q = 0; q < 600; ++q) asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(acc)); cur.code_lo ^= (acc & 0u); }
-#endif
         // the plane words go through a wave-private 2 KiB of LDS (index 8 t + word: lane l's register m is entry
         // 64 m + l), so that ONE loop over the 64 chunks can fetch them (a register per eight chunks would need eight
         // copies of the loop — and the compiler then carries all their store pointers through every one of them)
@@ -1709,18 +1706,11 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
                 const int s_flags = __builtin_amdgcn_readlane(cur.flags, t);
                 if (!(s_flags & 1)) continue;                                // wave-uniform: past the end / masked out
                 const uint32_t w = lw_read[8 * t];
-#if RCW_EXP == 12      // experiment: 20 extra dependent VALU instructions per chunk (does the chunk loop's arithmetic matter?)
-                uint32_t w2 = w; for (int q = 0; q < 20; ++q) asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(w2)); const uint32_t wx = w | (w2 & 0u);
-#define w wx
-#endif
                 const u32x4 o = top_chunk_pixels<WIDE>(L, w, (uint32_t)__builtin_amdgcn_readlane((int)cur.code_lo, t),
                                                        WIDE ? (uint32_t)__builtin_amdgcn_readlane((int)cur.code_hi, t) : 0u, s_flags,
                                                        (uint32_t)__builtin_amdgcn_readlane((int)cur.cmask, t),
                                                        __builtin_amdgcn_readlane(cur.r0, t));
                 store16<PLAIN>(dst + lane, o);
-#if RCW_EXP == 12
-#undef w
-#endif
             }
         }
     }
@@ -2129,18 +2119,13 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
             uint4 d = desc[rel];
             uint32_t w = lw_read[0];
             uint4 re = rtab[r >> 2];
-#pragma unroll RCW_EXP_UNROLL
+#pragma unroll 2
             for (int t = 0; t < 64; ++t, dst += dstep_b) {
                 // (the last trip fetches a 65th chunk's values: lane 0's row again — v_readlane takes the lane number modulo
                 // 64 — and whatever lies behind this wavefront's descriptors and plane words in the workgroup's LDS; unused)
                 flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Ht, rel_n, r_n);
-#if RCW_EXP == 9       // experiment: 4-byte instead of 16-byte LDS reads (wrong pixels, timing only): is it the LDS return traffic?
-                const uint32_t dx_ = desc[(t + 1) * KS + rel_n].x, rx_ = rtab[r_n >> 2].x;
-                const uint4 d_n = make_uint4(dx_, dx_, dx_, dx_), re_n = make_uint4(rx_ & 0xFFFFu, rx_, rx_, 0u);
-#else
                 const uint4 d_n = desc[(t + 1) * KS + rel_n];
                 const uint4 re_n = rtab[r_n >> 2];
-#endif
                 const uint32_t w_n = lw_read[8 * (t + 1)];
                 put(top_flat_pixels<STRADDLE, NARROW>(C, r, d, w, re.x, re.y, re.z, ((circle_chunks >> t) & 1ull) != 0));
                 d = d_n; w = w_n; re = re_n; r = r_n;
@@ -2252,9 +2237,13 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     case kFillFlat: {
         // the moving window over 256-pixel chunks of the flat batch
         const int K = rcw_fill_flat_cols(p);
-        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint2);
-        if ((p.Hc & 3) == 0) hipLaunchKernelGGL(rcw_fill_flat_kernel<true>, dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev, K);
-        else                 hipLaunchKernelGGL(rcw_fill_flat_kernel<false>, dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev, K);
+        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint2) + 128;   // (+ the fast loop reads a 65th chunk's pairs behind the last wavefront's)
+#define RCW_FILL_FLAT(AL, KK) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev)
+#define RCW_FILL_FLAT_K(KK) case KK: if ((p.Hc & 3) == 0) RCW_FILL_FLAT(true, KK); else RCW_FILL_FLAT(false, KK); break
+        switch (K) { RCW_FILL_FLAT_K(2); RCW_FILL_FLAT_K(3); RCW_FILL_FLAT_K(4); RCW_FILL_FLAT_K(5); RCW_FILL_FLAT_K(6); RCW_FILL_FLAT_K(7); RCW_FILL_FLAT_K(8);
+                     default: return hipErrorInvalidValue; }
+#undef RCW_FILL_FLAT_K
+#undef RCW_FILL_FLAT
         break;
     }
     case kFillFrame: {
