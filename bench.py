@@ -110,6 +110,10 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="also time the optional observation gather (RCCL all-gather of descriptors / frames) after the "
                          "timed region; on by default when --gpus > 1, with one GPU it runs a one-rank process group")
+    ap.add_argument("--api", default="raw", choices=["raw", "rlbase"],
+                    help="raw: time RCW.act!(env, actions) alone (the headline).  rlbase: ALSO time the loop of the reference's own "
+                         "test (test/runtests.jl:26-33: RLBase.state -> env(action) -> RLBase.reward -> RLBase.is_terminated every step, "
+                         "with a device-resident consumer of reward / done) and report it as `api_loop` beside the headline")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share GPU 0 and rendezvous over gloo (checks the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -222,49 +226,52 @@ def main():
                          device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms, cast_ms, fill_ms, top_ms = (float(v) for v in t)
+    # Outside the timed region too (--api rlbase): the same steps through the verbs the reference's test drives
+    # (test/runtests.jl:26-33), with a GPU-resident consumer: state(env) -> env(action) -> reward(env) -> is_terminated(env)
+    # every step.  reward / is_terminated return the engine's own device arrays (refreshed in stream order), so the loop
+    # issues no host synchronisation; `host_syncs_per_step` counts what the host layer issued.
+    api_loop = None
+    if args.api == "rlbase":
+        RLBase = RCW.RLBase
+        rl = RCW.RLBaseEnv(env)
+        returns = torch.zeros(B, dtype=torch.float32, device="cuda")
+        episodes = torch.zeros(B, dtype=torch.int32, device="cuda")
+        for s in range(args.warmup):
+            rl(actions[s])
+        sync_counting_bounds_errors()
+        torch.cuda.synchronize()
+        barrier()
+        syncs0 = env.host_syncs
+        t0a = time.perf_counter()
+        for s in range(args.warmup, total):
+            state = RLBase.state(rl)                                  # runtests.jl:27 (aliased, device-resident)
+            rl(actions[s])                                            # runtests.jl:29
+            r = RLBase.reward(rl).torch(sync=False)                   # runtests.jl:30
+            d = RLBase.is_terminated(rl).torch(sync=False)            # runtests.jl:31
+            returns += r                                              # the consumer: on the stream the engine runs on
+            episodes += d
+        syncs = env.host_syncs - syncs0                               # (before the closing synchronisation below)
+        bounds_api = sync_counting_bounds_errors()
+        torch.cuda.synchronize()
+        barrier()
+        dta = time.perf_counter() - t0a
+        if dist is not None:
+            ta = torch.tensor([dta], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            dta = float(ta[0])
+        api_loop = {"loop": "RLBase.state -> env(action) -> RLBase.reward -> RLBase.is_terminated per step (test/runtests.jl:26-33), "
+                            "reward / done consumed on the device (returns += reward; episodes += done)",
+                    "value": world * B * args.steps / dta, "unit": "env-steps/s", "ms_per_step": dta * 1e3 / args.steps,
+                    "fraction_of_raw_act": (world * B * args.steps / dta) / (world * B * args.steps / dt),
+                    "host_syncs_per_step": syncs / args.steps, "state_shape": list(state.shape),
+                    "goals_reached": int(episodes.sum().item()), "agents_that_hit_reference_BoundsError": bounds_api}
     # Outside the timed region too: the OPTIONAL observation gather north_star names (stepping itself has no
     # collective).  RCCL all-gather over the process group, issued on the stream the engine runs on: the compact
     # descriptors (5 B per column) with the pixel expansion on the receiver, and the frames themselves.
-    gather = None
-    if dist is not None and not args.rehearse_on_one_gpu:
-        try:
-            h_loc, c_loc = env.columns_device()
-            h_loc, c_loc = h_loc.torch(sync=False), c_loc.torch(sync=False)
-            obs_loc = env.camera_view.torch(sync=False).view(torch.int32)
-            gh = torch.empty((world * B, N), dtype=torch.int32, device="cuda")
-            gc = torch.empty((world * B, N), dtype=torch.uint8, device="cuda")
-            frames_all = torch.empty((world * B, N, Hc), dtype=torch.uint32, device="cuda")
+    fill_kernel = env.fill_kernel_name()
+    top_pu, top_form = env.cfg.pu_per_tu, env.top_view_form()
 
-            def timed(fn, reps):
-                fn()
-                torch.cuda.synchronize(); barrier()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    fn()
-                torch.cuda.synchronize(); barrier()
-                return (time.perf_counter() - t0) / reps * 1e6
-
-            def cols():
-                dist.all_gather_into_tensor(gh, h_loc)
-                dist.all_gather_into_tensor(gc, c_loc)
-
-            def cols_expand():
-                cols()
-                env.expand_columns(gh, gc, out=frames_all)
-
-            t_cols, t_cols_expand = timed(cols, 10), timed(cols_expand, 5)
-            t_frames = timed(lambda: dist.all_gather_into_tensor(frames_all.view(torch.int32), obs_loc), 3)
-            tt = torch.tensor([t_cols, t_cols_expand, t_frames], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            gather = {"ranks": world, "agents_per_rank": B, "descriptor_bytes_per_rank": 5 * N * B,
-                      "frame_bytes_per_rank": 4 * N * Hc * B, "columns_us": float(tt[0]),
-                      "columns_plus_expand_us": float(tt[1]), "frames_us": float(tt[2]),
-                      "note": "max over ranks, host-timed between barriers; not part of `value` (the gather is optional)"}
-            del gh, gc, frames_all
-        except Exception as e:   # noqa: BLE001 — a reported extra must never cost the bench line
-            gather = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-
-    if rank == 0:
+    def build_line(gather):
         frame_bytes = 4 * Hc * N                          # bytes per env-step
         bytes_per_launch = frame_bytes * B                # one fill launch = B agents
         fill_s = fill_ms / 1e3                            # dominant kernel, HIP events around it
@@ -315,7 +322,7 @@ def main():
                 "traffic_source": ("profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE of the fill kernel from separate "
                                    "rocprofv3 --pmc passes of this command, committed; not re-measured in this run"
                                    if traffic is not None else None),
-                "kernel": "rcw_fill256_kernel" if Hc == 256 else "rcw_fill_any_kernel",
+                "kernel": fill_kernel,
                 "bytes_per_launch": bytes_per_launch,
                 "launch_ms": fill_ms,
                 "launches_timed": nrec,
@@ -331,14 +338,14 @@ def main():
         if gather is not None:
             out["gather"] = gather
         if args.top_view:
-            pu = env.cfg.pu_per_tu
+            pu = top_pu
             top_bytes = 4 * (kw["height_tile_map_tu"] * pu) * (kw["width_tile_map_tu"] * pu) * B
             top_gbs = top_bytes / (top_ms / 1e3) / 1e9
             out["config"]["render_top_view"] = True
-            form = env.top_view_form()
+            form = top_form
             out["top_view"] = {
                 "form": form,
-                "kernel": "rcw_top_store_kernel" if form == "two-kernels" else "rcw_top_view_kernel",
+                "kernel": ("rcw_top_store_kernel (or its _units / _flat sibling for this geometry)" if form == "two-kernels" else "rcw_top_view_kernel"),
                 "bound": "hbm", "bytes_per_launch": top_bytes, "launch_ms": top_ms,
                 "achieved": top_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top_gbs / HBM_PEAK_GBS,
                 "note": "update_top_view! SR:446-483, 4*(H*pu)*(W*pu) bytes per agent written once; opt-in, not in `value` of the headline run"
@@ -346,10 +353,87 @@ def main():
                            "(rcw_top_draw_kernel, VALU/LDS work, planes of 1/32 of the image) runs on a side stream beside the "
                            "camera fill and is inside the fill's launch_ms — see profiles/ for its own duration" if form == "two-kernels" else ""),
             }
+        if api_loop is not None:
+            out["api_loop"] = api_loop
+        return out
+
+    gather = None
+    headline_ready = {"line": None}
+
+    def emit(line_dict):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line_dict) + "\n").encode())
+
+    def watchdog():
+        # The gather is an optional extra: if it hangs (a rank that failed inside a collective leaves the others
+        # waiting), the bench line must still go out.  Every rank leaves after the deadline; rank 0 first writes the
+        # headline it has ready, with the gather reported as timed out.
+        if rank == 0 and headline_ready["line"] is not None:
+            out_t = dict(headline_ready["line"])
+            out_t["gather"] = {"error": "the optional observation gather did not finish within 120 s; headline unaffected"}
+            emit(out_t)
+        os._exit(0)
+
+    if dist is not None and not args.rehearse_on_one_gpu:
+        import threading
+
+        if rank == 0:
+            headline_ready["line"] = build_line(None)
+        timer = threading.Timer(120.0, watchdog)
+        timer.daemon = True
+        timer.start()
+        ok = 1
+        try:
+            h_loc, c_loc = env.columns_device()
+            h_loc, c_loc = h_loc.torch(sync=False), c_loc.torch(sync=False)
+            obs_loc = env.camera_view.torch(sync=False).view(torch.int32)
+            gh = torch.empty((world * B, N), dtype=torch.int32, device="cuda")
+            gc = torch.empty((world * B, N), dtype=torch.uint8, device="cuda")
+            frames_all = torch.empty((world * B, N, Hc), dtype=torch.uint32, device="cuda")
+
+            def timed(fn, reps):
+                fn()
+                torch.cuda.synchronize(); barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(); barrier()
+                return (time.perf_counter() - t0) / reps * 1e6
+
+            def cols():
+                dist.all_gather_into_tensor(gh, h_loc)
+                dist.all_gather_into_tensor(gc, c_loc)
+
+            def cols_expand():
+                cols()
+                env.expand_columns(gh, gc, out=frames_all)
+
+            t_cols, t_cols_expand = timed(cols, 10), timed(cols_expand, 5)
+            t_frames = timed(lambda: dist.all_gather_into_tensor(frames_all.view(torch.int32), obs_loc), 3)
+        except Exception as e:   # noqa: BLE001 — a reported extra must never cost the bench line
+            ok = 0
+            gather = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            t_cols = t_cols_expand = t_frames = 0.0
+        try:
+            # collective-safe: every rank reaches this all-reduce, whatever happened above on it
+            tt = torch.tensor([t_cols, t_cols_expand, t_frames, -float(ok)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if float(tt[3]) > -1.0:                     # some rank failed
+                gather = gather or {"error": "the gather failed on another rank"}
+            else:
+              gather = {"ranks": world, "agents_per_rank": B, "descriptor_bytes_per_rank": 5 * N * B,
+                      "frame_bytes_per_rank": 4 * N * Hc * B, "columns_us": float(tt[0]),
+                      "columns_plus_expand_us": float(tt[1]), "frames_us": float(tt[2]),
+                      "note": "max over ranks, host-timed between barriers; not part of `value` (the gather is optional)"}
+        except Exception as e:   # noqa: BLE001
+            gather = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        timer.cancel()
+
+    if rank == 0:
+        out = build_line(gather)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, B)
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(out)
     env.close()
     if dist is not None:
         dist.barrier()

@@ -369,6 +369,18 @@ function done_device_ptr(env::BatchedSingleRoom)
     check(ccall((:rcw_done_device_ptr, librcw), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), env.handle, p)); p[]
 end
 
+# The RLBase verbs for a GPU-RESIDENT agent: where `RLBase.state / reward / is_terminated` below hand out host arrays
+# (one device-to-host copy and a wait for the engine's stream per call), these hand out what the engine itself writes —
+# (device pointer, element type, dims), stable for the handle's lifetime and refreshed by every step in stream order, to
+# be wrapped once, e.g. with AMDGPU.jl `unsafe_wrap(ROCArray{R,1}, Ptr{R}(ptr), dims)`.  A loop
+# `act!(env, actions_device_ptr) -> policy kernels on stream(env)` then never synchronises the host (the Python mirror's
+# RLBase.reward / is_terminated return exactly these aliases by default; bench.py --api rlbase measures the loop).
+state_device(env::BatchedSingleRoom) =
+    (ptr = camera_view_device_ptr(env), eltype = UInt32,
+     dims = (Int(env.config.height_camera_view_pu), Int(env.config.num_rays), env.batch))
+reward_device(env::BatchedSingleRoom{T, R}) where {T, R} = (ptr = reward_device_ptr(env), eltype = R, dims = (env.batch,))
+is_terminated_device(env::BatchedSingleRoom) = (ptr = done_device_ptr(env), eltype = UInt8, dims = (env.batch,))
+
 # The compact per-column descriptor of the frames: height_line_pu (single_room.jl:408-411) and colour id by image column
 function columns(env::BatchedSingleRoom; first::Integer = 0, count::Integer = env.batch - first)
     N = Int(env.config.num_rays)

@@ -22,9 +22,13 @@ class RLBaseEnv:
 
 
 def state(env: RLBaseEnv):
-    """`RLBase.state(env)` SR:576: `env.env.camera_view`, ALIASED device memory (no copy);
-    it is overwritten in place by the next action, as in the reference."""
-    return env.env.camera_view
+    """`RLBase.state(env)` SR:576: `env.env.camera_view`, ALIASED device memory (no copy, no synchronisation);
+    it is overwritten in place by the next action, as in the reference.  The same object until `bind_obs` moves it."""
+    e = env.env
+    cv = getattr(e, "_state_alias", None)
+    if cv is None or cv.ptr != e._obs_ptr():
+        cv = e._state_alias = e.camera_view
+    return cv
 
 
 def state_space(env: RLBaseEnv):
@@ -43,10 +47,13 @@ def action_space(env: RLBaseEnv):
 
 
 def reward(env: RLBaseEnv):
-    """`RLBase.reward(env)` SR:583: Float32 (B,)."""
-    return env.env.world.reward
+    """`RLBase.reward(env) = env.env.world.reward` SR:583, where it lives: a `DeviceArray` R (B,) over the engine's reward
+    array — the same object on every call, rewritten by every action in stream order, NO host synchronisation.  A
+    GPU-resident agent takes `reward(env).torch(sync=False)`; host code uses it as an array (`reward(env) == 0`,
+    `total += reward(env)`, `np.asarray(...)`), which copies it to the host at that moment."""
+    return env.env.reward_device()
 
 
 def is_terminated(env: RLBaseEnv):
-    """`RLBase.is_terminated(env)` SR:584: Bool (B,)."""
-    return env.env.world.done
+    """`RLBase.is_terminated(env) = env.env.world.done` SR:584: Bool (B,), device-resident like `reward`."""
+    return env.env.done_device(as_bool=True)

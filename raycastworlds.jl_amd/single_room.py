@@ -36,20 +36,28 @@ CAMERA_VIEW = 1   # SR:238
 TOP_VIEW = 2      # SR:239
 
 
-class DeviceArray:
+class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
     """A typed view of library-owned device memory (no copy).
 
     Exposes `__cuda_array_interface__` (v3), so `torch.as_tensor(x, device="cuda")` and
     friends alias it exactly as `RLBase.state(env)` aliases `camera_view` (SR:576).
+
+    A GPU-resident consumer takes `x.torch(sync=False)` — one cached tensor over the stable device pointer, ordered on
+    the engine's stream, no host synchronisation ever.  A host consumer just uses it as an array: `np.asarray(x)`,
+    `x == 0`, `x.any()`, `total += x` copy the current contents to the host at that moment (one device-to-host copy
+    behind the engine's stream — the explicit request; a sticky device error such as the reference's BoundsError
+    surfaces there).
     """
 
-    def __init__(self, ptr: int, shape: Sequence[int], dtype, owner, sync):
+    def __init__(self, ptr: int, shape: Sequence[int], dtype, owner, sync, host_getter=None):
         self.ptr = int(ptr)
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self._owner = owner   # keeps the handle alive
         self._sync = sync
         self._sync_on_export = True
+        self._host_getter = host_getter
+        self._torch = None
 
     @property
     def nbytes(self) -> int:
@@ -63,28 +71,64 @@ class DeviceArray:
         # before reading frames a later step writes — INTEGRATION.md "Streams".
         if self._sync_on_export:
             self._sync()
+        # (device memory behind a Bool view is one byte per element: exported as uint8, viewed as bool by .torch())
         return {
             "shape": self.shape,
-            "typestr": self.dtype.str,
+            "typestr": "|u1" if self.dtype == np.bool_ else self.dtype.str,
             "data": (self.ptr, False),
             "version": 3,
             "strides": None,
         }
 
     def torch(self, sync: bool = True):
-        """Zero-copy torch tensor on the handle's device.  `sync=False` skips the host synchronisation: for
-        callers that order their work on the engine's stream themselves (the observation gather does)."""
+        """Zero-copy torch tensor on the handle's device (made once per DeviceArray, the pointer is stable).
+        `sync=False` skips the host synchronisation: for callers that order their work on the engine's stream
+        themselves (a policy on the shared stream, the observation gather)."""
         import torch
 
+        if self._torch is not None:
+            if sync:
+                self._sync()
+            return self._torch
         self._sync_on_export = bool(sync)
         try:
-            return torch.as_tensor(self, device=f"cuda:{self._owner.device}")
+            t = torch.as_tensor(self, device=f"cuda:{self._owner.device}")
         finally:
             self._sync_on_export = True
+        self._torch = t.view(torch.bool) if self.dtype == np.bool_ else t
+        return self._torch
 
     def numpy(self) -> np.ndarray:
-        """Copy to host."""
+        """Copy to host (waits for the engine's stream)."""
+        if self._host_getter is not None:
+            return self._host_getter()
         return self._owner._copy_device_array(self)
+
+    # ---- host-side use as an array: every operation below starts with one device-to-host copy --------------
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        inputs = tuple(np.asarray(x) if isinstance(x, DeviceArray) else x for x in inputs)
+        if out is not None:
+            kwargs["out"] = out
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def any(self, *a, **k):
+        return self.numpy().any(*a, **k)
+
+    def all(self, *a, **k):
+        return self.numpy().all(*a, **k)
+
+    def sum(self, *a, **k):
+        return self.numpy().sum(*a, **k)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
 
     def __repr__(self):
         return f"DeviceArray(ptr=0x{self.ptr:x}, shape={self.shape}, dtype={self.dtype})"
@@ -103,6 +147,7 @@ class SingleRoomWorld:
 
     def _get(self, fn, dtype, shape):
         out = np.empty(shape, dtype=dtype)
+        self._env.host_syncs += 1                      # every host getter waits for the engine's stream
         self._env._check(fn(self._env._h, _as_ptr(out)))
         return out
 
@@ -283,6 +328,7 @@ class SingleRoom:
         self._h = C.c_void_p()
         self._check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
         self.world = SingleRoomWorld(self)
+        self.host_syncs = 0      # host synchronisations / device-to-host getters issued through this object (bench.py --api rlbase)
         self._held = []          # (event, tensors): torch tensors the engine's stream may still be reading
         self._free_events = []
         # colour fields of the reference struct SR:241-256
@@ -319,6 +365,7 @@ class SingleRoom:
 
     # ---- device views ---------------------------------------------------------------
     def _sync(self):
+        self.host_syncs += 1
         self._check(self._lib.rcw_sync(self._h))
 
     def sync(self):
@@ -436,14 +483,25 @@ class SingleRoom:
         ring.append((ev, tensors))
 
     def reward_device(self) -> DeviceArray:
-        p = C.c_void_p()
-        self._check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
-        return DeviceArray(p.value, (self.batch,), self.R, self, self._sync)
+        """`world.reward` (SR:33) where it lives: R (B,) in device memory, stable for the handle's lifetime, rewritten
+        by every step in stream order.  The same object on every call (its torch alias is made once)."""
+        if getattr(self, "_reward_dev", None) is None:
+            p = C.c_void_p()
+            self._check(self._lib.rcw_reward_device_ptr(self._h, C.byref(p)))
+            self._reward_dev = DeviceArray(p.value, (self.batch,), self.R, self, self._sync,
+                                           host_getter=lambda: self.world.reward)
+        return self._reward_dev
 
-    def done_device(self) -> DeviceArray:
-        p = C.c_void_p()
-        self._check(self._lib.rcw_done_device_ptr(self._h, C.byref(p)))
-        return DeviceArray(p.value, (self.batch,), np.uint8, self, self._sync)
+    def done_device(self, as_bool: bool = False) -> DeviceArray:
+        """`world.done` (SR:35) in device memory: one byte per agent (`as_bool`: the same bytes viewed as Bool)."""
+        name = "_done_dev_bool" if as_bool else "_done_dev"
+        if getattr(self, name, None) is None:
+            p = C.c_void_p()
+            self._check(self._lib.rcw_done_device_ptr(self._h, C.byref(p)))
+            getter = (lambda: self.world.done) if as_bool else (lambda: self.world.done.astype(np.uint8))
+            setattr(self, name, DeviceArray(p.value, (self.batch,), np.bool_ if as_bool else np.uint8, self, self._sync,
+                                            host_getter=getter))
+        return getattr(self, name)
 
     def ray_table(self) -> np.ndarray:
         """(nd, 5, N) float32: per heading [dx | dy | |1/dx| | |1/dy| | dir·ray]."""

@@ -167,6 +167,49 @@ def test_expand_columns_reproduces_frames(rcw, oracle):
     env.close()
 
 
+def test_rlbase_verbs_are_device_resident_and_do_not_synchronise(rcw, oracle):
+    """RLBase.state / reward / is_terminated (SR:576-584) hand out the engine's own device arrays: the same object on
+    every call, refreshed by every action in stream order.  The loop of the reference's test (test/runtests.jl:26-33) with
+    a GPU-resident consumer issues NO host synchronisation; used as host arrays the same objects copy on demand."""
+    torch = pytest.importorskip("torch")
+    B = 64
+    env, orc = _make(rcw, oracle, B, seed=8, out_of_bounds=1, **CFG2)
+    rl = rcw.RLBaseEnv(env)
+    RLBase = rcw.RLBase
+    stream = torch.cuda.Stream()
+    env.set_stream(stream.cuda_stream)
+    rng = np.random.default_rng(6)
+    acts = rng.integers(1, 5, (40, B)).astype(np.uint8)
+    with torch.cuda.stream(stream):
+        dev_acts = torch.from_numpy(acts).cuda()
+        returns = torch.zeros(B, dtype=torch.float32, device="cuda")
+        ended = torch.zeros(B, dtype=torch.int32, device="cuda")
+        stream.synchronize()
+        before = env.host_syncs
+        for s in range(40):
+            state = RLBase.state(rl)
+            rl(dev_acts[s])
+            r, d = RLBase.reward(rl), RLBase.is_terminated(rl)
+            assert r is RLBase.reward(rl) and d is RLBase.is_terminated(rl) and state is RLBase.state(rl)
+            returns += r.torch(sync=False)
+            ended += d.torch(sync=False)
+        assert env.host_syncs == before                                      # not one synchronisation in 40 steps
+        stream.synchronize()
+    want_r, want_e = np.zeros(B, np.float32), np.zeros(B, np.int32)
+    for s in range(40):
+        assert orc.step(acts[s]) == 0
+        want_r += orc.reward; want_e += (orc.done != 0)
+    np.testing.assert_array_equal(returns.cpu().numpy(), want_r)
+    np.testing.assert_array_equal(ended.cpu().numpy(), want_e)
+    # the same objects as host arrays: copied at the moment of use
+    assert RLBase.is_terminated(rl).dtype == np.bool_ and RLBase.reward(rl).dtype == np.float32
+    np.testing.assert_array_equal(np.asarray(RLBase.reward(rl)), orc.reward)
+    np.testing.assert_array_equal(np.asarray(RLBase.is_terminated(rl)), orc.done != 0)
+    assert ((RLBase.reward(rl) == 0) | RLBase.is_terminated(rl)).all()
+    assert env.host_syncs > before
+    env.close()
+
+
 def test_odd_camera_heights(rcw, oracle):
     """H_cam other than 256 (height_camera_view_pu, SR:271): the moving-window kernel for 64 / 128 / 512 / 768 (chunks of
     whole columns or row blocks); rcw_fill_flat_kernel — 256-pixel chunks of the flat batch, each lane finding its own

@@ -112,3 +112,73 @@ def test_two_ranks_equal_one_unsharded_batch(oracle):
         np.testing.assert_array_equal(frames_f.astype(np.uint32), ref.camera_view, err_msg="frames-mode gather")
     ref.reset(seed=5)
     np.testing.assert_array_equal(results[0][5], ref.col_height, err_msg="after sharded reset")
+
+
+class _RecordingLib:
+    """What comm_init_abi needs of the library: rank 0's unique id (a recognisable pattern) and a record of the
+    rcw_comm_init arguments."""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, []
+
+    def rcw_comm_unique_id(self, uid):
+        for k in range(len(uid)):
+            uid[k] = (7 * k + 3) & 0xFF
+        self.calls.append(("unique_id",))
+        return 0
+
+    def rcw_comm_init(self, h, uid, rank, world):
+        self.calls.append(("init", bytes(uid), rank, world))
+        return 0
+
+    def rcw_comm_destroy(self, h):
+        return 0
+
+
+class _AbiEngine(OracleEngine):
+    def __init__(self, batch, agent_id_offset, device, seed=0, **kw):
+        super().__init__(batch, agent_id_offset, device, seed=seed, **kw)
+        self.device, self._h = 0, None
+        self._lib = _RecordingLib(dist.get_rank())
+
+    def _check(self, rc):
+        assert rc == 0
+
+
+def _uid_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import raycastworlds_jl_amd as RCW
+
+        sh = RCW.ShardedSingleRoom(GLOBAL_B, env_factory=_AbiEngine, seed=1, **CFG)
+        sh.comm_init_abi()
+        sh.comm_init_abi()                                                   # idempotent
+        q.put((rank, sh.env._lib.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_unique_id_hand_over_between_two_ranks():
+    """ShardedSingleRoom.comm_init_abi with two ranks on the CPU (gloo): only rank 0 asks the library for the
+    ncclUniqueId, its 128 bytes reach rank 1 through the process group unchanged, and each rank calls rcw_comm_init once
+    with its own (rank, world = 2).  (The library side of the same call runs on the GPU with two ranks:
+    tests/test_gpu_rccl.py::test_library_transport_with_two_ranks.)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = bytes((7 * k + 3) & 0xFF for k in range(128))
+    assert results[0] == [("unique_id",), ("init", want, 0, 2)]
+    assert results[1] == [("init", want, 1, 2)]
