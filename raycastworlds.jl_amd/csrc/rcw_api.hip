@@ -385,7 +385,7 @@ int validate_config(const rcw_config* c, int32_t batch)
         return fail(RCW_ERR_INVALID_ARGUMENT, "tile map must be at least 3x3 (got %dx%d)",
                     c->height_tile_map_tu, c->width_tile_map_tu);
     // the cast kernel stages a byte per tile in dynamic LDS next to a few static words: 64 KiB per workgroup in all
-    if ((long long)c->height_tile_map_tu * c->width_tile_map_tu > 65536 - 256)
+    if ((long long)c->height_tile_map_tu * c->width_tile_map_tu + 2ll * c->height_tile_map_tu > 65536 - 256)   // (+ the cast kernel's two guard bands of H bytes)
         return fail(RCW_ERR_UNSUPPORTED, "tile map larger than 65280 tiles does not fit the LDS staging");
     if (c->num_directions < 1 || c->num_rays < 1 || c->height_camera_view_pu < 1)
         return fail(RCW_ERR_INVALID_ARGUMENT, "num_directions, num_rays, height_camera_view_pu must be >= 1");
@@ -706,7 +706,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
     if (const char* v = RCW_DEV_ENV("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_CAST_TABLE"))   // only where tile bytes + 5 N table values fit the default 64 KiB
-        d.cast_table_lds = std::strcmp(v, "lds") == 0 && rcw_step_lds_bytes(d) + (size_t)RCW_TABLE_ROWS * N * h->real_size + 64 <= 64 * 1024 ? 1 : 0;
+        d.cast_table_lds = std::strcmp(v, "lds") == 0 && rcw_step_lds_bytes(d) + 2 * (size_t)H + (size_t)RCW_TABLE_ROWS * N * h->real_size + 128 <= 64 * 1024 ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.fill_grid = g; }
     if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;

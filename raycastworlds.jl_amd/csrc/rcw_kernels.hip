@@ -100,9 +100,14 @@ __device__ __forceinline__ int floor_to_int32(double f) { return (int)fmin(fmax(
 
 // In LDS the tile map is staged UNPACKED, one byte per tile (value = the tile's 2 bits), so a
 // lookup in the ray march is a single ds_read_u8 at the linear tile index.
+// The LAST tile — the wall ring's corner (H, W), a wall in every map the engine builds — is staged as an obstacle whatever
+// HBM holds: cast_ray's march reads it for any index outside the map and relies on it to stop (see there).
 __device__ __forceinline__ void stage_tile_bytes(uint8_t* tb, const uint32_t* tm_hbm, int HW, int tid, int nthreads)
 {
-    for (int t = tid; t < HW; t += nthreads) tb[t] = (uint8_t)((tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u);
+    for (int t = tid; t < HW; t += nthreads) {
+        const uint32_t b = (tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u;
+        tb[t] = (uint8_t)(t == HW - 1 ? (b | 1u) : b);
+    }
 }
 
 // ---- is_player_colliding for both layers in one sweep  (CD:21-42) ----------------------
@@ -202,10 +207,14 @@ template <typename T> struct RayHit { int t, dim; T dist; uint32_t bits; bool oo
 // The march is written with selects, not branches (lanes of a wavefront disagree on the step
 // axis at almost every iteration; a divergent if/else costs more in exec-mask bookkeeping than
 // the few v_cndmask), and it carries only what the result needs: the two side distances, the
-// linear tile index t (the stop tile is t mod H, t div H) and the last axis.  The chip's VALU
-// issue rate bounds this loop (B·N rays x trip count x instructions), so every instruction
-// counts.  A closed wall ring (SR:57-60) stops every ray; `cap` only guards a corrupt map
-// against hanging the wavefront, and is reported as out of bounds.
+// linear tile index t (the stop tile is t mod H, t div H) and the last step.  The chip's
+// instruction issue bounds this loop (B·N rays x trip count x instructions — scalar ones count like
+// vector ones), so every instruction counts: ONE exit condition (the tile's byte), nothing counted.
+// Termination needs no counter: t moves strictly monotonically along both axes, an index outside
+// [0, H·W) reads the LAST tile instead, and stage_tile_bytes makes that byte an obstacle whatever
+// HBM holds (it is the wall ring's corner, SR:57-60: a wall in every map the engine builds) — so a
+// corrupt map ends a ray at the latest when it leaves the index range, reported as out of bounds.
+// The hit dimension is read off the last step (+-1 along x, +-H along y; H >= 3).
 template <typename T, bool TIE_LE, bool DIST_PRE>
 __device__ __forceinline__ RayHit<T> cast_ray(const uint8_t* tb, int H, int W, T x, T y, T dx, T dy, T ddx, T ddy)
 {
@@ -219,24 +228,70 @@ __device__ __forceinline__ RayHit<T> cast_ray(const uint8_t* tb, int H, int W, T
     T sx = fx * ddx, sy = fy * ddy;
     int t = (i0 - 1) + H * (j0 - 1);
     const unsigned last = (unsigned)(H * W - 1);
-    const int cap = H + W;
     RayHit<T> r;
-    r.dim = 0; r.dist = (T)0;
-    int n = 0;
-    for (;;) {
-        const unsigned tc = (unsigned)t < last ? (unsigned)t : last;      // never read outside the map
-        r.bits = tb[tc];
-        if (r.bits != 0u || n >= cap) break;
-        ++n;
+    r.dist = (T)0;
+    int step = 0;                                                             // the last step: si, tj, or none
+    r.bits = tb[(unsigned)t < last ? (unsigned)t : last];                     // never read outside the map
+    while (r.bits == 0u) {
         const bool xf = TIE_LE ? (sx <= sy) : (sx < sy);
         const T nx = sx + ddx, ny = sy + ddy;
         if (DIST_PRE) r.dist = xf ? sx : sy;
         sx = xf ? nx : sx;
         sy = xf ? sy : ny;
-        t += xf ? si : tj;
-        r.dim = xf ? 1 : 2;
+        step = xf ? si : tj;
+        t += step;
+        r.bits = tb[(unsigned)t < last ? (unsigned)t : last];
     }
-    r.oob = r.bits == 0u || (unsigned)t > last;
+    r.dim = step == 0 ? 0 : (step == si ? 1 : 2);
+    r.oob = (unsigned)t > last;
+    if (!DIST_PRE) {
+        const T d1 = sx - ddx, d2 = sy - ddy;
+        r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : (T)0);
+    }
+    r.t = t;
+    return r;
+}
+
+// The same march for the cast kernel, which lays the tile bytes out with a GUARD BAND of H obstacle bytes in front of
+// tile 0 and behind the last tile: a step moves the linear index by 1 or by H, so the first index outside the map falls
+// into a band, reads as an obstacle and ends the ray — no clamp in the loop.  The loop carries the LDS byte ADDRESS of
+// the current tile (tile index + the array's LDS address, added once) and reads it with ds_read_u8 by name: written in C
+// the compiler re-adds the (link-time) base of the dynamic LDS array to the index in every iteration.  8 vector
+// instructions and the LDS read per tile crossed (the clamped form: 10; the round-2 form with its step counter: 14 and
+// eleven scalar ones) — at the deep-march config (32×32 map, rays of up to 60 tiles) the kernel is issue-bound.
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__device__ __forceinline__ RayHit<T> cast_ray_guarded(const uint8_t* tiles, int H, int W, T x, T y, T dx, T dy, T ddx, T ddy)
+{
+    const int i0 = (int)rfloor(x) + 1;    // wu_to_tu UT:5
+    const int j0 = (int)rfloor(y) + 1;
+    const bool neg_x = dx < (T)0, neg_y = dy < (T)0;
+    const int si = neg_x ? -1 : 1;
+    const int tj = neg_y ? -H : H;
+    const T fx = neg_x ? x - (T)(i0 - 1) : (T)i0 - x;
+    const T fy = neg_y ? y - (T)(j0 - 1) : (T)j0 - y;
+    T sx = fx * ddx, sy = fy * ddy;
+    const uint32_t base = (uint32_t)reinterpret_cast<size_t>((__attribute__((address_space(3))) const uint8_t*)tiles);   // LDS address of tile 0
+    const int t0 = (i0 - 1) + H * (j0 - 1);
+    const unsigned last = (unsigned)(H * W - 1);
+    // (a start outside the map — no state the engine produces — starts in the front band: the march ends at once)
+    uint32_t u = base + ((unsigned)t0 <= last ? (uint32_t)t0 : 0xFFFFFFFFu);
+    RayHit<T> r;
+    r.dist = (T)0;
+    int step = 0;                                                             // the last step: si, tj, or none
+    asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r.bits) : "v"(u) : "memory");
+    while (r.bits == 0u) {
+        const bool xf = TIE_LE ? (sx <= sy) : (sx < sy);
+        const T nx = sx + ddx, ny = sy + ddy;
+        if (DIST_PRE) r.dist = xf ? sx : sy;
+        sx = xf ? nx : sx;
+        sy = xf ? sy : ny;
+        step = xf ? si : tj;
+        u += (uint32_t)step;
+        asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r.bits) : "v"(u) : "memory");
+    }
+    const int t = (int)(u - base);
+    r.dim = step == 0 ? 0 : (step == si ? 1 : 2);
+    r.oob = (unsigned)t > last;
     if (!DIST_PRE) {
         const T d1 = sx - ddx, d2 = sy - ddy;
         r.dist = r.dim == 1 ? d1 : (r.dim == 2 ? d2 : (T)0);
@@ -348,11 +403,13 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     const int tid = threadIdx.x;
     if (mask != nullptr && mask[a] == 0) return;
 
-    uint8_t* tb = reinterpret_cast<uint8_t*>(lds);          // [H*W] the agent's tile map, a byte per tile
-    __shared__ T s_pose[2];
-    __shared__ int s_pose_d;
+    // LDS: [H guard bytes | H*W tile bytes, the agent's tile map | H guard bytes] (cast_ray_guarded) | the re-sampled pose
     typedef typename Real<T>::vec2 vec2;
     const int HW = p.H * p.W;
+    uint8_t* const tb = reinterpret_cast<uint8_t*>(lds) + p.H;
+    for (int k = tid; k < 2 * p.H; k += (int)blockDim.x) (k < p.H ? tb - p.H + k : tb + HW + (k - p.H))[0] = 1;
+    T* const s_pose = reinterpret_cast<T*>(lds + ((HW + 2 * p.H + 15) / 16) * 4);     // [2] + the heading (auto-reset)
+    int& s_pose_d = *reinterpret_cast<int*>(s_pose + 2);
 
     // ---- every load of the agent's state is issued up front (all wave-uniform addresses) ----
     uint32_t* tm_hbm = p.tile_map + (size_t)a * p.nwords;
@@ -420,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         // Development switch RCW_CAST_TABLE=lds: stage the heading's table slice (5 N values) in LDS first, as
         // north_star words it, then read it back.  Every entry is used exactly once by exactly one lane, so the copy
         // buys no reuse — measured against the direct, coalesced L2 read below (profiles/).
-        T* stab = reinterpret_cast<T*>(lds + ((HW + 15) / 16) * 4);
+        T* stab = reinterpret_cast<T*>(lds + ((HW + 2 * p.H + 15) / 16) * 4 + 8);
         __syncthreads();
         for (int k = tid; k < RCW_TABLE_ROWS * p.N; k += (int)blockDim.x) stab[k] = tab[k];
         __syncthreads();
@@ -433,9 +490,9 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         const T dot = tab[4 * p.N + i];
 #ifdef RCW_DEV_SWITCHES
         const RayHit<T> r = p.cast_ballot ? cast_ray_ballot<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy)
-                                          : cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+                                          : cast_ray_guarded<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
 #else
-        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+        const RayHit<T> r = cast_ray_guarded<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
 #endif
         if (r.oob) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }
         const int h = r.oob ? p.Hc : height_line_pu<T>(p, r.dist, dot);
@@ -2177,12 +2234,13 @@ size_t rcw_step_lds_bytes(const RcwDev& p)
     return (((size_t)p.H * p.W + 15) & ~(size_t)15);   // one byte per tile
 }
 // the cast kernel's LDS: the tile bytes (+ the heading's table slice under the RCW_CAST_TABLE=lds development switch)
-static size_t rcw_cast_lds_bytes(const RcwDev& p)
+static size_t rcw_cast_lds_bytes(const RcwDev& p)                          // guard | tile bytes | guard | re-sampled pose (32 B) [| table slice]
 {
+    const size_t tiles = (((size_t)p.H * p.W + 2 * (size_t)p.H + 15) & ~(size_t)15);
 #ifdef RCW_DEV_SWITCHES
-    if (p.cast_table_lds) return rcw_step_lds_bytes(p) + (size_t)RCW_TABLE_ROWS * p.N * (p.real64 ? 8 : 4);
+    if (p.cast_table_lds) return tiles + 32 + (size_t)RCW_TABLE_ROWS * p.N * (p.real64 ? 8 : 4);
 #endif
-    return rcw_step_lds_bytes(p);
+    return tiles + 32;
 }
 
 // rcw_fill_flat_kernel: the image columns a 256-pixel chunk can touch at this camera height; 0: the kernel does not take it
