@@ -328,9 +328,19 @@ class SingleRoom:
         self._h = C.c_void_p()
         self._check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
         self.world = SingleRoomWorld(self)
-        self.host_syncs = 0      # host synchronisations / device-to-host getters issued through this object (bench.py --api rlbase)
-        self._held = []          # (event, tensors): torch tensors the engine's stream may still be reading
+        self._held = []          # (event, tensors): torch tensors a NON-torch stream may still be reading (_release_after_use)
         self._free_events = []
+        self._torch_owned_stream = None
+        # With torch in the process the engine runs on a stream TORCH owns (never destroyed, so `Tensor.record_stream` on it
+        # is safe for tensors that outlive the engine); without torch, on the library's own stream.
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                self.set_stream(torch.cuda.Stream(device=self.device))
+        except ImportError:
+            pass
+        self.host_syncs = 0      # host synchronisations / device-to-host getters issued through this object (bench.py --api rlbase)
         # colour fields of the reference struct SR:241-256
         self.floor_color = cfg.floor_color
         self.ceiling_color = cfg.ceiling_color
@@ -467,10 +477,23 @@ class SingleRoom:
         return True
 
     def _release_after_use(self, *tensors):
-        """Hold references to `tensors` until an event recorded NOW on the engine's stream has completed (a
-        ring of 16 reusable events; the host only ever blocks when it runs 16 launches ahead of the GPU)."""
+        """Keep `tensors` (handed to the engine on its stream) from being recycled by torch's caching allocator before the
+        engine has used them, although the caller may drop them right after the call.
+
+        On a stream torch owns (the default: see __init__) this is `Tensor.record_stream` — no bookkeeping, never blocks.
+        On any other stream (the library's own, a caller's raw hipStream_t) record_stream must NOT be used: the
+        allocator records an event on every recorded stream when the tensor is finally freed, which may be long after
+        `close()` has destroyed that stream — an event record on a destroyed HIP stream is a use after free inside the
+        runtime (the segmentation fault of rounds 2 and 3).  There, references are held instead until an
+        event recorded now on the engine's stream has completed (a ring of 16 reusable events; the host only ever blocks
+        when it runs 16 launches ahead of the GPU)."""
         import torch
 
+        if self._stream_is_torch_owned():
+            ts = self.torch_stream()
+            for t in tensors:
+                t.record_stream(ts)
+            return
         ring, free = self._held, self._free_events
         while ring and ring[0][0].query():
             free.append(ring.pop(0)[0])
@@ -535,14 +558,31 @@ class SingleRoom:
         self._check(self._lib.rcw_get_stream(self._h, C.byref(p)))
         return int(p.value or 0)
 
+    def _stream_is_torch_owned(self) -> bool:
+        ts = getattr(self, "_torch_owned_stream", None)
+        return ts is not None and ts.cuda_stream == self.stream_ptr()
+
     def torch_stream(self):
-        """The engine's stream as a torch stream object (for wait_stream / wait_event)."""
+        """The engine's stream as a torch stream object (for wait_stream / wait_event / record_stream): the torch Stream
+        itself where torch owns it, else ONE `ExternalStream` wrapper per raw stream, kept for the engine's lifetime."""
         import torch
 
-        return torch.cuda.ExternalStream(self.stream_ptr(), device=f"cuda:{self.device}")
+        if self._stream_is_torch_owned():
+            return self._torch_owned_stream
+        ptr = self.stream_ptr()
+        cached = getattr(self, "_torch_stream", None)
+        if cached is None or cached[0] != ptr:
+            cached = self._torch_stream = (ptr, torch.cuda.ExternalStream(ptr, device=f"cuda:{self.device}"))
+        return cached[1]
 
-    def set_stream(self, hip_stream: Optional[int]):
-        self._check(self._lib.rcw_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+    def set_stream(self, stream):
+        """Order the engine's work on another stream: a `torch.cuda.Stream` (kept alive here; torch never destroys its
+        streams, so tensors may be handed over with record_stream), a raw hipStream_t as an int (the caller keeps it
+        alive for as long as the engine — and any tensor it was given — lives), or None: the library's own stream."""
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            self._torch_owned_stream = stream
+            stream = stream.cuda_stream
+        self._check(self._lib.rcw_set_stream(self._h, C.c_void_p(stream) if stream else None))
 
     def bind_obs(self, device_ptr: Optional[int]):
         self._check(self._lib.rcw_bind_obs(self._h, C.c_void_p(device_ptr) if device_ptr else None))

@@ -569,7 +569,8 @@ def test_frame_dump_of_engine_frames(rcw, oracle, tmp_path):
 
 def test_device_actions_may_be_dropped_right_after_act(rcw, oracle):
     """The engine runs on its own stream; a temporary action tensor handed to act_ and dropped at once must
-    not be recycled by torch's caching allocator before the cast kernel has read it (record_stream in act_).
+    not be recycled by torch's caching allocator before the cast kernel has read it (`Tensor.record_stream` on the
+    engine's stream in act_).
     No host synchronisation anywhere in the loop; each step allocates same-sized tensors that would reuse
     the freed block immediately."""
     torch = pytest.importorskip("torch")
