@@ -86,7 +86,8 @@ function main()
             gi, gj = parse(Int, c[5]), parse(Int, c[6])
             x, y = f32(c[7]), f32(c[8])
             d = parse(Int, c[9])
-            env = SRM.SingleRoom(height_tile_map_tu = H, width_tile_map_tu = W, num_rays = N)
+            pu = length(c) >= 10 ? parse(Int, c[10]) : 32                              # (optional column: pixels per tile of the top view)
+            env = SRM.SingleRoom(height_tile_map_tu = H, width_tile_map_tu = W, num_rays = N, pu_per_tu = pu)
             inject!(env, gi, gj, x, y, d)
             world = env.world
             write(joinpath(OUT, name * ".camera_view.u32"), env.camera_view)

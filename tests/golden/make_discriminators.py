@@ -127,19 +127,28 @@ def main():
         switches={"dda_tie_break": {"0": "x first when side_x < side_y", "1": "x first when side_x <= side_y"},
                   "dda_distance": {"0": "side - delta after the step", "1": "side before the increment"},
                   "normalize_mode": {"0": "inv(norm(v)) * v", "1": "v / norm(v)"}},
-        cases=cases)
+        cases=cases,
+        # not switch discriminators: inputs whose top_view pins SimpleDraw's rasterisers on a pixel scale that is not a power of two
+        rasteriser_cases=[dict(
+            name="top_view_pu12_rasterisers",
+            config=dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, pu_per_tu=12),
+            goal=[6, 3], position=[3.71875, 5.40625], direction=23,
+            why="not a switch discriminator: pins SimpleDraw's Line / Circle (top_view) on a pixel scale that is not a power of two — "
+                "12 pixels a tile: wu_to_pu end points, Bresenham lines and the midpoint circle (radius_pu = 2) on a 96 x 96 image, "
+                "where the engine's flat store kernel (any pixel scale from 9) renders; compared through <name>.top_view.u32")])
     with open(os.path.join(HERE, "discriminators.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
         f.write("\n")
     # the inputs alone, in a form julia/make_reference_fixtures.jl parses with Base only
     with open(os.path.join(ROOT, "julia", "discriminator_cases.tsv"), "w") as f:
-        f.write("# name\tH\tW\tnum_rays\tgoal_i\tgoal_j\tx_bits\ty_bits\tdirection_au   (Float32 bit patterns; "
+        f.write("# name\tH\tW\tnum_rays\tgoal_i\tgoal_j\tx_bits\ty_bits\tdirection_au\t[pu_per_tu = 32]   (Float32 bit patterns; "
                 "written by tests/golden/make_discriminators.py)\n")
-        for c in cases:
+        for c in cases + out["rasteriser_cases"]:
             x, y = np.array(c["position"], dtype=np.float32).view(np.uint32).tolist()
             cfg = c["config"]
             f.write(f"{c['name']}\t{cfg['height_tile_map_tu']}\t{cfg['width_tile_map_tu']}\t{cfg['num_rays']}\t"
-                    f"{c['goal'][0]}\t{c['goal'][1]}\t{x}\t{y}\t{c['direction']}\n")
+                    f"{c['goal'][0]}\t{c['goal'][1]}\t{x}\t{y}\t{c['direction']}"
+                    + (f"\t{cfg['pu_per_tu']}" if "pu_per_tu" in cfg else "") + "\n")
     print(len(cases), "cases written")
 
 

@@ -18,6 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "discriminators.json")) as f:
     DISC = json.load(f)
 CASES = DISC["cases"]
+RASTER_CASES = DISC.get("rasteriser_cases", [])      # no switch: inputs whose top_view pins SimpleDraw's rasterisers
+ALL_CASES = CASES + RASTER_CASES
 
 
 def _check(case, value, got):
@@ -38,11 +40,14 @@ def test_kit_covers_every_switch():
     # the inputs the Julia script reads are the same cases
     tsv = [l.split("\t") for l in open(os.path.join(os.path.dirname(HERE), "julia", "discriminator_cases.tsv"))
            if not l.startswith("#")]
-    assert [r[0] for r in tsv] == [c["name"] for c in CASES]
-    for r, c in zip(tsv, CASES):
+    assert [r[0] for r in tsv] == [c["name"] for c in ALL_CASES]
+    for r, c in zip(tsv, ALL_CASES):
         x, y = np.array([int(r[6]), int(r[7])], dtype=np.uint32).view(np.float32)
         assert [float(x), float(y)] == c["position"] and int(r[8]) == c["direction"]
         assert [int(r[4]), int(r[5])] == c["goal"] and int(r[3]) == c["config"]["num_rays"]
+        assert (int(r[9]) if len(r) > 9 else 32) == c["config"].get("pu_per_tu", 32)
+    assert any(c["config"].get("pu_per_tu", 32) % 4 == 0 and c["config"]["pu_per_tu"] & (c["config"]["pu_per_tu"] - 1)
+               for c in RASTER_CASES), "a top-view case on a pixel scale that is not a power of two"
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import reference_pin as RP
-from test_discriminators import CASES
+from test_discriminators import ALL_CASES as CASES          # the switch discriminators + the rasteriser case(s)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(HERE, "golden", "reference")
@@ -129,7 +129,7 @@ def _write_like_the_julia_script(directory, case, out, nd, directions):
     with open(os.path.join(directory, name + ".txt"), "w") as f:
         f.write(f"name {name}\nversions self-test (CPU oracle, not Julia)\n")
         f.write(f"shape {cfg['height_tile_map_tu']} {cfg['width_tile_map_tu']} {cfg['num_rays']} {nd} 256 "
-                f"{cfg['height_tile_map_tu'] * 32} {cfg['width_tile_map_tu'] * 32}\n")
+                f"{cfg['height_tile_map_tu'] * cfg.get('pu_per_tu', 32)} {cfg['width_tile_map_tu'] * cfg.get('pu_per_tu', 32)}\n")
         f.write("directions_wu_bits " + j(directions.view(np.uint32)) + "\n")
         for k in RP.RAY_FIELDS:
             f.write(f"{k} {j(out[k])}\n")
