@@ -236,20 +236,25 @@ def main():
         rl = RCW.RLBaseEnv(env)
         returns = torch.zeros(B, dtype=torch.float32, device="cuda")
         episodes = torch.zeros(B, dtype=torch.int32, device="cuda")
-        for s in range(args.warmup):
-            rl(actions[s])
-        sync_counting_bounds_errors()
-        torch.cuda.synchronize()
-        barrier()
-        syncs0 = env.host_syncs
-        t0a = time.perf_counter()
-        for s in range(args.warmup, total):
+        def api_step(s):
             state = RLBase.state(rl)                                  # runtests.jl:27 (aliased, device-resident)
             rl(actions[s])                                            # runtests.jl:29
             r = RLBase.reward(rl).torch(sync=False)                   # runtests.jl:30
             d = RLBase.is_terminated(rl).torch(sync=False)            # runtests.jl:31
-            returns += r                                              # the consumer: on the stream the engine runs on
-            episodes += d
+            returns.add_(r)                                           # the consumer: on the stream the engine runs on
+            episodes.add_(d)
+            return state
+
+        for s in range(args.warmup):                                  # (the whole loop body: torch loads its kernels on first use)
+            api_step(s)
+        sync_counting_bounds_errors()
+        torch.cuda.synchronize()
+        barrier()
+        returns.zero_(); episodes.zero_()
+        syncs0 = env.host_syncs
+        t0a = time.perf_counter()
+        for s in range(args.warmup, total):
+            state = api_step(s)
         syncs = env.host_syncs - syncs0                               # (before the closing synchronisation below)
         bounds_api = sync_counting_bounds_errors()
         torch.cuda.synchronize()

@@ -65,6 +65,7 @@ struct rcw_handle {
     hipEvent_t ev_actions[2] = {nullptr, nullptr};
     int action_slot = 0;
     bool profiling = false;
+    int step_pieces = 1;               // development experiment only (RCW_STEP_PIECES)
     int prof_count = 0;
     std::vector<hipEvent_t> prof_ev;   // 4 per recorded step: start | after cast | after top view | after fill
     void* d_rays[4] = {nullptr, nullptr, nullptr, nullptr};   // rcw_rays scratch (grow-only)
@@ -143,6 +144,29 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
     hipEvent_t* ev = prof ? &h->prof_ev[4 * h->prof_count] : nullptr;
     hipError_t e;
     if (prof && (e = hipEventRecord(ev[0], h->stream)) != hipSuccess) return e;
+#ifdef RCW_DEV_SWITCHES
+    if (h->step_pieces == 2 && !d.top_view && h->top_stream && d.B >= 2) {
+        // Development experiment (RCW_STEP_PIECES=2): the batch in two halves, the second half's cast kernel on
+        // the side stream BESIDE the first half's fill: cast(1) | fork | fill(1) ∥ cast(2) | join | fill(2).
+        const int B1 = d.B / 2, B2 = d.B - B1;
+        const long long cols1 = (long long)B1 * d.N;
+        if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream, 0, B1)) != hipSuccess) return e;
+        if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
+        e = rcw_launch_cast(d, actions_dev, mask_dev, h->top_stream, B1, B2);
+        const hipError_t rec = hipEventRecord(h->ev_top_join[0], h->top_stream);
+        if (prof && e == hipSuccess) e = hipEventRecord(ev[1], h->stream);
+        if (prof && e == hipSuccess) e = hipEventRecord(ev[2], h->stream);
+        if (e == hipSuccess) e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, cols1, mask_dev, h->stream);
+        if (rec == hipSuccess) { const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[0], 0); if (e == hipSuccess) e = w; }
+        if (e == hipSuccess) e = rec;
+        if (e == hipSuccess)
+            e = rcw_launch_fill(d, d.col_h + cols1, d.col_c + cols1, d.obs + cols1 * d.Hc, (long long)B2 * d.N, mask_dev ? mask_dev + B1 : nullptr, h->stream);
+        if (e != hipSuccess) return e;
+        if (prof) { if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e; h->prof_count++; }
+        return hipSuccess;
+    }
+#endif
     if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
     if (prof && (e = hipEventRecord(ev[1], h->stream)) != hipSuccess) return e;
     auto fill = [&]() -> hipError_t {
@@ -711,6 +735,15 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
+    if (const char* v = RCW_DEV_ENV("RCW_STEP_PIECES")) {
+        h->step_pieces = std::atoi(v) == 2 ? 2 : 1;
+        if (h->step_pieces == 2) {                                                            // the side stream and its two events
+            hipError_t e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_top_join[0], hipEventDisableTiming);
+            if (e != hipSuccess) { free_all(h); delete h; return fail(RCW_ERR_HIP, "side stream: %s", hipGetErrorString(e)); }
+        }
+    }
     {
         int want_form = 0, want_runs = 0;
         if (const char* v = RCW_DEV_ENV("RCW_TOP_SPLIT")) { const int f = std::atoi(v); if (!f) want_form = RCW_TOP_VIEW_ONE_KERNEL; else if (f == 2) want_form = RCW_TOP_VIEW_TWO_KERNELS; }

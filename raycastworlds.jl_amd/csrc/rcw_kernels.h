@@ -89,7 +89,7 @@ size_t rcw_step_lds_bytes(const RcwDev& p);
 // the fill kernel (descriptors -> pixels).  actions == nullptr: render only (after reset /
 // set_state); mask == nullptr: all agents.
 hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
-                           hipStream_t s);
+                           hipStream_t s, int first = 0, int count = -1);   // agents [first, first + count); -1: to the end
 hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c, uint32_t* frames,
                            long long total_cols, const uint8_t* mask_dev, hipStream_t s);
 // update_top_view!(env) SR:446-483 for every (unmasked) agent; needs p.top_view

@@ -396,10 +396,10 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d)
 template <typename T, bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
                                                           const uint8_t* __restrict__ actions,
-                                                          const uint8_t* __restrict__ mask)
+                                                          const uint8_t* __restrict__ mask, int first)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int a = blockIdx.x;
+    const int a = first + (int)blockIdx.x;                  // agents [first, first + gridDim.x)
     const int tid = threadIdx.x;
     if (mask != nullptr && mask[a] == 0) return;
 
@@ -2337,9 +2337,10 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     } while (0)
 
 hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev,
-                           hipStream_t s)
+                           hipStream_t s, int first, int count)
 {
-    RCW_DISPATCH(rcw_cast_kernel, dim3(p.B), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev);
+    if (count < 0) count = p.B - first;
+    RCW_DISPATCH(rcw_cast_kernel, dim3(count), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev, first);
     return hipGetLastError();
 }
 
