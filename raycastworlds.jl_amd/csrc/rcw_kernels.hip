@@ -646,25 +646,30 @@ __device__ __forceinline__ void flat_locate(const FlatLane& L, int rem0, int hei
     rel = L.qv + (t >= (uint32_t)height ? 1 : 0);
 }
 
+// a column's descriptor in LDS: x = rows of ceiling (SR:436), y = H_cam - x (the first row of floor), z = colour, w = valid.
+// The lane's first pixel is row r of column d0 (the following pixels may lie in d1 when H_cam % 4 != 0); pixel e is
+// ceiling while e < x - r, colour while e < y - r, else floor (SR:437-439): two subtractions, then compares with constants.
 template <bool ALIGNED>
-__device__ __forceinline__ u32x4 flat_fill_pixels(int r, int Hc, uint2 d0, uint2 d1, uint32_t ceil_c, uint32_t floor_c, bool* ok)
+__device__ __forceinline__ u32x4 flat_fill_pixels(int r, int Hc, uint4 d0, uint4 d1, uint32_t ceil_c, uint32_t floor_c, bool* ok)
 {
-    const int pad0 = (int)(d0.x & 0x7FFFFFFFu);
     u32x4 v;
+    const int a0 = (int)d0.x - r, b0 = (int)d0.y - r;
     if (ALIGNED) {
-        v.x = pixel(r + 0, pad0, Hc, d0.y, ceil_c, floor_c);
-        v.y = pixel(r + 1, pad0, Hc, d0.y, ceil_c, floor_c);
-        v.z = pixel(r + 2, pad0, Hc, d0.y, ceil_c, floor_c);
-        v.w = pixel(r + 3, pad0, Hc, d0.y, ceil_c, floor_c);
-        ok[0] = ok[1] = ok[2] = ok[3] = (d0.x >> 31) != 0u;
+        v.x = 0 < a0 ? ceil_c : (0 < b0 ? d0.z : floor_c);
+        v.y = 1 < a0 ? ceil_c : (1 < b0 ? d0.z : floor_c);
+        v.z = 2 < a0 ? ceil_c : (2 < b0 ? d0.z : floor_c);
+        v.w = 3 < a0 ? ceil_c : (3 < b0 ? d0.z : floor_c);
+        ok[0] = ok[1] = ok[2] = ok[3] = d0.w != 0u;
     } else {
-        const int pad1 = (int)(d1.x & 0x7FFFFFFFu);
+        const int c = Hc - r;                                              // pixels e >= c are in the following column, from its row 0
+        const int a1 = (int)d1.x + c, b1 = (int)d1.y + c;                   // (row e - c of d1: e - c < x  <=>  e < x + c)
         uint32_t px[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool next = r + e >= Hc;                                 // this pixel is in the following column
-            px[e] = pixel(next ? r + e - Hc : r + e, next ? pad1 : pad0, Hc, next ? d1.y : d0.y, ceil_c, floor_c);
-            ok[e] = ((next ? d1.x : d0.x) >> 31) != 0u;
+            const bool next = e >= c;
+            const int a = next ? a1 : a0, b = next ? b1 : b0;
+            px[e] = e < a ? ceil_c : (e < b ? (next ? d1.z : d0.z) : floor_c);
+            ok[e] = (next ? d1.w : d0.w) != 0u;
         }
         v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
     }
@@ -682,12 +687,13 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
     const int lane = threadIdx.x & 63;
     const uint32_t G = gridDim.x * (kBlock / 64);
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    asm volatile("" : "+v"(ceil_c), "+v"(floor_c));                         // (in vector registers once: a v_cndmask reads at most one scalar)
     const int Hc = p.Hc;
     constexpr int KS = K + 1;                                             // (one spare pair per chunk: the straddling read of the last column)
     const unsigned long long total_px = (unsigned long long)total_cols * (unsigned)Hc;
     const unsigned long long total_chunks = (total_px + 255) >> 8;
-    uint2* const desc = reinterpret_cast<uint2*>(lds) + (size_t)(threadIdx.x >> 6) * 64 * KS;   // [64 chunks][KS]
+    uint4* const desc = reinterpret_cast<uint4*>(lds) + (size_t)(threadIdx.x >> 6) * 64 * KS;   // [64 chunks][KS]
     const FlatLane L = flat_lane(lane, Hc);
     // this lane's chunk of the first group, as (first column, row in it); every group moves all lanes by the same pixels
     const unsigned long long id0 = (unsigned long long)g + (unsigned long long)lane * G;
@@ -719,10 +725,9 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             const bool valid = j <= touched && col + (unsigned)j <= last_col && mm[j] != 0u;
-            const uint32_t pad = valid ? ((uint32_t)column_padding(Hc, hh[j]) | 0x80000000u) : 0u;
-            const uint32_t colour = valid ? p.colour[cc[j] & 3] : 0u;
+            const uint32_t pad = (uint32_t)column_padding(Hc, hh[j]);
             if (j <= touched && !valid) all_valid = false;
-            desc[lane * KS + j] = make_uint2(pad, colour);
+            desc[lane * KS + j] = make_uint4(pad, (uint32_t)Hc - pad, p.colour[cc[j] & 3], valid ? 1u : 0u);
         }
         const int state_l = (exists ? 1 : 0) | (all_valid ? 2 : 0);
         const int rem_l = (int)rem;
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
             // every chunk of the group is whole and unmasked: no branch in the loop, the next chunk's pair(s) on their way
             int rel, r, rel_n, r_n;
             flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Hc, rel, r);
-            uint2 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
+            uint4 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
             // (measured, µs per GiB: four-pixel groups inside one column 162 / 163 / 173 / 182 unrolled by 1 / 2 / 4 / 8 — unrolled, the
             // compiler bunches the stores of several chunks together, and the memory system takes evenly spaced stores best —;
             // groups that straddle columns, with their longer arithmetic, 182 / 177 / 171 / 171)
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
             for (int t = 0; t < 64; ++t, dst += dstep) {
                 // (the last trip fetches a 65th chunk's pair: lane 0's row again, and whatever lies behind in LDS; unused)
                 flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Hc, rel_n, r_n);
-                const uint2 n0 = desc[(t + 1) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + 1) * KS + rel_n + 1];
+                const uint4 n0 = desc[(t + 1) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + 1) * KS + rel_n + 1];
                 bool ok[4];
                 const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
                 __builtin_nontemporal_store(v, dst + lane);
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
                 if (!(s_state & 1)) continue;                                // wave-uniform: past the end
                 int rel, r;
                 flat_locate(L, __builtin_amdgcn_readlane(rem_l, t), Hc, rel, r);
-                const uint2 d0 = desc[t * KS + rel], d1 = ALIGNED ? d0 : desc[t * KS + rel + 1];
+                const uint4 d0 = desc[t * KS + rel], d1 = ALIGNED ? d0 : desc[t * KS + rel + 1];
                 bool ok[4];
                 const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
                 if (s_state & 2) {
@@ -2295,7 +2300,7 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     case kFillFlat: {
         // the moving window over 256-pixel chunks of the flat batch
         const int K = rcw_fill_flat_cols(p);
-        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint2) + 128;   // (+ the fast loop reads a 65th chunk's pairs behind the last wavefront's)
+        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint4) + 256;   // (+ the fast loop reads a 65th chunk's pairs behind the last wavefront's)
 #define RCW_FILL_FLAT(AL, KK) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev)
 #define RCW_FILL_FLAT_K(KK) case KK: if ((p.Hc & 3) == 0) RCW_FILL_FLAT(true, KK); else RCW_FILL_FLAT(false, KK); break
         switch (K) { RCW_FILL_FLAT_K(2); RCW_FILL_FLAT_K(3); RCW_FILL_FLAT_K(4); RCW_FILL_FLAT_K(5); RCW_FILL_FLAT_K(6); RCW_FILL_FLAT_K(7); RCW_FILL_FLAT_K(8);
