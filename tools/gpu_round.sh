@@ -6,6 +6,7 @@
 set -o pipefail
 tag=${1:-rXX}
 R=$PWD
+DEVLIB=$R/raycastworlds.jl_amd/lib/librcw_hip_dev.so
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 stop_if_killed() { if [ "$1" -eq 124 ] || [ "$1" -eq 137 ]; then echo "step '$2' timed out ($1): stopping"; exit "$1"; fi; }
@@ -13,7 +14,7 @@ stop_if_killed() { if [ "$1" -eq 124 ] || [ "$1" -eq 137 ]; then echo "step '$2'
 if [ "$2" != "notests" ]; then
   timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?; tail -2 gpurun_out/${tag}_pytest_gpu.log; stop_if_killed $rc pytest
 fi
-timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; rc=$?; cut -c1-160 gpurun_out/${tag}_bench.json; stop_if_killed $rc bench
+timeout -k 10 300 python bench.py --api rlbase > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; rc=$?; cut -c1-160 gpurun_out/${tag}_bench.json; stop_if_killed $rc bench
 (cd $R && timeout -k 10 300 python bench.py --no-cpu-baseline --top-view --steps 100 --warmup 10 > gpurun_out/${tag}_top_bench.json 2> gpurun_out/${tag}_top_bench.err); rc=$?; stop_if_killed $rc top_bench
 rm -rf gpurun_out/${tag}_top_pmc_fetch gpurun_out/${tag}_top_ring_stats gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_top_stats gpurun_out/${tag}_top_pmc_write gpurun_out/${tag}_cfg5_*
 cd /tmp
@@ -31,9 +32,10 @@ prof ${tag}_pmc_fetch ${tag}_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --
 prof ${tag}_top_stats ${tag}_top_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
 prof ${tag}_top_pmc_write ${tag}_top_pmc_write.log --pmc WRITE_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
 prof ${tag}_top_pmc_fetch ${tag}_top_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
-RCW_TOP_SPLIT=0 prof ${tag}_top_ring_stats ${tag}_top_ring_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
+RCW_LIBRARY=$DEVLIB RCW_TOP_SPLIT=0 prof ${tag}_top_ring_stats ${tag}_top_ring_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
 prof ${tag}_top_pmc_sq ${tag}_top_pmc_sq.log --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -- --top-view --steps 20 --warmup 2
 # --- cast kernel at cfg-5 (32x32 map, 1024 columns: 60-step rays), exec-masked march vs ballot-bounded march
+export RCW_LIBRARY=$DEVLIB          # (the measured-and-rejected variants live in the development build only; both marches from it)
 for march in exec ballot; do
   export RCW_CAST_MARCH=$march
   prof ${tag}_cfg5_${march}_stats ${tag}_cfg5_${march}_stats.log --kernel-trace --stats -- --workload cfg5 --steps 30 --warmup 3
@@ -46,7 +48,22 @@ for w in cfg2 cfg5; do
   RCW_CAST_TABLE=lds prof ${tag}_${w}_tablelds_stats ${tag}_${w}_tablelds_stats.log --kernel-trace --stats -- --workload $w --steps 30 --warmup 3
   prof ${tag}_${w}_tablel2_stats ${tag}_${w}_tablel2_stats.log --kernel-trace --stats -- --workload $w --steps 30 --warmup 3
 done
+unset RCW_LIBRARY
 cd $R
+# --- the flat kernels (any camera height / any top-view pixel scale): per-kernel times by rocprofv3 on their shapes, bytes written
+export TOPSHAPES_STEPS=60
+: > gpurun_out/${tag}_top_shapes_kernels.txt; : > gpurun_out/${tag}_top_shapes_steps.txt
+for shape in 8,8,32,256 8,16,32,512 16,16,32,256 8,8,10,256 8,8,12,256 8,8,13,256 8,8,20,256 8,8,24,256 8,16,24,512 16,16,20,256 9,9,32,256 9,12,32,256 12,12,32,256 8,8,16,256 8,8,64,256 24,24,32,256 32,32,32,1024 32,32,8,256; do
+  tools/kprof.sh "top_$shape" tools/top_view_shapes.py $shape >> gpurun_out/${tag}_top_shapes_kernels.txt 2>&1 || echo "shape $shape failed"
+  grep -h "^map" gpurun_out/kp_top_$shape.log >> gpurun_out/${tag}_top_shapes_steps.txt
+done
+tools/kprof.sh hcam tools/hcam_bench.py > gpurun_out/${tag}_hcam_kernels.txt 2>&1; grep -h "^H_cam" gpurun_out/kp_hcam.log > gpurun_out/${tag}_hcam_steps.txt
+export TMPDIR=/tmp TOPSHAPES_STEPS=12
+for what in "top_view_shapes.py 8,8,24,256" "top_view_shapes.py 8,8,13,256" "hcam_bench.py 100,10486 250,4194"; do
+  n=$(echo $what | tr ' ,.' '___'); rm -rf $R/gpurun_out/${tag}_flat_write_$n
+  (cd /tmp && timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_flat_write_$n -- python3 $R/tools/$what > $R/gpurun_out/${tag}_flat_write_$n.log 2>&1)
+  python3 tools/pmc_summary.py gpurun_out/${tag}_flat_write_$n WRITE_SIZE rcw_ | grep -E "flat|fill256|top_store" >> gpurun_out/${tag}_flat_write.txt
+done
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_write.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_fetch FETCH_SIZE | tee gpurun_out/${tag}_fetch.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_top_write.txt

@@ -18,6 +18,8 @@ for H, W, pu, N in SHAPES:
     B = max(64, min(16384, (1 << 30) // (4 * px)))
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
                                           width_tile_map_tu=W, num_rays=N, pu_per_tu=pu, render_top_view=True)
+    if os.environ.get("TOPSHAPES_RUNS"):                  # development: the two-kernel form in this many runs of agents
+        env.set_top_view_form("two-kernels", runs=int(os.environ["TOPSHAPES_RUNS"]))
     st = torch.cuda.Stream(); env.set_stream(st.cuda_stream); torch.cuda.set_stream(st)
     a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
     STEPS = int(os.environ.get("TOPSHAPES_STEPS", "20"))
