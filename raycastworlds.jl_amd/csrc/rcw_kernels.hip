@@ -13,14 +13,17 @@
 //            a small fixed grid sweeps one compact window through the (H_cam, N, B) batch,
 //            lanes mapped along the image's contiguous axis (rows of one column, Julia
 //            column-major), one 16-byte store per lane, one whole 1 KiB column per wavefront
-//            store instruction at H_cam = 256.
+//            store instruction at H_cam = 256 (rcw_fill256_kernel); rcw_fill_window_kernel for
+//            256 k / 128 / 64 rows, rcw_fill_flat_kernel for every other height from 37 rows
+//            (256-pixel chunks of the flat batch, each lane finds its own column).
 // This is an integer/indexing + streaming-store path: no MFMA, the roofline is HBM write
 // bandwidth, and the frame (4·H_cam·N bytes per agent-step) is written exactly once.
 //
 // (opt-in) the reference's other per-step image, update_top_view! SR:446-483, every pixel written once:
-//   rcw_top_draw_kernel + rcw_top_store_kernel / rcw_top_store_units_kernel   rays -> lines in an LDS bit plane -> the
-//            plane (1/32 of the image) to HBM, on a side stream beside the fill kernel; then the fill kernel's moving
-//            window over the image with the top view's pixel logic;
+//   rcw_top_draw_kernel + rcw_top_store_kernel / rcw_top_store_flat_kernel / rcw_top_store_units_kernel   rays -> lines in
+//            an LDS bit plane -> the plane (1/32 of the image) to HBM, on a side stream beside the fill kernel; then the fill
+//            kernel's moving window over the image with the top view's pixel logic (_flat: any pixel scale from 9 pixels a
+//            tile, 256-pixel chunks of the flat batch, descriptor loads one group ahead awaited with vmcnt(63));
 //   rcw_top_view_kernel           the same in one persistent kernel (draw and store groups, a ring of LDS planes);
 //   rcw_top_view_inplace_kernel   images whose bit plane does not fit in LDS.
 //
