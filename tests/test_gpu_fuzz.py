@@ -15,4 +15,13 @@ def test_random_configurations_stay_in_parity():
     res = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "2025"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
-    assert "120 random configurations, 0 mismatches" in res.stdout
+    assert "120 random configurations" in res.stdout and ", 0 mismatches" in res.stdout
+
+
+def test_random_flat_kernel_geometries_stay_in_parity():
+    """The same over the geometries only the flat kernels take: top views at 9..60 pixels a tile (two-kernel form asked
+    for) and camera heights anywhere from 37 rows."""
+    res = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "77", "flat"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "80 random configurations" in res.stdout and ", 0 mismatches" in res.stdout

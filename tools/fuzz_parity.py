@@ -3,8 +3,10 @@
 configurations (map size, columns, headings, field of view, radius, step, camera height, image
 height, world-unit type, the three unpinned switches, both BoundsError policies, auto-reset).
 
-    python tools/fuzz_parity.py [configs] [seed] [top|split]   # "top": every configuration renders the top view;
-                                                              # "split": ... with a geometry the two-kernel top view takes
+    python tools/fuzz_parity.py [configs] [seed] [top|split|flat]   # "top": every configuration renders the top view;
+                                                                   # "split": ... with a geometry of the unit store kernels;
+                                                                   # "flat": ... of the flat store kernel (any pu >= 9), and any
+                                                                   #         camera height from 37 rows (the flat fill kernel)
 """
 import os
 import sys
@@ -19,10 +21,10 @@ from oracle import oracle as O
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split")
-split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the two-kernel top view (units of 256 / 128 / 64 / 32 rows)
-if split_geometry:
-    os.environ["RCW_TOP_SPLIT"] = "2"          # ... and that form at these small batches too (by default only from 256 MiB of top view a step)
+always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split", "flat")
+split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the unit store kernels (units of 256 / 128 / 64 / 32 rows)
+flat_geometry = len(sys.argv) > 3 and sys.argv[3] == "flat"     # geometries of the flat store kernel; the two-kernel form is asked for
+two_kernel_forms = 0                                            # (rcw_set_top_view_form: by default it is taken only from 256 MiB a step)
 fails = 0
 O.set_num_threads(8)
 for c in range(n_cfg):
@@ -52,6 +54,16 @@ for c in range(n_cfg):
         kw["height_tile_map_tu"] = H
         kw["width_tile_map_tu"] = int(rng.integers(4, 10 if pu >= 64 else 20))
         B = int(rng.integers(1, 12 if pu >= 64 else 40))
+    if flat_geometry:
+        pu = int(rng.integers(9, 61))
+        kw["pu_per_tu"] = pu
+        H = int(rng.integers(4, 20))
+        if (H * pu) % 4:                                   # image height a multiple of 4
+            H += (4 - H % 4) % 4 if pu % 2 else (2 - H % 2) % 2
+        kw["height_tile_map_tu"] = max(H, 4)
+        kw["width_tile_map_tu"] = int(rng.integers(4, 14))
+        kw["height_camera_view_pu"] = int(rng.choice([int(rng.integers(37, 700)), 84, 100, 250, 300, 333, 40]))
+        B = int(rng.integers(1, 30))
     seed = int(rng.integers(0, 2**31))
     okw = {k: v for k, v in kw.items()}
     okw["auto_reset"] = int(kw["auto_reset"]); okw["render_top_view"] = int(kw["render_top_view"])
@@ -64,6 +76,12 @@ for c in range(n_cfg):
         env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, T="Float64" if T64 else "Float32", R=R, **kw)
         orc = O.OracleBatch(B, seed=seed, **okw)
         assert_state_equal(env, orc, rays=True, where="create")
+        if kw["render_top_view"] and (split_geometry or flat_geometry or rng.integers(0, 2)):
+            try:
+                env.set_top_view_form("two-kernels", runs=int(rng.integers(0, 4)))
+                two_kernel_forms += 1
+            except Exception:                                  # the geometry does not take it: the automatic form stays
+                pass
         if rng.integers(0, 2):
             # arbitrary injected poses: uniform, exactly on tile boundaries, a hair off them, tile centres,
             # possibly inside the goal tile (a ray that starts inside an obstacle)
@@ -107,5 +125,5 @@ for c in range(n_cfg):
         print(f"config {c} FAILED: T64={T64} R={R} B={B} seed={seed} {kw}\n   {type(e).__name__}: {str(e)[:300]}")
         if fails >= 5:
             break
-print(f"{n_cfg} random configurations, {fails} mismatches")
+print(f"{n_cfg} random configurations ({two_kernel_forms} with the two-kernel top view asked for and taken), {fails} mismatches")
 sys.exit(1 if fails else 0)

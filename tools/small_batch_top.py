@@ -9,8 +9,9 @@ CFG2 = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256)
 for B in (1, 64, 256, 1024):
     for top in (False, True):
         for split in ("1", "0") if top else ("1",):
-            os.environ["RCW_TOP_SPLIT"] = "2" if split == "1" else "0"
             env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, render_top_view=top, **CFG2)
+            if top:
+                env.set_top_view_form("two-kernels" if split == "1" else "one-kernel")
             st = torch.cuda.Stream(); env.set_stream(st.cuda_stream); torch.cuda.set_stream(st)
             a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
             for _ in range(50): RCW.act_(env, a)

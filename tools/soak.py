@@ -18,11 +18,11 @@ from oracle import oracle as O
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 top = len(sys.argv) > 2 and sys.argv[2] == "top"
-if top:
-    os.environ["RCW_TOP_SPLIT"] = "2"                      # (256 agents would take the one-kernel form)          # also render the top view every step (two-kernel form: side stream fork / join)
 B = 256
 kw = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
 env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=99, auto_reset=True, out_of_bounds=1, render_top_view=top, **kw)
+if top:
+    env.set_top_view_form("two-kernels")                   # (256 agents would take the one-kernel form): side stream fork / join every step
 orc = O.OracleBatch(B, seed=99, auto_reset=1, out_of_bounds=1, render=False, **kw)
 O.set_num_threads(16)
 rng = np.random.default_rng(0)
