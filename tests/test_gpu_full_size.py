@@ -37,7 +37,7 @@ def check_frames_against_descriptors(env, chunk=512):
     h, c = env.columns_device()
     h, c = h.torch(), c.torch()
     for a0 in range(0, env.batch, chunk):
-        want = torch_expand(h[a0:a0 + chunk], c[a0:a0 + chunk]).to(torch.int32)
+        want = torch_expand(h[a0:a0 + chunk], c[a0:a0 + chunk], Hc=obs.shape[-1]).to(torch.int32)
         got = obs[a0:a0 + chunk].view(torch.int32)
         assert torch.equal(got, want), f"frames of agents {a0}..{a0 + chunk} differ from their descriptors"
 
@@ -71,16 +71,53 @@ def test_full_size_parity(rcw, oracle, cfg, batch, steps):
     env.close()
 
 
-@pytest.mark.parametrize("cfg,batch,form", [(CFG2, 4096, "two-kernels"), (dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=512), 2048, "two-kernels"),
-                                            (CFG4, 1024, "two-kernels"), (CFG4, 4100, "two-kernels")],
-                         ids=["cfg2_4096", "reference_default_2048", "cfg4_1024", "cfg4_4100_in_runs"])
-def test_full_size_top_view(rcw, oracle, cfg, batch, form):
+@pytest.mark.parametrize("hc,cfg,batch", [(100, CFG2, 8192), (84, CFG2, 9001), (250, CFG3, 2048), (40, CFG5, 6000)],
+                         ids=["100_rows_8192x256", "84_rows_9001x256", "250_rows_2048x512", "40_rows_6000x1024"])
+def test_full_size_other_camera_heights(rcw, oracle, hc, cfg, batch):
+    """rcw_fill_flat_kernel at 0.8–1 GiB of pixels a step (height_camera_view_pu other than a power-of-two multiple of 64,
+    SR:271): 100 and 84 rows (16-byte groups inside one column; 9001 agents: the batch ends inside a chunk), 250 and 40 rows
+    (groups that straddle columns; up to eight columns a chunk).  State and descriptors of every agent against the
+    non-rendering oracle, ALL frames against the torch expansion of the descriptors, sampled frames against the oracle."""
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=11, out_of_bounds=1, height_camera_view_pu=hc, **cfg)
+    assert env.fill_kernel_name() == "rcw_fill_flat_kernel"
+    orc = oracle.OracleBatch(batch, seed=11, render=False, out_of_bounds=1, height_camera_view_pu=hc, **cfg)
+    rng = np.random.default_rng(6)
+    for s in range(5):
+        a = rng.integers(1, 5, batch).astype(np.uint8)
+        rcw.act_(env, a)
+        assert orc.step(a) == 0
+    h, c = env.columns()
+    np.testing.assert_array_equal(h, orc.col_height)
+    np.testing.assert_array_equal(c, orc.col_colour)
+    check_frames_against_descriptors(env, chunk=256)
+    mask = (rng.random(batch) < 0.3).astype(np.uint8)
+    rcw.reset_(env, mask=mask, seed=5); orc.reset(mask=mask, seed=5)
+    a = rng.integers(1, 5, batch).astype(np.uint8)
+    rcw.act_(env, a); orc.step(a)
+    check_frames_against_descriptors(env, chunk=256)
+    sample = np.unique(np.concatenate([[0, 1, batch // 2, batch - 2, batch - 1], rng.choice(batch, 11, replace=False)]))
+    small = oracle.OracleBatch(len(sample), seed=0, height_camera_view_pu=hc, **cfg)
+    small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
+    got = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
+    np.testing.assert_array_equal(got, small.camera_view)
+    env.close()
+
+
+@pytest.mark.parametrize("cfg,batch,form,pu", [(CFG2, 4096, "two-kernels", 32), (dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=512), 2048, "two-kernels", 32),
+                                               (CFG4, 1024, "two-kernels", 32), (CFG4, 4100, "two-kernels", 32),
+                                               (CFG2, 24576, "two-kernels", 13), (CFG2, 3000, "two-kernels", 20),
+                                               (dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 1999, "two-kernels", 12)],
+                         ids=["cfg2_4096", "reference_default_2048", "cfg4_1024", "cfg4_4100_in_runs",
+                              "cfg2_24576_of_104x104", "cfg2_3000_of_320x320", "room24_1999_of_288x288"])
+def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
     """The opt-in top view at full batch sizes (1 GiB of pixels a step: the two-kernel form's store kernel sweeps its
     window 16 times; 4 GiB of 512² px images: the batch goes in four runs of agents, 4100 does not divide evenly).  State of every agent against the non-rendering oracle; both images of a sample of agents (the
     first and last, around the middle, random ones) against a small rendering oracle given the same states; and over
     ALL images a size-independent property: no pixel outside the six colours update_top_view! can write (SR:288-290,
-    SR:364-367) — a chunk the store kernel skipped or wrote twice with stale descriptors would show."""
-    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=77, out_of_bounds=1, render_top_view=True, pu_per_tu=32, **cfg)
+    SR:364-367) — a chunk the store kernel skipped or wrote twice with stale descriptors would show.  The last three
+    cases go through rcw_top_store_flat_kernel (13-, 20- and 12-pixel tiles; ≈ 1 GiB, 1.1 GiB and 0.6 GiB of pixels in images whose
+    size is no multiple of a chunk, so nearly every chunk holds a border between columns or images)."""
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=77, out_of_bounds=1, render_top_view=True, pu_per_tu=pu, **cfg)
     assert env.top_view_form() == form
     orc = oracle.OracleBatch(batch, seed=77, render=False, out_of_bounds=1, **cfg)
     rng = np.random.default_rng(3)
@@ -92,7 +129,7 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form):
     np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
     np.testing.assert_array_equal(w.player_direction_au, orc.direction)
     sample = np.unique(np.concatenate([[0, 1, 3, 4, batch // 2 - 1, batch // 2, batch - 2, batch - 1], rng.choice(batch, 16, replace=False)]))
-    small = oracle.OracleBatch(len(sample), seed=0, render_top_view=1, pu_per_tu=32, **cfg)
+    small = oracle.OracleBatch(len(sample), seed=0, render_top_view=1, pu_per_tu=pu, **cfg)
     small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
     got = np.stack([env.top_view_host(int(i), 1)[0] for i in sample])
     np.testing.assert_array_equal(got, small.top_view)
@@ -102,6 +139,31 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form):
     palette = torch.tensor([0x000000, 0xFFFFFF, 0xFF0000, 0xCCCCCC, 0x808080, 0xC0C0C0], dtype=torch.int32, device=tv.device)
     for a0 in range(0, batch, 256):
         assert bool(torch.isin(tv[a0:a0 + 256], palette).all()), f"a pixel outside the palette in agents {a0}.."
+    # ... and every pixel that is neither ray grey nor circle grey is the tile layer's, rebuilt here with torch ops from
+    # the goal positions alone (SR:348-369: walls on the room's border, the goal tile, 0xCCCCCC tile borders)
+    H, W = cfg["height_tile_map_tu"], cfg["width_tile_map_tu"]
+    goal = torch.from_numpy(np.ascontiguousarray(w.goal_position)).to(tv.device).to(torch.int64)        # 1-based (i, j)
+    ii = torch.arange(H, device=tv.device).view(1, 1, H)
+    jj = torch.arange(W, device=tv.device).view(1, W, 1)
+    wall = (ii == 0) | (ii == H - 1) | (jj == 0) | (jj == W - 1)
+    edge_i = torch.arange(H * pu, device=tv.device) % pu
+    edge_j = torch.arange(W * pu, device=tv.device) % pu
+    edge = ((edge_j == 0) | (edge_j == pu - 1)).view(1, W * pu, 1) | ((edge_i == 0) | (edge_i == pu - 1)).view(1, 1, H * pu)
+    step = max(1, (64 << 20) // (H * W * pu * pu * 4))
+    rays_seen = 0
+    for a0 in range(0, batch, step):
+        g = goal[a0:a0 + step]
+        is_goal = (ii == (g[:, 0] - 1).view(-1, 1, 1)) & (jj == (g[:, 1] - 1).view(-1, 1, 1))
+        tiles = torch.where(wall, 0xFFFFFF, torch.where(is_goal, 0xFF0000, 0)).to(torch.int32)
+        layer = tiles.repeat_interleave(pu, dim=1).repeat_interleave(pu, dim=2)
+        layer = torch.where(edge, torch.tensor(0xCCCCCC, dtype=torch.int32, device=tv.device), layer)
+        got_px = tv[a0:a0 + step].reshape(layer.shape)
+        drawn = (got_px == 0x808080) | (got_px == 0xC0C0C0)
+        assert bool(((got_px == layer) | drawn).all()), f"tile layer differs in agents {a0}.."
+        per_agent = drawn.flatten(1).sum(1)
+        assert int(per_agent.min()) >= 4, "an image without a ray or circle pixel"
+        rays_seen += int(per_agent.sum())
+    assert rays_seen > batch * pu
     env.close()
 
 
