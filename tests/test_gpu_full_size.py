@@ -103,12 +103,52 @@ def test_full_size_other_camera_heights(rcw, oracle, hc, cfg, batch):
     env.close()
 
 
+def _skip_unless_free(nbytes):
+    free, _ = torch.cuda.mem_get_info()
+    if free < nbytes * 1.15 + (4 << 30):
+        pytest.skip(f"needs {nbytes / 2**30:.0f} GiB of free device memory, {free / 2**30:.0f} GiB are free")
+
+
+@pytest.mark.parametrize("hc,cfg,batch", [(256, CFG2, 70000), (100, CFG2, 170000), (250, CFG2, 70001), (256, CFG3, 400000)],
+                         ids=["256_rows_18GB", "100_rows_17GB", "250_rows_18GB", "256_rows_210GB"])
+def test_batches_beyond_2_32_pixels(rcw, oracle, hc, cfg, batch):
+    """A frame batch of more than 2^32 pixels (17–18 GB of the card's 288, and once 210 GB — the 16×16 room's 512-column frames
+    of 400,000 agents: byte offsets and pixel offsets need 64 bits, chunk and column ids still fit 32) through rcw_fill256_kernel and rcw_fill_flat_kernel: descriptors of every agent against the
+    oracle, every frame against the expansion of its descriptors, the frames either side of the 2^32-pixel and
+    2^32-byte marks and the last ones against the rendering oracle."""
+    px_agent = hc * cfg["num_rays"]
+    _skip_unless_free(4 * px_agent * batch)
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=13, out_of_bounds=1, height_camera_view_pu=hc, **cfg)
+    assert batch * px_agent > 1 << 32
+    orc = oracle.OracleBatch(batch, seed=13, render=False, out_of_bounds=1, height_camera_view_pu=hc, **cfg)
+    rng = np.random.default_rng(8)
+    for s in range(2):
+        a = rng.integers(1, 5, batch).astype(np.uint8)
+        rcw.act_(env, a)
+        assert orc.step(a) == 0
+    h, c = env.columns()
+    np.testing.assert_array_equal(h, orc.col_height)
+    np.testing.assert_array_equal(c, orc.col_colour)
+    check_frames_against_descriptors(env, chunk=1024)
+    marks = [(1 << 32) // px_agent, (1 << 30) // px_agent, (1 << 31) // px_agent]
+    sample = np.unique(np.clip(np.concatenate([[m - 1, m, m + 1] for m in marks] + [[0, batch - 2, batch - 1]]), 0, batch - 1))
+    small = oracle.OracleBatch(len(sample), seed=0, height_camera_view_pu=hc, **cfg)
+    small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
+    got = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
+    np.testing.assert_array_equal(got, small.camera_view)
+    env.close()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("cfg,batch,form,pu", [(CFG2, 4096, "two-kernels", 32), (dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=512), 2048, "two-kernels", 32),
                                                (CFG4, 1024, "two-kernels", 32), (CFG4, 4100, "two-kernels", 32),
                                                (CFG2, 24576, "two-kernels", 13), (CFG2, 3000, "two-kernels", 20),
-                                               (dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 1999, "two-kernels", 12)],
+                                               (dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 1999, "two-kernels", 12),
+                                               (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64), 70000, "two-kernels", 32),
+                                               (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=32), 420000, "two-kernels", 13)],
                          ids=["cfg2_4096", "reference_default_2048", "cfg4_1024", "cfg4_4100_in_runs",
-                              "cfg2_24576_of_104x104", "cfg2_3000_of_320x320", "room24_1999_of_288x288"])
+                              "cfg2_24576_of_104x104", "cfg2_3000_of_320x320", "room24_1999_of_288x288",
+                              "beyond_2_32_pixels_of_256x256", "beyond_2_32_pixels_of_104x104"])
 def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
     """The opt-in top view at full batch sizes (1 GiB of pixels a step: the two-kernel form's store kernel sweeps its
     window 16 times; 4 GiB of 512² px images: the batch goes in four runs of agents, 4100 does not divide evenly).  State of every agent against the non-rendering oracle; both images of a sample of agents (the
@@ -117,6 +157,7 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
     SR:364-367) — a chunk the store kernel skipped or wrote twice with stale descriptors would show.  The last three
     cases go through rcw_top_store_flat_kernel (13-, 20- and 12-pixel tiles; ≈ 1 GiB, 1.1 GiB and 0.6 GiB of pixels in images whose
     size is no multiple of a chunk, so nearly every chunk holds a border between columns or images)."""
+    _skip_unless_free(4 * batch * (cfg["height_tile_map_tu"] * cfg["width_tile_map_tu"] * pu * pu + 256 * cfg["num_rays"]))
     env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=77, out_of_bounds=1, render_top_view=True, pu_per_tu=pu, **cfg)
     assert env.top_view_form() == form
     orc = oracle.OracleBatch(batch, seed=77, render=False, out_of_bounds=1, **cfg)
