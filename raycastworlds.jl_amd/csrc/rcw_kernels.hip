@@ -517,6 +517,18 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
 // image column: the wavefront prefetches 64 descriptors (one per lane, for its next 64
 // chunks), then per chunk broadcasts one with v_readlane and lane l writes rows 4l..4l+3
 // with one 16-byte store — 64 lanes x 16 B = the whole column in one instruction.
+#ifdef RCW_TRACE_WAVES
+// Measurement build only (make trace -> lib/librcw_hip_trace.so, tools/wave_trace.py): rcw_fill256_kernel's wavefronts
+// leave the time (s_memrealtime, 100 MHz, one clock for the whole device) at which each of their groups starts its
+// descriptor loads and has them back, the time they end, and where they ran (HW_ID, XCC_ID).
+__device__ unsigned long long g_wave_trace[1024 * 40];
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int rcw_wave_trace_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 1024 * 40);
+}
+namespace {
+#endif
 template <bool PLAIN>
 __device__ __forceinline__ void store16(u32x4* dst, u32x4 v)
 {
@@ -535,7 +547,13 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
     const long long g = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
     const int r0 = lane * 4;
+#ifdef RCW_TRACE_WAVES
+    int grp = 0;
+#endif
     for (long long base = g; base < total_cols; base += G * 64) {
+#ifdef RCW_TRACE_WAVES
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         // lane l holds the descriptor of this wavefront's l-th next chunk
         const long long mine = base + (long long)lane * G;
         int pad_l = -1;                       // -1: nothing to write (past the end / masked out)
@@ -544,6 +562,12 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
             pad_l = column_padding(256, col_h[mine]);
             colour_l = p.colour[col_c[mine] & 3];
         }
+#ifdef RCW_TRACE_WAVES
+        asm volatile("" : "+v"(pad_l), "+v"(colour_l));
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && g < 1024 && grp < 18) { g_wave_trace[(g * 20 + grp) * 2] = t0; g_wave_trace[(g * 20 + grp) * 2 + 1] = t1; }
+        grp += 1;
+#endif
 #pragma unroll 4
         for (int l = 0; l < 64; ++l) {
             const int pad = __builtin_amdgcn_readlane(pad_l, l);
@@ -557,6 +581,14 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
             store16<PLAIN>(out + (base + (long long)l * G) * 64 + lane, v);
         }
     }
+#ifdef RCW_TRACE_WAVES
+    if (lane == 0 && g < 1024) {
+        g_wave_trace[(g * 20 + 19) * 2] = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        g_wave_trace[(g * 20 + 18) * 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
 }
 
 // The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of
@@ -588,10 +620,28 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_window_kernel(const RcwDev p,
             const long long col0 = M == 1 ? mine / k : mine * M;             // first (only) column of the chunk
             if (mask == nullptr || mask[col0 / p.N] != 0) {                   // (a chunk never spans two agents: N*Hc % 256 == 0 here)
                 rb_l = M == 1 ? (int)(mine - col0 * k) * 256 : 0;
+                if constexpr (M == 1) {
+                    pad_l[0] = column_padding(Hc, col_h[col0]);
+                    colour_l[0] = p.colour[col_c[col0] & 3];
+                } else {
+                    // the chunk's M columns start at a multiple of M: ONE M·4-byte and ONE M-byte load instead of 2·M scattered ones
+                    // (H_cam 64: 176 -> 163 µs per GiB, 128: 160 -> 158; at M = 4 the colours by selects, not by M more — dependent —
+                    // loads from the kernel argument's array)
+                    struct __attribute__((aligned(4 * M))) Heights { int32_t h[M]; };
+                    struct __attribute__((aligned(M))) Ids { uint8_t c[M]; };
+                    const Heights hw = *reinterpret_cast<const Heights*>(col_h + col0);
+                    const Ids cw = *reinterpret_cast<const Ids*>(col_c + col0);
 #pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    pad_l[j] = column_padding(Hc, col_h[col0 + j]);
-                    colour_l[j] = p.colour[col_c[col0 + j] & 3];
+                    for (int j = 0; j < M; ++j) {
+                        pad_l[j] = column_padding(Hc, hw.h[j]);
+                        if constexpr (M == 4) {
+                            const uint32_t id = cw.c[j];
+                            const uint32_t lo = (id & 1u) ? p.colour[1] : p.colour[0], hi = (id & 1u) ? p.colour[3] : p.colour[2];
+                            colour_l[j] = (id & 2u) ? hi : lo;
+                        } else {
+                            colour_l[j] = p.colour[cw.c[j] & 3];
+                        }
+                    }
                 }
             }
         }

@@ -1,0 +1,56 @@
+"""Dev tool (GPU box): what rcw_fill256_kernel's 1024 wavefronts do in time.  Needs the measurement build of the library
+(`make -C raycastworlds.jl_amd/csrc trace` -> lib/librcw_hip_trace.so, loaded here by path; the package never loads it):
+every wavefront leaves the s_memrealtime (100 MHz, one clock for the device) at which each of its 16 groups starts its
+descriptor loads and has them back, when it ends, and where it ran (HW_ID, XCC_ID).
+
+Prints, for cfg-2 (1 GiB a launch): the kernel's length, the pause a group's prefetch makes, how far apart the wavefronts
+run, and the end time by XCD / shader engine.  usage: python tools/wave_trace.py [reps]
+"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import raycastworlds_jl_amd as RCW
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.environ.get("RCW_LIBRARY") or os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "librcw_hip_trace.so")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+env = RCW.SingleRoomModule.SingleRoom(batch=4096, seed=1, auto_reset=True, out_of_bounds=1, library=LIB,
+                                      height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256)
+a = torch.randint(1, 5, (4096,), dtype=torch.uint8, device="cuda")
+buf = np.zeros(1024 * 40, dtype=np.uint64)
+waves = np.arange(1024)
+print(f"rcw_fill256_kernel, 4096 agents x 256 columns x 256 rows (1 GiB a launch), {reps} launches traced; times in us")
+print(" launch | kernel | prefetch pause median / max | restart spread | end spread | group period | ends: even XCDs / odd XCDs")
+ends = []
+for rep in range(reps):
+    for _ in range(4):
+        RCW.act_(env, a)
+    env.sync()
+    assert env._lib.rcw_wave_trace_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    t = buf.reshape(1024, 20, 2).astype(np.int64)
+    t0, t1, tend, hw = t[:, :16, 0], t[:, :16, 1], t[:, 19, 0], t[:, 18, 0]
+    xcc = (hw >> 32) & 0xF
+    start = t0[:, 0].min()
+    pause = (t1 - t0)[:, 1:] / 100.0
+    spread = ((t1.max(axis=0) - t1.min(axis=0)) / 100.0)[1:].mean()
+    period = np.diff(np.median(t1, axis=0)).mean() / 100.0
+    e = (tend - start) / 100.0
+    ends.append(e)
+    print(f" {rep:6d} | {e.max():6.1f} | {np.median(pause):5.2f} / {pause.max():5.2f}               | {spread:14.1f} | {e.max() - e.min():10.1f} | {period:12.2f} |"
+          f" {e[xcc % 2 == 0].mean():6.1f} / {e[xcc % 2 == 1].mean():6.1f}")
+ends = np.array(ends)
+hwid = hw & 0xFFFFFFFF
+cu, sh, se = (hwid >> 8) & 0xF, (hwid >> 12) & 1, (hwid >> 13) & 7
+print("XCC_ID of workgroups 0..15:", xcc[::4][:16].tolist(), "| wavefronts per XCC:", np.bincount(xcc, minlength=8).tolist(),
+      "| distinct CUs:", len(np.unique(xcc * 4096 + se * 512 + sh * 256 + cu)))
+print("mean end time by XCC_ID:", np.round([ends[:, xcc == x].mean() for x in range(8)], 1).tolist())
+print("mean end time by shader engine within XCC 0 / XCC 1:", np.round([ends[:, (xcc == 0) & (se == x)].mean() for x in range(4)], 1).tolist(),
+      "/", np.round([ends[:, (xcc == 1) & (se == x)].mean() for x in range(4)], 1).tolist())
+c = np.corrcoef(ends)
+print("correlation of the per-wavefront end times between launches:", round(float((c.sum() - reps) / (reps * reps - reps)), 3))
+env.close()
