@@ -44,6 +44,13 @@ for rep in range(reps):
     print(f" {rep:6d} | {e.max():6.1f} | {np.median(pause):5.2f} / {pause.max():5.2f}               | {spread:14.1f} | {e.max() - e.min():10.1f} | {period:12.2f} |"
           f" {e[xcc % 2 == 0].mean():6.1f} / {e[xcc % 2 == 1].mean():6.1f}")
 ends = np.array(ends)
+# the last traced launch in detail: where do the odd XCDs lose their time — in the prefetch pause or in the store loop?
+loop = (t0[:, 1:] - t1[:, :-1]) / 100.0                      # 64 chunks' stores of group k (issue time, incl. back-pressure)
+pz = (t1 - t0) / 100.0
+for name, sel in (("even XCDs", xcc % 2 == 0), ("odd XCDs ", xcc % 2 == 1)):
+    print(f"{name}: prefetch pause by group (median over wavefronts):", np.round(np.median(pz[sel], axis=0), 2).tolist())
+    print(f"{name}: store loop by group:", np.round(np.median(loop[sel], axis=0), 2).tolist())
+    print(f"{name}: sum of pauses {np.median(pz[sel].sum(axis=1)):.1f}, sum of store loops {np.median(loop[sel].sum(axis=1)):.1f}, first group starts at {np.median(t0[sel, 0] - start) / 100.0:.2f}")
 hwid = hw & 0xFFFFFFFF
 cu, sh, se = (hwid >> 8) & 0xF, (hwid >> 12) & 1, (hwid >> 13) & 7
 print("XCC_ID of workgroups 0..15:", xcc[::4][:16].tolist(), "| wavefronts per XCC:", np.bincount(xcc, minlength=8).tolist(),
