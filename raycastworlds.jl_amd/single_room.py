@@ -98,6 +98,16 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         self._torch = t.view(torch.bool) if self.dtype == np.bool_ else t
         return self._torch
 
+    # DLPack (the array-API exchange protocol: `jax.dlpack.from_dlpack(x)`, `cupy.from_dlpack(x)`, `torch.from_dlpack(x)`):
+    # the same zero-copy alias, handed over by the cached torch tensor.  The consumer's stream is ordered behind the
+    # engine's by one host synchronisation at export, as with __cuda_array_interface__.
+    def __dlpack__(self, stream=None, **kwargs):
+        t = self.torch(sync=True)
+        return t.__dlpack__(**kwargs) if stream is None else t.__dlpack__(stream=stream, **kwargs)
+
+    def __dlpack_device__(self):
+        return self.torch(sync=False).__dlpack_device__()
+
     def numpy(self) -> np.ndarray:
         """Copy to host (waits for the engine's stream)."""
         if self._host_getter is not None:

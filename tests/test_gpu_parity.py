@@ -148,6 +148,14 @@ def test_state_aliases_device_buffer(rcw, oracle):
     assert s0.ptr == s1.ptr
     env.sync()
     np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), orc.camera_view)
+    # the same alias through DLPack (what jax / cupy would take): no copy, the engine's pointer
+    d = torch.from_dlpack(s1)
+    assert d.data_ptr() == s0.ptr and d.dtype == torch.uint32 and tuple(d.shape) == s0.shape
+    assert torch.from_dlpack(rcw.RLBase.is_terminated(rl)).dtype == torch.bool
+    rl(4)
+    orc.step(np.full(4, 4, dtype=np.uint8))
+    env.sync()
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), orc.camera_view)
     env.close()
 
 
