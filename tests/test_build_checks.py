@@ -18,3 +18,41 @@ def test_no_register_is_touched_between_an_asynchronous_load_and_its_wait():
                           os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "asm", "rcw_kernels.s")], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-4000:]
     assert "asynchronous loads checked" in res.stdout and not res.stdout.startswith("0 ")
+
+
+SYNTHETIC = """\
+_Z{name}:
+	v_mov_b32_e32 v1, 0
+	;;#ASMSTART
+	global_load_dword v5, v[2:3], off
+	;;#ASMEND
+{between}
+.LBB0_1:
+	global_store_dwordx4 v[8:9], v[10:13], off nt
+	s_cbranch_scc1 .LBB0_1
+	;;#ASMSTART
+	s_waitcnt vmcnt(63)
+	;;#ASMEND
+	v_add_u32_e32 v6, v5, v5
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def _check(tmp_path, text):
+    f = tmp_path / "k.s"
+    f.write_text(text)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_loads.py"), str(f)], capture_output=True, text=True)
+
+
+def test_the_checker_sees_a_hazard_when_there_is_one(tmp_path):
+    """The guard itself: a clean kernel passes; a register copy slipped in between the load and its wait, a use on one
+    branch only, and a use inside the store loop are each reported."""
+    ok = _check(tmp_path, SYNTHETIC.format(name="clean", between="\tv_add_u32_e32 v7, v1, v1"))
+    assert ok.returncode == 0 and "1 asynchronous loads, 0 hazards" in ok.stdout, ok.stdout
+    copy = _check(tmp_path, SYNTHETIC.format(name="copy", between="\tv_mov_b32_e32 v9, v5"))
+    assert copy.returncode == 1 and "HAZARD" in copy.stdout and "v_mov_b32_e32 v9, v5" in copy.stdout, copy.stdout
+    branch = _check(tmp_path, SYNTHETIC.format(name="branch", between="\ts_cbranch_scc0 .LBB0_1\n\tv_add_u32_e32 v7, v5, v1"))
+    assert branch.returncode == 1 and "HAZARD" in branch.stdout, branch.stdout
+    in_loop = _check(tmp_path, SYNTHETIC.format(name="loop", between="").replace("global_store_dwordx4 v[8:9], v[10:13]", "global_store_dwordx4 v[4:5], v[10:13]"))
+    assert in_loop.returncode == 1 and "HAZARD" in in_loop.stdout and "global_store_dwordx4 v[4:5]" in in_loop.stdout, in_loop.stdout
