@@ -14,7 +14,7 @@
 //            lanes mapped along the image's contiguous axis (rows of one column, Julia
 //            column-major), one 16-byte store per lane, one whole 1 KiB column per wavefront
 //            store instruction at H_cam = 256 (rcw_fill256_kernel); rcw_fill_window_kernel for
-//            256 k / 128 / 64 rows, rcw_fill_flat_kernel for every other height from 37 rows
+//            256 k / 128 / 64 rows, rcw_fill_flat_kernel for every other height from 24 rows
 //            (256-pixel chunks of the flat batch, each lane finds its own column).
 // This is an integer/indexing + streaming-store path: no MFMA, the roofline is HBM write
 // bandwidth, and the frame (4·H_cam·N bytes per agent-step) is written exactly once.
@@ -45,7 +45,7 @@
 namespace {
 
 constexpr int kBlock = 256;   // 4 wavefronts of 64
-constexpr int kFlatMaxCols = 8;   // image columns a 256-pixel chunk of the flat batch may touch (rcw_fill_flat_kernel, rcw_top_store_flat_kernel)
+constexpr int kFlatMaxCols = 12;   // image columns a 256-pixel chunk of the flat batch may touch in rcw_fill_flat_kernel (H_cam >= 24; 53 KiB of descriptors in LDS)
 
 // 16-byte store unit (a native vector, so __builtin_nontemporal_store accepts it)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_window_kernel(const RcwDev p,
     }
 }
 
-// The moving window for ANY camera height of at least 37 rows (height_camera_view_pu is a free kwarg, SR:271): a chunk
+// The moving window for ANY camera height of at least 24 rows (height_camera_view_pu is a free kwarg, SR:271): a chunk
 // is 256 consecutive pixels of the flat (H_cam, N, B) batch, whatever columns they belong to.  A chunk that starts at
 // row rem0 of its first column touches at most K = 254 / H_cam + 2 columns; lane l of the prefetch finds (first
 // column, rem0) of the wavefront's l-th next chunk — carried from group to group as (quotient, remainder), no division
@@ -2315,7 +2315,7 @@ static FillKernel fill_choice(const RcwDev& p, long long total_cols)
     if (p.Hc == 256) return kFill256;
     if ((p.Hc & 255) == 0) return kFillWindow1;                             // a 1 KiB chunk is a row block of one column
     if ((p.Hc == 128 || p.Hc == 64) && ((long long)p.N * p.Hc) % 256 == 0 && !p.fill_flat) return p.Hc == 128 ? kFillWindow2 : kFillWindow4;   // 2 / 4 whole columns
-    if (rcw_fill_flat_cols(p) && total_cols < (1ll << 31) - 16) return kFillFlat;   // any other height of at least 37 rows
+    if (rcw_fill_flat_cols(p) && total_cols < (1ll << 31) - 16) return kFillFlat;   // any other height of at least 24 rows
     if (p.N <= 8192 && (long long)p.N * p.Hc < (1ll << 25)) return kFillFrame;
     return kFillAny;
 }
@@ -2357,6 +2357,7 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
 #define RCW_FILL_FLAT(AL, KK) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev)
 #define RCW_FILL_FLAT_K(KK) case KK: if ((p.Hc & 3) == 0) RCW_FILL_FLAT(true, KK); else RCW_FILL_FLAT(false, KK); break
         switch (K) { RCW_FILL_FLAT_K(2); RCW_FILL_FLAT_K(3); RCW_FILL_FLAT_K(4); RCW_FILL_FLAT_K(5); RCW_FILL_FLAT_K(6); RCW_FILL_FLAT_K(7); RCW_FILL_FLAT_K(8);
+                     RCW_FILL_FLAT_K(9); RCW_FILL_FLAT_K(10); RCW_FILL_FLAT_K(11); RCW_FILL_FLAT_K(12);
                      default: return hipErrorInvalidValue; }
 #undef RCW_FILL_FLAT_K
 #undef RCW_FILL_FLAT

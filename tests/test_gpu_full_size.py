@@ -71,8 +71,8 @@ def test_full_size_parity(rcw, oracle, cfg, batch, steps):
     env.close()
 
 
-@pytest.mark.parametrize("hc,cfg,batch", [(100, CFG2, 8192), (84, CFG2, 9001), (250, CFG3, 2048), (40, CFG5, 6000)],
-                         ids=["100_rows_8192x256", "84_rows_9001x256", "250_rows_2048x512", "40_rows_6000x1024"])
+@pytest.mark.parametrize("hc,cfg,batch", [(100, CFG2, 8192), (84, CFG2, 9001), (250, CFG3, 2048), (40, CFG5, 6000), (27, CFG2, 30000)],
+                         ids=["100_rows_8192x256", "84_rows_9001x256", "250_rows_2048x512", "40_rows_6000x1024", "27_rows_30000x256"])
 def test_full_size_other_camera_heights(rcw, oracle, hc, cfg, batch):
     """rcw_fill_flat_kernel at 0.8–1 GiB of pixels a step (height_camera_view_pu other than a power-of-two multiple of 64,
     SR:271): 100 and 84 rows (16-byte groups inside one column; 9001 agents: the batch ends inside a chunk), 250 and 40 rows

@@ -221,18 +221,20 @@ def test_rlbase_verbs_are_device_resident_and_do_not_synchronise(rcw, oracle):
 def test_odd_camera_heights(rcw, oracle):
     """H_cam other than 256 (height_camera_view_pu, SR:271): the moving-window kernel for 64 / 128 / 512 / 768 (chunks of
     whole columns or row blocks); rcw_fill_flat_kernel — 256-pixel chunks of the flat batch, each lane finding its own
-    column — for every other height from 37 rows (84, 100, 300: 16-byte groups inside one column; 250, 37, 99, 257: groups
-    that straddle two columns; batches whose pixel count is not a multiple of 256 or of 4: a short last chunk); the
-    frame-per-workgroup kernel below 37 rows (36: 16-byte stores; 21: 4-byte stores); with a masked reset in between
+    column — for every other height from 24 rows (84, 100, 300, 36, 24: 16-byte groups inside one column; 250, 37, 99, 257, 27,
+    31, 25: groups that straddle two columns; batches whose pixel count is not a multiple of 256 or of 4: a short last chunk;
+    up to twelve columns a chunk at 24 rows); the frame-per-workgroup kernel below 24 rows (20: 16-byte stores; 21, 23:
+    4-byte stores); with a masked reset in between
     (the mask path of each kernel: chunks at a masked agent's border are written pixel by pixel)."""
     rng = np.random.default_rng(1)
     want = {64: "rcw_fill_window_kernel", 128: "rcw_fill_window_kernel", 512: "rcw_fill_window_kernel", 768: "rcw_fill_window_kernel",
-            36: "rcw_fill_frame_kernel", 21: "rcw_fill_frame_kernel"}
+            20: "rcw_fill_frame_kernel", 21: "rcw_fill_frame_kernel", 23: "rcw_fill_frame_kernel"}
     for hc, cfg in ((64, CFG1), (128, CFG1), (512, CFG1), (768, CFG1), (250, CFG1), (37, CFG1), (84, CFG2), (100, CFG2), (300, CFG1),
                     (99, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=33)),     # 9 x 33 x 99 pixels: not a multiple of 4
                     (257, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=65)),
                     (1000, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=31)),
-                    (36, CFG1), (21, CFG1),
+                    (36, CFG1), (21, CFG1), (24, CFG2), (27, CFG1), (31, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=100)),
+                    (25, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=7)), (20, CFG1), (23, CFG1),
                     (64, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=66)),
                     (128, dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=33))):
         env, orc = _make(rcw, oracle, 9, seed=3, height_camera_view_pu=hc, **cfg)

@@ -6,7 +6,7 @@ height, world-unit type, the three unpinned switches, both BoundsError policies,
     python tools/fuzz_parity.py [configs] [seed] [top|split|flat]   # "top": every configuration renders the top view;
                                                                    # "split": ... with a geometry of the unit store kernels;
                                                                    # "flat": ... of the flat store kernel (any pu >= 9), and any
-                                                                   #         camera height from 37 rows (the flat fill kernel)
+                                                                   #         camera height from 24 rows (the flat fill kernel)
 """
 import os
 import sys
@@ -62,7 +62,7 @@ for c in range(n_cfg):
             H += (4 - H % 4) % 4 if pu % 2 else (2 - H % 2) % 2
         kw["height_tile_map_tu"] = max(H, 4)
         kw["width_tile_map_tu"] = int(rng.integers(4, 14))
-        kw["height_camera_view_pu"] = int(rng.choice([int(rng.integers(37, 700)), 84, 100, 250, 300, 333, 40]))
+        kw["height_camera_view_pu"] = int(rng.choice([int(rng.integers(24, 700)), int(rng.integers(24, 48)), 84, 100, 250, 300, 333, 40]))
         B = int(rng.integers(1, 30))
     seed = int(rng.integers(0, 2**31))
     okw = {k: v for k, v in kw.items()}
