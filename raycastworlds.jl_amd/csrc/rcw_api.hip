@@ -722,8 +722,10 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // fill kernel: one workgroup per CU (256 on an MI355X in SPX mode; a partitioned device reports fewer)
     d.fill_grid = h->num_cus; d.fill_plain = 0; d.fill_flat = 0;
-    // cast kernel: two view columns per lane (measured best at 4096 x 256), 64..256 threads per agent
-    { const int lanes = (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
+    // lanes per agent in the cast kernel: four rays a lane once the batch fills the chip (measured, µs: 512 columns 45.6 vs 51.4
+    // with two a lane, 256 columns 12.3 vs 12.7; 1024 columns take 256 lanes either way), two a lane for small batches, where
+    // an agent's own latency is what counts
+    { const int lanes = h->B >= 1024 ? (N + 3) / 4 : (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
     d.cast_ballot = 0; d.cast_table_lds = 0; d.top_debug = 0;
     // development builds (make dev: -DRCW_DEV_SWITCHES -> librcw_hip_dev.so) read tuning knobs and the measured-and-rejected
     // kernel variants from the environment; the shipped library reads nothing but RCW_RCCL_LIBRARY
