@@ -20,8 +20,18 @@ def test_random_configurations_stay_in_parity():
 
 def test_random_flat_kernel_geometries_stay_in_parity():
     """The same over the geometries only the flat kernels take: top views at 9..60 pixels a tile (two-kernel form asked
-    for) and camera heights anywhere from 37 rows."""
+    for) and camera heights anywhere from 24 rows."""
     res = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "77", "flat"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert "80 random configurations" in res.stdout and ", 0 mismatches" in res.stdout
+
+
+def test_random_sequences_of_api_calls_stay_in_parity():
+    """tools/api_fuzz.py: 12 handles x 50 random calls — steps with host / device / scalar actions, masked and full resets,
+    injected states, rejected actions, another stream, another output buffer, another top-view form, stand-alone
+    re-renders, rays, descriptor expansion, profiling — every observable compared with the oracle after every call."""
+    res = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tools", "api_fuzz.py"), "12", "5", "50"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "12 runs x 50 calls, every observable equal" in res.stdout

@@ -711,6 +711,39 @@ def test_top_view_forms_write_the_same_pixels(rcw, oracle, form):
         env.close()
 
 
+def test_masked_render_right_after_a_change_of_form(rcw, oracle):
+    """Found by tools/api_fuzz.py: rcw_set_top_view_form allocates the two-kernel form's line planes; the re-render that
+    follows may be the one-kernel form (12-pixel tiles: stand-alone calls take it), which writes no planes; a MASKED render
+    next draws the masked agents' planes only, and the flat store kernel ORs in the first words of the unmasked
+    neighbour's region for the chunk the two share — uninitialised memory, unless the planes start out zero."""
+    import ctypes as C
+
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    kw = dict(height_tile_map_tu=5, width_tile_map_tu=5, num_rays=7, height_camera_view_pu=512, pu_per_tu=12)
+    for trial in range(4):
+        env, orc = _make(rcw, oracle, 64, seed=100 + trial, render_top_view=1, **kw)
+        assert env.top_view_form() == "one-kernel"
+        # leave all-ones blocks of the planes' size in the device allocator, for the planes to land on
+        blocks = []
+        for _ in range(8):
+            p = C.c_void_p()
+            env._check(env._lib.rcw_device_malloc(env._h, 64 * 128 * 4 + 64, C.byref(p)))
+            blocks.append(p)
+            alias = rcw.SingleRoomModule.DeviceArray(p.value, (64 * 128 + 16,), np.int32, env, env._sync).torch(sync=False)
+            alias.fill_(-1)
+        torch.cuda.synchronize()
+        for p in blocks:
+            env._check(env._lib.rcw_device_free(env._h, p))
+        env.set_top_view_form("two-kernels", runs=2)
+        rcw.update_top_view_(env)                                            # (one-kernel form: 12-pixel tiles, stand-alone)
+        mask = (rng.random(64) < 0.6).astype(np.uint8)
+        rcw.reset_(env, mask=mask, seed=7 + trial); orc.reset(mask=mask, seed=7 + trial)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"trial {trial}")
+        assert_state_equal(env, orc, where=f"masked reset after the change of form, trial {trial}")
+        env.close()
+
+
 def test_top_view_form_of_other_geometries(rcw):
     """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form — and so
     does a batch too small to pay for two more launches and a stream fork / join (below 256 MiB of top view a step),

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): stateful fuzzing of the host API.  Random SEQUENCES of calls — steps with host / device / scalar
+actions, masked and full resets, injected states, rejected actions, another stream, another output buffer
+(rcw_bind_obs), another top-view form, stand-alone re-renders, ray materialisation, descriptor expansion, profiling
+on / off — against the CPU oracle driven by the same sequence; every observable is compared after every call.
+
+    python tools/api_fuzz.py [runs] [seed] [ops per run]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+
+import raycastworlds_jl_amd as RCW
+from helpers import assert_state_equal
+from oracle import oracle as O
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+O.set_num_threads(8)
+GEOMETRIES = (
+    dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64),
+    dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=100, height_camera_view_pu=100),
+    dict(height_tile_map_tu=12, width_tile_map_tu=7, num_rays=33, height_camera_view_pu=37),
+    dict(height_tile_map_tu=6, width_tile_map_tu=9, num_rays=256, height_camera_view_pu=64),
+    dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=128, height_camera_view_pu=27),
+    dict(height_tile_map_tu=5, width_tile_map_tu=5, num_rays=7, height_camera_view_pu=512),
+)
+counts = {}
+for run in range(runs):
+    kw = dict(GEOMETRIES[int(rng.integers(len(GEOMETRIES)))])
+    B = int(rng.choice([1, 7, 64, 300]))
+    top = bool(rng.integers(0, 2))
+    if top:
+        kw.update(render_top_view=True, pu_per_tu=int(rng.choice([8, 12, 13, 16, 32])))
+    if rng.integers(0, 4) == 0:
+        kw["T"] = "Float64"
+    auto = bool(rng.integers(0, 2))
+    seed = int(rng.integers(1, 1 << 30))
+    env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, auto_reset=auto, out_of_bounds=1, **kw)
+    okw = {k: v for k, v in kw.items() if k not in ("T",)}
+    if kw.get("T") == "Float64":
+        okw["world_unit_bits"] = 64
+    if top:
+        okw["render_top_view"] = 1
+    orc = O.OracleBatch(B, seed=seed, auto_reset=1 if auto else 0, out_of_bounds=1, **okw)
+    H, W, N, Hc = kw["height_tile_map_tu"], kw["width_tile_map_tu"], kw["num_rays"], kw.get("height_camera_view_pu", 256)
+    keep = []                                                # buffers / streams handed to the engine stay alive for the run
+
+    def check(where, rays=False):
+        assert_state_equal(env, orc, rays=rays, where=where)
+        np.testing.assert_array_equal(env.world.episode, orc.episode, err_msg=f"episode {where}")
+        if top:
+            np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"top_view {where}")
+
+    check(f"run {run} after create")
+    log, last, last_form = [], {}, None
+    try:
+        for k in range(n_ops):
+            op = str(rng.choice(["act_host", "act_host", "act_device", "act_device", "act_scalar", "reset_mask", "reset_all", "set_state",
+                                 "bad_action", "stream", "bind_obs", "form", "rerender", "rays", "expand", "profile"]))
+            log.append(op)
+            counts[op] = counts.get(op, 0) + 1
+            if op in ("act_host", "act_device"):
+                a = rng.integers(1, 5, B).astype(np.uint8)
+                RCW.act_(env, a if op == "act_host" else torch.from_numpy(a).cuda())
+                assert orc.step(a) == 0
+            elif op == "act_scalar":
+                a = int(rng.integers(1, 5))
+                RCW.act_(env, a)
+                assert orc.step(np.full(B, a, dtype=np.uint8)) == 0
+            elif op in ("reset_mask", "reset_all"):
+                mask = (rng.random(B) < 0.5).astype(np.uint8) if op == "reset_mask" else None
+                s = int(rng.integers(0, 1 << 30))
+                RCW.reset_(env, mask=mask, seed=s)
+                orc.reset(mask=mask, seed=s)
+            elif op == "set_state":
+                if H < 4:
+                    continue                                 # (no second free interior row to move the player to)
+                goal = np.stack([rng.integers(2, H, B), rng.integers(2, W, B)], axis=1).astype(np.int32)
+                tile = np.stack([rng.integers(2, H, B), rng.integers(2, W, B)], axis=1)
+                same = (tile == goal).all(axis=1)                # the player never starts on the goal tile (SR:124)
+                tile[same, 0] = np.where(goal[same, 0] > 2, goal[same, 0] - 1, goal[same, 0] + 1)
+                pos = (tile - 0.5).astype(np.float64 if kw.get("T") == "Float64" else np.float32)
+                d = rng.integers(0, 128, B).astype(np.int32)
+                mask = (rng.random(B) < 0.6).astype(np.uint8) if rng.integers(0, 2) else None
+                last = dict(op=op, mask=None if mask is None else mask.tolist())
+                env.set_state(goal, pos, d, mask=mask)
+                orc.set_state(goal, pos, d, mask=mask)
+            elif op == "bad_action":
+                a = rng.integers(1, 5, B).astype(np.uint8)
+                a[int(rng.integers(0, B))] = int(rng.choice([0, 5, 255]))
+                try:
+                    RCW.act_(env, a)
+                    raise SystemExit("an invalid action was accepted")
+                except AssertionError:
+                    pass
+                assert orc.step(a) == -2
+            elif op == "stream":
+                choice = int(rng.integers(0, 3))
+                st = torch.cuda.Stream() if choice else None
+                keep.append(st)
+                env.sync()
+                env.set_stream(st if choice != 2 else st.cuda_stream)
+            elif op == "bind_obs":
+                if rng.integers(0, 3) == 0:
+                    env.sync(); env.bind_obs(None)
+                else:
+                    buf = torch.empty(B * N * Hc, dtype=torch.int32, device="cuda")
+                    keep.append(buf)
+                    env.sync(); env.bind_obs(buf.data_ptr())
+                RCW.update_camera_view_(env)                 # (the new buffer holds nothing yet: SR:374's call fills it)
+            elif op == "form":
+                if not top:
+                    continue
+                form = [None, "one-kernel", "two-kernels", "in-place"][int(rng.integers(0, 4))]
+                try:
+                    nr = int(rng.integers(0, 4))
+                    last_form = (form, nr)
+                    env.set_top_view_form(form, runs=nr)
+                except (RuntimeError, ValueError, AssertionError, NotImplementedError):
+                    pass                                     # (a form this geometry cannot take is refused, nothing changes)
+                RCW.update_top_view_(env)
+            elif op == "rerender":
+                RCW.update_camera_view_(env)
+                if top:
+                    RCW.update_top_view_(env)
+            elif op == "rays":
+                check(f"run {run} op {k} rays", rays=True)
+            elif op == "expand":
+                h, c = env.columns_device()
+                out = env.expand_columns(h.torch(), c.torch())
+                env.sync()
+                np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(orc.camera_view.shape), orc.camera_view)
+            elif op == "profile":
+                env.profile(bool(rng.integers(0, 2)))
+            check(f"run {run} op {k} ({op})")
+    except BaseException:
+        print(f"FAILED in run {run}: B={B} top={top} auto_reset={auto} kw={kw}\n  ops: {log}\n  last arguments: {last}, last form asked: {last_form}", flush=True)
+        if top:
+            print(f"  top view form now: {env.top_view_form()}")
+            try:
+                env.clear_error()
+                diff = (env.top_view_host() != orc.top_view).reshape(B, -1)
+                bad = np.nonzero(diff.any(axis=1))[0]
+                print(f"  agents with wrong top-view pixels: {bad.tolist()} ({diff.sum(axis=1)[bad].tolist()} pixels)")
+                a0 = int(bad[0]); q = np.nonzero(diff[a0])[0]
+                print(f"  agent {a0}: flat pixel offsets {q[:40].tolist()} got {env.top_view_host(a0, 1).reshape(-1)[q[:8]].tolist()} want {orc.top_view[a0].reshape(-1)[q[:8]].tolist()}")
+                RCW.update_top_view_(env)
+                diff2 = (env.top_view_host() != orc.top_view).reshape(B, -1)
+                print(f"  after one more rcw_update_top_view: {int(diff2.sum())} wrong pixels")
+            except Exception as e:                           # noqa: BLE001
+                print("  (diagnosis failed:", e, ")")
+        raise
+    env.close(); orc.close()
+    if run % 5 == 4:
+        print(f"run {run + 1} ok", flush=True)
+print(f"{runs} runs x {n_ops} calls, every observable equal to the oracle's after every call; calls made: {dict(sorted(counts.items()))}")
