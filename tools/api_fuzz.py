@@ -29,6 +29,10 @@ GEOMETRIES = (
     dict(height_tile_map_tu=6, width_tile_map_tu=9, num_rays=256, height_camera_view_pu=64),
     dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=128, height_camera_view_pu=27),
     dict(height_tile_map_tu=5, width_tile_map_tu=5, num_rays=7, height_camera_view_pu=512),
+    dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256),
+    dict(height_tile_map_tu=9, width_tile_map_tu=11, num_rays=150, height_camera_view_pu=250),
+    dict(height_tile_map_tu=4, width_tile_map_tu=20, num_rays=64, height_camera_view_pu=24, player_radius_wu=0.3, position_increment_wu=0.2),
+    dict(height_tile_map_tu=32, width_tile_map_tu=32, num_rays=64, height_camera_view_pu=128),
 )
 counts = {}
 for run in range(runs):
@@ -36,15 +40,18 @@ for run in range(runs):
     B = int(rng.choice([1, 7, 64, 300]))
     top = bool(rng.integers(0, 2))
     if top:
-        kw.update(render_top_view=True, pu_per_tu=int(rng.choice([8, 12, 13, 16, 32])))
+        kw.update(render_top_view=True, pu_per_tu=int(rng.choice([8, 10, 12, 13, 16, 20, 24, 32])))
     if rng.integers(0, 4) == 0:
         kw["T"] = "Float64"
     auto = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, auto_reset=auto, out_of_bounds=1, **kw)
     okw = {k: v for k, v in kw.items() if k not in ("T",)}
-    if kw.get("T") == "Float64":
+    if kw.get("T") == "Float64":                              # convert(Float64, .) of the same kwargs (SR:263-270)
         okw["world_unit_bits"] = 64
+        for key in ("player_radius_wu", "position_increment_wu", "semi_field_of_view_wu", "camera_height_tile_wu"):
+            if key in kw:
+                okw[key + "_f64"] = float(kw[key])
     if top:
         okw["render_top_view"] = 1
     orc = O.OracleBatch(B, seed=seed, auto_reset=1 if auto else 0, out_of_bounds=1, **okw)
