@@ -4,10 +4,22 @@ actions, masked and full resets, injected states, rejected actions, another stre
 (rcw_bind_obs), another top-view form, stand-alone re-renders, ray materialisation, descriptor expansion, profiling
 on / off — against the CPU oracle driven by the same sequence; every observable is compared after every call.
 
-    python tools/api_fuzz.py [runs] [seed] [ops per run]
+    python tools/api_fuzz.py [runs] [seed] [ops per run] [sharded]
+
+"sharded": the engine sits behind ShardedSingleRoom in a torch.distributed "nccl" (= RCCL) group of ONE rank, with the
+collective forced, and the observation gather — both transports (torch.distributed / the library's own ncclAllGather),
+both modes (columns + expansion / frames) — joins the calls.
 """
 import os
+import socket
 import sys
+
+SHARDED = len(sys.argv) > 4 and sys.argv[4] == "sharded"
+if SHARDED:                                                  # (the rendezvous variables before anything touches the GPU)
+    with socket.socket() as _s:
+        _s.bind(("127.0.0.1", 0))
+        _port = _s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -22,6 +34,11 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 O.set_num_threads(8)
+if SHARDED:
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 GEOMETRIES = (
     dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64),
     dict(height_tile_map_tu=8, width_tile_map_tu=16, num_rays=100, height_camera_view_pu=100),
@@ -45,7 +62,11 @@ for run in range(runs):
         kw["T"] = "Float64"
     auto = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
-    env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, auto_reset=auto, out_of_bounds=1, **kw)
+    if SHARDED:
+        sh = RCW.ShardedSingleRoom(B, collective="always", device=0, seed=seed, auto_reset=auto, out_of_bounds=1, **kw)
+        env = sh.env
+    else:
+        env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=seed, auto_reset=auto, out_of_bounds=1, **kw)
     okw = {k: v for k, v in kw.items() if k not in ("T",)}
     if kw.get("T") == "Float64":                              # convert(Float64, .) of the same kwargs (SR:263-270)
         okw["world_unit_bits"] = 64
@@ -69,7 +90,8 @@ for run in range(runs):
     try:
         for k in range(n_ops):
             op = str(rng.choice(["act_host", "act_host", "act_device", "act_device", "act_scalar", "reset_mask", "reset_all", "set_state",
-                                 "bad_action", "stream", "bind_obs", "form", "rerender", "rays", "expand", "profile"]))
+                                 "bad_action", "stream", "bind_obs", "form", "rerender", "rays", "expand", "profile"]
+                                + (["gather_columns", "gather_columns_abi", "gather_obs", "gather_obs_abi"] * 2 if SHARDED else [])))
             log.append(op)
             counts[op] = counts.get(op, 0) + 1
             if op in ("act_host", "act_device"):
@@ -145,6 +167,16 @@ for run in range(runs):
                 np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(orc.camera_view.shape), orc.camera_view)
             elif op == "profile":
                 env.profile(bool(rng.integers(0, 2)))
+            elif op in ("gather_columns", "gather_columns_abi"):
+                gh, gc = sh.gather_columns() if op == "gather_columns" else sh.gather_columns_abi()
+                env.sync()
+                np.testing.assert_array_equal(gh.cpu().numpy(), orc.col_height, err_msg=op)
+                np.testing.assert_array_equal(gc.cpu().numpy(), orc.col_colour, err_msg=op)
+            elif op in ("gather_obs", "gather_obs_abi"):
+                mode = str(rng.choice(["columns", "frames"]))
+                frames = sh.gather_observations(mode) if op == "gather_obs" else sh.gather_observations_abi(mode)
+                env.sync()
+                np.testing.assert_array_equal(frames.cpu().numpy().view(np.uint32).reshape(orc.camera_view.shape), orc.camera_view, err_msg=f"{op} {mode}")
             check(f"run {run} op {k} ({op})")
     except BaseException:
         print(f"FAILED in run {run}: B={B} top={top} auto_reset={auto} kw={kw}\n  ops: {log}\n  last arguments: {last}, last form asked: {last_form}", flush=True)
@@ -163,7 +195,11 @@ for run in range(runs):
             except Exception as e:                           # noqa: BLE001
                 print("  (diagnosis failed:", e, ")")
         raise
+    if SHARDED:
+        sh.close()
     env.close(); orc.close()
     if run % 5 == 4:
         print(f"run {run + 1} ok", flush=True)
 print(f"{runs} runs x {n_ops} calls, every observable equal to the oracle's after every call; calls made: {dict(sorted(counts.items()))}")
+if SHARDED:
+    dist.destroy_process_group()
