@@ -93,3 +93,29 @@ def test_shipped_library_reads_no_development_switch(rcw):
         # the development build exports the same ABI
         lib = C.CDLL(_capi.DEV_LIB_PATH)
         assert not [n for n in _declared() if not hasattr(lib, n)]
+
+
+def test_every_entry_point_refuses_a_null_handle(rcw):
+    """No entry point dereferences a NULL handle: each returns a negative RCW_ERR_* with a message (rcw_destroy(NULL) is a
+    no-op, like free).  Runs without a GPU: the check comes before any HIP call."""
+    from raycastworlds_jl_amd import _capi
+
+    lib = _capi.load()
+    called = 0
+    for name, sig in _capi.SIGNATURES.items():
+        if not sig or sig[0] is not C.c_void_p or name in ("rcw_destroy",):
+            continue
+        args = [None]
+        for t in sig[1:]:
+            if t in (C.c_float, C.c_double):
+                args.append(0.0)
+            elif t is C.c_void_p or hasattr(t, "contents"):
+                args.append(None)
+            else:
+                args.append(t(0))
+        rc = getattr(lib, name)(*args)
+        assert isinstance(rc, int) and rc < 0, (name, rc)
+        assert _capi.last_error(lib), name
+        called += 1
+    assert called >= 50
+    assert lib.rcw_destroy(None) == 0
