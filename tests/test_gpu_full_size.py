@@ -68,6 +68,20 @@ def test_full_size_parity(rcw, oracle, cfg, batch, steps):
     small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
     got = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
     np.testing.assert_array_equal(got, small.camera_view)
+    # a masked reset (the fill kernel's mask path: whole chunks of masked-out agents are skipped) and one more step
+    mask = (rng.random(batch) < 0.35).astype(np.uint8)
+    rcw.reset_(env, mask=mask, seed=321); orc.reset(mask=mask, seed=321)
+    h, c = env.columns()
+    np.testing.assert_array_equal(h, orc.col_height)
+    np.testing.assert_array_equal(c, orc.col_colour)
+    check_frames_against_descriptors(env)
+    a = rng.integers(1, 5, batch).astype(np.uint8)
+    rcw.act_(env, a)
+    assert orc.step(a) == 0
+    np.testing.assert_array_equal(env.world.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
+    h, c = env.columns()
+    np.testing.assert_array_equal(h, orc.col_height)
+    check_frames_against_descriptors(env)
     env.close()
 
 
@@ -166,45 +180,59 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
         a = rng.integers(1, 5, batch).astype(np.uint8)
         rcw.act_(env, a)
         assert orc.step(a) == 0
-    w = env.world
-    np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
-    np.testing.assert_array_equal(w.player_direction_au, orc.direction)
-    sample = np.unique(np.concatenate([[0, 1, 3, 4, batch // 2 - 1, batch // 2, batch - 2, batch - 1], rng.choice(batch, 16, replace=False)]))
-    small = oracle.OracleBatch(len(sample), seed=0, render_top_view=1, pu_per_tu=pu, **cfg)
-    small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
-    got = np.stack([env.top_view_host(int(i), 1)[0] for i in sample])
-    np.testing.assert_array_equal(got, small.top_view)
-    cam = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
-    np.testing.assert_array_equal(cam, small.camera_view)
-    tv = env.top_view.torch().view(torch.int32)
-    palette = torch.tensor([0x000000, 0xFFFFFF, 0xFF0000, 0xCCCCCC, 0x808080, 0xC0C0C0], dtype=torch.int32, device=tv.device)
-    for a0 in range(0, batch, 256):
-        assert bool(torch.isin(tv[a0:a0 + 256], palette).all()), f"a pixel outside the palette in agents {a0}.."
-    # ... and every pixel that is neither ray grey nor circle grey is the tile layer's, rebuilt here with torch ops from
-    # the goal positions alone (SR:348-369: walls on the room's border, the goal tile, 0xCCCCCC tile borders)
-    H, W = cfg["height_tile_map_tu"], cfg["width_tile_map_tu"]
-    goal = torch.from_numpy(np.ascontiguousarray(w.goal_position)).to(tv.device).to(torch.int64)        # 1-based (i, j)
-    ii = torch.arange(H, device=tv.device).view(1, 1, H)
-    jj = torch.arange(W, device=tv.device).view(1, W, 1)
-    wall = (ii == 0) | (ii == H - 1) | (jj == 0) | (jj == W - 1)
-    edge_i = torch.arange(H * pu, device=tv.device) % pu
-    edge_j = torch.arange(W * pu, device=tv.device) % pu
-    edge = ((edge_j == 0) | (edge_j == pu - 1)).view(1, W * pu, 1) | ((edge_i == 0) | (edge_i == pu - 1)).view(1, 1, H * pu)
-    step = max(1, (64 << 20) // (H * W * pu * pu * 4))
-    rays_seen = 0
-    for a0 in range(0, batch, step):
-        g = goal[a0:a0 + step]
-        is_goal = (ii == (g[:, 0] - 1).view(-1, 1, 1)) & (jj == (g[:, 1] - 1).view(-1, 1, 1))
-        tiles = torch.where(wall, 0xFFFFFF, torch.where(is_goal, 0xFF0000, 0)).to(torch.int32)
-        layer = tiles.repeat_interleave(pu, dim=1).repeat_interleave(pu, dim=2)
-        layer = torch.where(edge, torch.tensor(0xCCCCCC, dtype=torch.int32, device=tv.device), layer)
-        got_px = tv[a0:a0 + step].reshape(layer.shape)
-        drawn = (got_px == 0x808080) | (got_px == 0xC0C0C0)
-        assert bool(((got_px == layer) | drawn).all()), f"tile layer differs in agents {a0}.."
-        per_agent = drawn.flatten(1).sum(1)
-        assert int(per_agent.min()) >= 4, "an image without a ray or circle pixel"
-        rays_seen += int(per_agent.sum())
-    assert rays_seen > batch * pu
+    def verify(sample_seed):
+        rng_s = np.random.default_rng(sample_seed)
+        w = env.world
+        np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
+        np.testing.assert_array_equal(w.player_direction_au, orc.direction)
+        sample = np.unique(np.concatenate([[0, 1, 3, 4, batch // 2 - 1, batch // 2, batch - 2, batch - 1], rng_s.choice(batch, 16, replace=False)]))
+        small = oracle.OracleBatch(len(sample), seed=0, render_top_view=1, pu_per_tu=pu, **cfg)
+        small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
+        got = np.stack([env.top_view_host(int(i), 1)[0] for i in sample])
+        np.testing.assert_array_equal(got, small.top_view)
+        cam = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
+        np.testing.assert_array_equal(cam, small.camera_view)
+        tv = env.top_view.torch().view(torch.int32)
+        palette = torch.tensor([0x000000, 0xFFFFFF, 0xFF0000, 0xCCCCCC, 0x808080, 0xC0C0C0], dtype=torch.int32, device=tv.device)
+        for a0 in range(0, batch, 256):
+            assert bool(torch.isin(tv[a0:a0 + 256], palette).all()), f"a pixel outside the palette in agents {a0}.."
+        # ... and every pixel that is neither ray grey nor circle grey is the tile layer's, rebuilt here with torch ops from
+        # the goal positions alone (SR:348-369: walls on the room's border, the goal tile, 0xCCCCCC tile borders)
+        H, W = cfg["height_tile_map_tu"], cfg["width_tile_map_tu"]
+        goal = torch.from_numpy(np.ascontiguousarray(w.goal_position)).to(tv.device).to(torch.int64)        # 1-based (i, j)
+        ii = torch.arange(H, device=tv.device).view(1, 1, H)
+        jj = torch.arange(W, device=tv.device).view(1, W, 1)
+        wall = (ii == 0) | (ii == H - 1) | (jj == 0) | (jj == W - 1)
+        edge_i = torch.arange(H * pu, device=tv.device) % pu
+        edge_j = torch.arange(W * pu, device=tv.device) % pu
+        edge = ((edge_j == 0) | (edge_j == pu - 1)).view(1, W * pu, 1) | ((edge_i == 0) | (edge_i == pu - 1)).view(1, 1, H * pu)
+        step = max(1, (64 << 20) // (H * W * pu * pu * 4))
+        rays_seen = 0
+        for a0 in range(0, batch, step):
+            g = goal[a0:a0 + step]
+            is_goal = (ii == (g[:, 0] - 1).view(-1, 1, 1)) & (jj == (g[:, 1] - 1).view(-1, 1, 1))
+            tiles = torch.where(wall, 0xFFFFFF, torch.where(is_goal, 0xFF0000, 0)).to(torch.int32)
+            layer = tiles.repeat_interleave(pu, dim=1).repeat_interleave(pu, dim=2)
+            layer = torch.where(edge, torch.tensor(0xCCCCCC, dtype=torch.int32, device=tv.device), layer)
+            got_px = tv[a0:a0 + step].reshape(layer.shape)
+            drawn = (got_px == 0x808080) | (got_px == 0xC0C0C0)
+            assert bool(((got_px == layer) | drawn).all()), f"tile layer differs in agents {a0}.."
+            per_agent = drawn.flatten(1).sum(1)
+            assert int(per_agent.min()) >= 4, "an image without a ray or circle pixel"
+            rays_seen += int(per_agent.sum())
+        assert rays_seen > batch * pu
+
+    verify(1)
+    # a MASKED reset next (the draw kernel then runs for the masked agents only, the store kernel writes their pixels only —
+    # chunk by chunk, per pixel where an image border or a run's border falls inside a chunk), one more step, and the same again
+    mask = (rng.random(batch) < 0.4).astype(np.uint8)
+    mask[[0, batch - 1]] = 1; mask[[1, batch - 2]] = 0
+    rcw.reset_(env, mask=mask, seed=123); orc.reset(mask=mask, seed=123)
+    verify(2)
+    a = rng.integers(1, 5, batch).astype(np.uint8)
+    rcw.act_(env, a)
+    assert orc.step(a) == 0
+    verify(3)
     env.close()
 
 
