@@ -757,7 +757,13 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
     u32x4* const out4 = reinterpret_cast<u32x4*>(out);
     const unsigned long long dstep = (unsigned long long)G * 64;
     const uint32_t last_col = (uint32_t)total_cols - 1u;
+#ifdef RCW_TRACE_WAVES
+    int grp = 0;
+#endif
     for (unsigned long long base = g; base < total_chunks; base += (unsigned long long)G * 64) {
+#ifdef RCW_TRACE_WAVES
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const unsigned long long id = base + (unsigned long long)lane * G;
         const bool exists = id < total_chunks;
         int touched = 0;                                                     // last column of the chunk, relative
@@ -787,6 +793,13 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
         col += dq; rem += dr;
         if (rem >= (unsigned)Hc) { rem -= (unsigned)Hc; col += 1; }
         __builtin_amdgcn_wave_barrier();                                     // (the lanes of a wavefront exchange through LDS: no reordering across)
+#ifdef RCW_TRACE_WAVES
+        {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && g < 1024 && grp < 18) { g_wave_trace[(g * 20 + grp) * 2] = t0; g_wave_trace[(g * 20 + grp) * 2 + 1] = t1; }
+            grp += 1;
+        }
+#endif
         u32x4* dst = out4 + base * 64;                                       // wave-uniform
         if (__ballot(state_l == 3) == ~0ull) {
             // every chunk of the group is whole and unmasked: no branch in the loop, the next chunk's pair(s) on their way
@@ -807,8 +820,28 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
                 d0 = n0; d1 = n1; r = r_n;
             }
         } else {
+            // The group holds a masked agent's border or the batch's end: its LEADING whole chunks (all of them up to the
+            // batch's last chunk, in the last group of every wavefront) still take the branch-free loop — left to the general
+            // loop alone, the last group cost a launch up to 8 µs (the wavefronts that end last: profiles/r03_fill_flat_wave_trace.txt)
+            const unsigned long long whole = __ballot(state_l == 3);
+            const int n_fast = (int)__builtin_ctzll(~whole);                 // (not all ones here)
+            if (n_fast >= 4) {
+                int rel, r, rel_n, r_n;
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Hc, rel, r);
+                uint4 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
+#pragma unroll 1
+                for (int t = 0; t < n_fast; ++t, dst += dstep) {
+                    flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Hc, rel_n, r_n);
+                    const uint4 n0 = desc[(t + 1) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + 1) * KS + rel_n + 1];
+                    bool ok[4];
+                    const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
+                    __builtin_nontemporal_store(v, dst + lane);
+                    d0 = n0; d1 = n1; r = r_n;
+                }
+            }
+            const int t_first = n_fast >= 4 ? n_fast : 0;
 #pragma unroll 2
-            for (int t = 0; t < 64; ++t, dst += dstep) {
+            for (int t = t_first; t < 64; ++t, dst += dstep) {
                 const int s_state = __builtin_amdgcn_readlane(state_l, t);
                 if (!(s_state & 1)) continue;                                // wave-uniform: past the end
                 int rel, r;
@@ -830,6 +863,14 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
         }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef RCW_TRACE_WAVES
+    if (lane == 0 && g < 1024) {
+        g_wave_trace[(g * 20 + 19) * 2] = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        g_wave_trace[(g * 20 + 18) * 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
 }
 
 // Any other H_cam: one workgroup per agent.  The agent's N descriptors are turned
@@ -2226,9 +2267,10 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
         char* dst = reinterpret_cast<char*>(out4) + (size_t)base * 1024;     // wave-uniform: the chunk's first byte
         const size_t dstep_b = dstep * 16;
         auto put = [&](const u32x4& o) { store16<PLAIN>(reinterpret_cast<u32x4*>(dst + lane16), o); };
-        if (__ballot((state_l & 3) == 3) == ~0ull) {
+        const unsigned long long whole = __ballot((state_l & 3) == 3);
+        const unsigned long long circle_chunks = __ballot((state_l & 4) != 0);   // bit t: chunk t crosses a player's circle
+        if (whole == ~0ull) {
             // every chunk of the group is whole and unmasked: the next chunk's LDS values on their way while this one's pixels are made
-            const unsigned long long circle_chunks = __ballot((state_l & 4) != 0);   // bit t: chunk t crosses a player's circle
             int rel, r, rel_n, r_n;
             flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Ht, rel, r);
             uint4 d = desc[rel];
@@ -2247,8 +2289,29 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
             }
             return true;
         }
+        // a masked agent's or a run's border, or the batch's end, lies in the group: its LEADING whole chunks (all up to the
+        // batch's last chunk, in the last group of every wavefront) take the same loop, the rest the general one
+        const int n_fast = (int)__builtin_ctzll(~whole);
+        int t0 = 0;
+        if (n_fast >= 4) {
+            int rel, r, rel_n, r_n;
+            flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Ht, rel, r);
+            uint4 d = desc[rel];
+            uint32_t w = lw_read[0];
+            uint4 re = rtab[r >> 2];
+#pragma unroll 1
+            for (int t = 0; t < n_fast; ++t, dst += dstep_b) {
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Ht, rel_n, r_n);
+                const uint4 d_n = desc[(t + 1) * KS + rel_n];
+                const uint4 re_n = rtab[r_n >> 2];
+                const uint32_t w_n = lw_read[8 * (t + 1)];
+                put(top_flat_pixels<STRADDLE, NARROW>(C, r, d, w, re.x, re.y, re.z, ((circle_chunks >> t) & 1ull) != 0));
+                d = d_n; w = w_n; re = re_n; r = r_n;
+            }
+            t0 = n_fast;
+        }
 #pragma unroll 2
-        for (int t = 0; t < 64; ++t, dst += dstep_b) {
+        for (int t = t0; t < 64; ++t, dst += dstep_b) {
             const int s_state = __builtin_amdgcn_readlane(state_l, t);
             if (!(s_state & 1)) continue;                                    // wave-uniform: past the end
             int rel, r;

@@ -19,12 +19,14 @@ import raycastworlds_jl_amd as RCW
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.environ.get("RCW_LIBRARY") or os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "librcw_hip_trace.so")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-env = RCW.SingleRoomModule.SingleRoom(batch=4096, seed=1, auto_reset=True, out_of_bounds=1, library=LIB,
+HC = int(sys.argv[2]) if len(sys.argv) > 2 else 256           # camera height: 256 traces rcw_fill256_kernel, any flat height rcw_fill_flat_kernel
+B = (1 << 30) // (4 * 256 * HC)
+env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, library=LIB, height_camera_view_pu=HC,
                                       height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256)
-a = torch.randint(1, 5, (4096,), dtype=torch.uint8, device="cuda")
+a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
 buf = np.zeros(1024 * 40, dtype=np.uint64)
 waves = np.arange(1024)
-print(f"rcw_fill256_kernel, 4096 agents x 256 columns x 256 rows (1 GiB a launch), {reps} launches traced; times in us")
+print(f"{env.fill_kernel_name()}, {B} agents x 256 columns x {HC} rows (1 GiB a launch), {reps} launches traced; times in us")
 print(" launch | kernel | prefetch pause median / max | restart spread | end spread | group period | ends: even XCDs / odd XCDs")
 ends = []
 for rep in range(reps):
