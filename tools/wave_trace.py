@@ -60,6 +60,13 @@ print("XCC_ID of workgroups 0..15:", xcc[::4][:16].tolist(), "| wavefronts per X
 print("mean end time by XCC_ID:", np.round([ends[:, xcc == x].mean() for x in range(8)], 1).tolist())
 print("mean end time by shader engine within XCC 0 / XCC 1:", np.round([ends[:, (xcc == 0) & (se == x)].mean() for x in range(4)], 1).tolist(),
       "/", np.round([ends[:, (xcc == 1) & (se == x)].mean() for x in range(4)], 1).tolist())
+last = ends[-1]
+order = np.argsort(-last)[:12]
+simd = (hwid >> 4) & 3
+print("the 12 wavefronts that ended last (wavefront, XCC, SE, CU, SIMD: end, its pauses, its store loops):")
+for w in order:
+    print(f"  {int(w):5d}  xcc {int(xcc[w])} se {int(se[w])} cu {int(cu[w]):2d} simd {int(simd[w])}: {last[w]:6.1f}  {pz[w].sum():5.1f}  {loop[w].sum():6.1f}   loops by group {np.round(loop[w], 1).tolist()}")
+print("end time percentiles within the odd XCDs (min, 10, 50, 90, 99, max):", np.round(np.percentile(last[xcc % 2 == 1], [0, 10, 50, 90, 99, 100]), 1).tolist())
 c = np.corrcoef(ends)
 print("correlation of the per-wavefront end times between launches:", round(float((c.sum() - reps) / (reps * reps - reps)), 3))
 env.close()
