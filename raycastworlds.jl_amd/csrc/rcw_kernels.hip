@@ -2331,12 +2331,26 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     TopFlatPre<K> P = {};
     int state_l = 0, rem_l = 0;
     issue(base, P); flat_wait_loads<0, K>(P); finish(P, state_l, rem_l);
+#ifdef RCW_TRACE_WAVES
+    int grp = 0;
+    unsigned long long t_pause = __builtin_amdgcn_s_memrealtime();           // (a group's "pause": from the end of the previous group's stores to its own first)
+#endif
     while (base + G * 64 < chunk_end) {                                      // (wave-uniform) there is a next group:
         // its loads go out now, ahead of this group's stores, and are awaited behind them — in one straight line, every
         // iteration, so that no register copy can come between a load and its wait (tools/check_async_loads.py)
         __builtin_amdgcn_wave_barrier();
         issue(base + G * 64, P);
+#ifdef RCW_TRACE_WAVES
+        {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && g < 1024 && grp < 18) { g_wave_trace[(g * 20 + grp) * 2] = t_pause; g_wave_trace[(g * 20 + grp) * 2 + 1] = t1; }
+            grp += 1;
+        }
+#endif
         const bool stored_64 = store_group(base, state_l, rem_l);
+#ifdef RCW_TRACE_WAVES
+        t_pause = __builtin_amdgcn_s_memrealtime();
+#endif
         __builtin_amdgcn_wave_barrier();
         if (!stored_64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (fewer than 64 stores behind the loads: wait for everything; names no register)
         flat_wait_loads<63, K>(P);
@@ -2345,6 +2359,14 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     }
     __builtin_amdgcn_wave_barrier();
     store_group(base, state_l, rem_l);
+#ifdef RCW_TRACE_WAVES
+    if (lane == 0 && g < 1024) {
+        g_wave_trace[(g * 20 + 19) * 2] = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        g_wave_trace[(g * 20 + 18) * 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
 }
 
 }  // namespace

@@ -19,14 +19,22 @@ import raycastworlds_jl_amd as RCW
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.environ.get("RCW_LIBRARY") or os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "librcw_hip_trace.so")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-HC = int(sys.argv[2]) if len(sys.argv) > 2 else 256           # camera height: 256 traces rcw_fill256_kernel, any flat height rcw_fill_flat_kernel
-B = (1 << 30) // (4 * 256 * HC)
-env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, library=LIB, height_camera_view_pu=HC,
-                                      height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256)
+HC = int(sys.argv[2]) if len(sys.argv) > 2 and "," not in sys.argv[2] else 256   # camera height: 256 traces rcw_fill256_kernel, any flat height rcw_fill_flat_kernel
+TOP = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 and "," in sys.argv[2] else None   # H,W,pu: rcw_top_store_flat_kernel
+if TOP:                                                       # (the camera is kept small — 24 rows, 64 columns — so that the trace is the top view's store kernel's, which runs last)
+    B = max(64, min(16384, (1 << 30) // (4 * TOP[0] * TOP[2] * TOP[1] * TOP[2])))
+    env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, library=LIB, height_camera_view_pu=20,
+                                          height_tile_map_tu=TOP[0], width_tile_map_tu=TOP[1], num_rays=64, render_top_view=True, pu_per_tu=TOP[2])
+    env.set_top_view_form("two-kernels", runs=1)
+else:
+    B = (1 << 30) // (4 * 256 * HC)
+    env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, library=LIB, height_camera_view_pu=HC,
+                                          height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256)
 a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
 buf = np.zeros(1024 * 40, dtype=np.uint64)
+env.sync()
 waves = np.arange(1024)
-print(f"{env.fill_kernel_name()}, {B} agents x 256 columns x {HC} rows (1 GiB a launch), {reps} launches traced; times in us")
+print((f"rcw_top_store_flat_kernel, map {TOP[0]}x{TOP[1]} at {TOP[2]} pixels a tile, {B} agents" if TOP else f"{env.fill_kernel_name()}, {B} agents x 256 columns x {HC} rows") + f" (~1 GiB a launch), {reps} launches traced; times in us")
 print(" launch | kernel | prefetch pause median / max | restart spread | end spread | group period | ends: even XCDs / odd XCDs")
 ends = []
 for rep in range(reps):
@@ -35,7 +43,8 @@ for rep in range(reps):
     env.sync()
     assert env._lib.rcw_wave_trace_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     t = buf.reshape(1024, 20, 2).astype(np.int64)
-    t0, t1, tend, hw = t[:, :16, 0], t[:, :16, 1], t[:, 19, 0], t[:, 18, 0]
+    ng = int(min(16, (t[:, :18, 0] > 0).sum(axis=1).min()))      # groups every wavefront traced (16 at 1 GiB; fewer for smaller batches)
+    t0, t1, tend, hw = t[:, :ng, 0], t[:, :ng, 1], t[:, 19, 0], t[:, 18, 0]
     xcc = (hw >> 32) & 0xF
     start = t0[:, 0].min()
     pause = (t1 - t0)[:, 1:] / 100.0
