@@ -391,9 +391,11 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         // that holds pixels of both and relies on a region's bits outside its own image being zero — true of every region the
         // draw kernel has written, but a masked render right after rcw_set_top_view_form (whose own re-render may be the
         // one-kernel form, which writes no planes) draws the masked agents only and reads their neighbours' regions as they lie.
-        if (e == hipSuccess) e = hipMemset(h->d_top_plane, 0, rcw_top_plane_bytes(d));
+        // (stream-ordered on the handle's stream: every later launch of the handle comes behind it, the side stream's draw
+        // kernel through the fork event)
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_top_plane, 0, rcw_top_plane_bytes(d), h->stream);
         if (e == hipSuccess) e = hipMalloc(&h->d_top_hdr, (size_t)h->B * sizeof(int2));
-        if (e == hipSuccess) e = hipMemset(h->d_top_hdr, 0, (size_t)h->B * sizeof(int2));
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_top_hdr, 0, (size_t)h->B * sizeof(int2), h->stream);
         if (e == hipSuccess) e = hipMalloc(&h->d_top_codes, rcw_top_codes_bytes(d));
         if (e == hipSuccess && !h->top_stream) e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
         if (e == hipSuccess && !h->ev_top_fork) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
