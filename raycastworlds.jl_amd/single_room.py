@@ -473,6 +473,21 @@ class SingleRoom:
             self._release_after_use(h, c, out)
         return out
 
+    def _constant_actions(self, action: int):
+        """A device array holding `action` for every agent (None without torch: the host path is taken)."""
+        cache = self.__dict__.setdefault("_constant_action_buffers", {})
+        buf = cache.get(action)
+        if buf is None and action not in cache:
+            try:
+                import torch
+
+                buf = torch.full((self.batch,), action, dtype=torch.uint8, device=f"cuda:{self.device}")
+                torch.cuda.synchronize(self.device)      # (made on torch's stream, used on the engine's from now on)
+            except Exception:                            # noqa: BLE001 — no torch / no CUDA torch: stay on the host path
+                buf = None
+            cache[action] = buf
+        return buf
+
     def _order_behind_torch(self, *tensors):
         """Make the engine's stream wait for torch's current stream (the producer of `tensors`), and keep the
         tensors alive until the engine has consumed them: `_release_after_use` must follow the launch.  Without
@@ -661,6 +676,9 @@ def host_actions(batch: int, action) -> np.ndarray:
         a = np.asarray(action).reshape(-1)
         if a.size != batch:
             raise ValueError(f"expected {batch} actions, got {a.size}")
+        if a.dtype == np.uint8 and a.flags.c_contiguous and a.size:          # the common case: two reductions, no temporaries
+            if a.min() >= 1 and a.max() <= NUM_ACTIONS:
+                return a
     ok = (a >= 1) & (a <= NUM_ACTIONS)
     if a.dtype.kind == "f":
         ok &= a == np.floor(a)
@@ -703,6 +721,15 @@ def act_(env: SingleRoom, action) -> None:
             env._check(env._lib.rcw_step_device(env._h, C.c_void_p(action.data_ptr())))
             if cross:
                 env._release_after_use(action)
+            return None
+    if isinstance(action, (int, np.integer)) and not isinstance(action, bool):
+        # one action for every agent (what the reference's own loop passes: env(rand(1:4)), test/runtests.jl:28): a
+        # device-resident constant per action, made once — no staging copy, no array to validate
+        if not 1 <= int(action) <= NUM_ACTIONS:
+            raise AssertionError(f"Invalid action: {action}")
+        buf = env._constant_actions(int(action))
+        if buf is not None:
+            env._check(env._lib.rcw_step_device(env._h, C.c_void_p(buf.data_ptr())))
             return None
     a = host_actions(env.batch, action)
     env._check(env._lib.rcw_step(env._h, _as_ptr(a)))
