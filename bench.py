@@ -95,6 +95,24 @@ def cpu_baseline(kw, batch_hint, target_seconds=10.0):
     }
 
 
+def make_watchdog(rank, emit, headline_ready, pending, seconds, exit_fn=os._exit, err=None):
+    """What runs when the optional gather has not finished `seconds` after it began (a rank that died or hangs inside a
+    collective leaves the others waiting for ever).  The bench line must still go out — rank 0 writes the headline it
+    has ready, with the gather reported as timed out — but a hang must LOOK like one to whoever launched the run: every
+    rank says on stderr which collective it was in (and the sizes), and leaves with exit code 3, not 0."""
+    def watchdog():
+        stream = err if err is not None else sys.stderr
+        print(f"bench.py: rank {rank}: the optional observation gather did not finish within {seconds:.0f} s; "
+              f"stuck in: {pending.get('what', 'unknown')}; exiting with code 3", file=stream, flush=True)
+        if rank == 0 and headline_ready.get("line") is not None:
+            out_t = dict(headline_ready["line"])
+            out_t["gather"] = {"error": f"the optional observation gather did not finish within {seconds:.0f} s "
+                                        f"(rank 0 was in: {pending.get('what', 'unknown')}); headline unaffected; exit code 3"}
+            emit(out_t)
+        exit_fn(3)
+    return watchdog
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,7 +133,11 @@ def main():
                          "test (test/runtests.jl:26-33: RLBase.state -> env(action) -> RLBase.reward -> RLBase.is_terminated every step, "
                          "with a device-resident consumer of reward / done) and report it as `api_loop` beside the headline")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="development only: all ranks share GPU 0 and rendezvous over gloo (checks the N>1 code path on a 1-GPU box)")
+                    help="development only: all ranks share GPU 0 and rendezvous over gloo (checks the N>1 code path on a 1-GPU box; "
+                         "the gather block runs too, its collectives staged through host memory because gloo does not all-gather "
+                         "device tensors, and its frame gather on the first 256 agents of every rank)")
+    ap.add_argument("--watchdog-seconds", type=float, default=120.0,
+                    help="how long the optional gather may take before every rank gives up with exit code 3")
     args = ap.parse_args()
 
     # Rank 0 must print ONE JSON line on stdout and nothing else.  Libraries do not know that (RCCL prints a version
@@ -364,75 +386,95 @@ def main():
 
     gather = None
     headline_ready = {"line": None}
+    pending = {"what": "nothing yet"}
 
     def emit(line_dict):
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line_dict) + "\n").encode())
 
-    def watchdog():
-        # The gather is an optional extra: if it hangs (a rank that failed inside a collective leaves the others
-        # waiting), the bench line must still go out.  Every rank leaves after the deadline; rank 0 first writes the
-        # headline it has ready, with the gather reported as timed out.
-        if rank == 0 and headline_ready["line"] is not None:
-            out_t = dict(headline_ready["line"])
-            out_t["gather"] = {"error": "the optional observation gather did not finish within 120 s; headline unaffected"}
-            emit(out_t)
-        os._exit(0)
-
-    if dist is not None and not args.rehearse_on_one_gpu:
+    if dist is not None:
         import threading
 
+        rehearsal = args.rehearse_on_one_gpu
         if rank == 0:
             headline_ready["line"] = build_line(None)
-        timer = threading.Timer(120.0, watchdog)
+        timer = threading.Timer(args.watchdog_seconds, make_watchdog(rank, emit, headline_ready, pending, args.watchdog_seconds))
         timer.daemon = True
         timer.start()
         ok = 1
+        Bf = min(B, 256) if rehearsal else B             # agents per rank in the FRAME gather (all of them on a real node)
+
+        def all_gather(out, inp, what):
+            pending["what"] = (f"all_gather_into_tensor of {what}: {inp.numel() * inp.element_size()} B per rank -> "
+                               f"{out.numel() * out.element_size()} B, world {world}")
+            if rehearsal:                                # gloo all-gathers host tensors only
+                host = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather_into_tensor(host, inp.cpu())
+                out.copy_(host)
+            else:
+                dist.all_gather_into_tensor(out, inp)
+
+        def all_reduce_max(values, what):
+            pending["what"] = f"all_reduce(MAX) of {what}, world {world}"
+            t = torch.tensor(values, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(v) for v in t]
+
         try:
             h_loc, c_loc = env.columns_device()
             h_loc, c_loc = h_loc.torch(sync=False), c_loc.torch(sync=False)
-            obs_loc = env.camera_view.torch(sync=False).view(torch.int32)
+            obs_loc = env.camera_view.torch(sync=False).view(torch.int32)[:Bf]
             gh = torch.empty((world * B, N), dtype=torch.int32, device="cuda")
             gc = torch.empty((world * B, N), dtype=torch.uint8, device="cuda")
             frames_all = torch.empty((world * B, N, Hc), dtype=torch.uint32, device="cuda")
+            frames_part = frames_all.view(torch.int32)[:world * Bf]
 
             def timed(fn, reps):
                 fn()
-                torch.cuda.synchronize(); barrier()
+                torch.cuda.synchronize(); pending["what"] = "barrier inside the gather timing"; barrier()
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     fn()
-                torch.cuda.synchronize(); barrier()
+                torch.cuda.synchronize(); pending["what"] = "barrier inside the gather timing"; barrier()
                 return (time.perf_counter() - t0) / reps * 1e6
 
             def cols():
-                dist.all_gather_into_tensor(gh, h_loc)
-                dist.all_gather_into_tensor(gc, c_loc)
+                all_gather(gh, h_loc, "height_line_pu (int32)")
+                all_gather(gc, c_loc, "colour ids (uint8)")
 
             def cols_expand():
                 cols()
                 env.expand_columns(gh, gc, out=frames_all)
 
-            t_cols, t_cols_expand = timed(cols, 10), timed(cols_expand, 5)
-            t_frames = timed(lambda: dist.all_gather_into_tensor(frames_all.view(torch.int32), obs_loc), 3)
+            t_cols, t_cols_expand = timed(cols, 2 if rehearsal else 10), timed(cols_expand, 1 if rehearsal else 5)
+            t_frames = timed(lambda: all_gather(frames_part, obs_loc, "frames (uint32 as int32)"), 1 if rehearsal else 3)
+            if rehearsal:
+                # what a rehearsal CAN check: the gathered global batch is this rank's own shard in the right place
+                torch.cuda.synchronize()
+                assert torch.equal(gh[rank * B:(rank + 1) * B], h_loc) and torch.equal(gc[rank * B:(rank + 1) * B], c_loc)
+                assert torch.equal(frames_part[rank * Bf:(rank + 1) * Bf], obs_loc)
         except Exception as e:   # noqa: BLE001 — a reported extra must never cost the bench line
             ok = 0
             gather = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            print(f"bench.py: rank {rank}: the optional gather failed in: {pending['what']}: {type(e).__name__}: {e}", file=sys.stderr)
             t_cols = t_cols_expand = t_frames = 0.0
         try:
             # collective-safe: every rank reaches this all-reduce, whatever happened above on it
-            tt = torch.tensor([t_cols, t_cols_expand, t_frames, -float(ok)], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            if float(tt[3]) > -1.0:                     # some rank failed
+            tt = all_reduce_max([t_cols, t_cols_expand, t_frames, -float(ok)], "the gather timings and the ok flag")
+            if tt[3] > -1.0:                              # some rank failed
                 gather = gather or {"error": "the gather failed on another rank"}
             else:
-              gather = {"ranks": world, "agents_per_rank": B, "descriptor_bytes_per_rank": 5 * N * B,
-                      "frame_bytes_per_rank": 4 * N * Hc * B, "columns_us": float(tt[0]),
-                      "columns_plus_expand_us": float(tt[1]), "frames_us": float(tt[2]),
-                      "note": "max over ranks, host-timed between barriers; not part of `value` (the gather is optional)"}
+                gather = {"ranks": world, "agents_per_rank": B, "descriptor_bytes_per_rank": 5 * N * B,
+                          "frame_bytes_per_rank": 4 * N * Hc * Bf, "columns_us": tt[0],
+                          "columns_plus_expand_us": tt[1], "frames_us": tt[2],
+                          "note": "max over ranks, host-timed between barriers; not part of `value` (the gather is optional)"}
+                if rehearsal:
+                    gather["rehearsal"] = ("all ranks on ONE GPU, collectives over gloo staged through host memory, frames of the "
+                                           f"first {Bf} agents of every rank: the code path, not a measurement")
         except Exception as e:   # noqa: BLE001
             gather = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         timer.cancel()
+        pending["what"] = "nothing (the gather is over)"
 
     if rank == 0:
         out = build_line(gather)

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -527,6 +528,9 @@ RcclApi g_rccl;
 
 int load_rccl()
 {
+    // several handles of one process (one rank each, a thread each) may get here together: one loads, the others wait
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.lib) return RCW_OK;
     const char* names[] = {std::getenv("RCW_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;

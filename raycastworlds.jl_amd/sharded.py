@@ -54,6 +54,18 @@ def default_device() -> int:
     return 0
 
 
+def make_unique_id(library: Optional[str] = None) -> bytes:
+    """rcw_comm_unique_id: the 128 bytes ONE rank makes and every rank of the gather group hands to
+    `ShardedSingleRoom.comm_init_abi(unique_id=...)` / rcw_comm_init."""
+    from . import _capi
+
+    _capi.preload_rccl()
+    lib = _capi.load(library)
+    uid = (C.c_uint8 * _capi.RCW_UNIQUE_ID_BYTES)()
+    _capi.check(lib.rcw_comm_unique_id(uid), lib)
+    return bytes(uid)
+
+
 class ShardedSingleRoom:
     """B agents over `world` ranks.  `env_factory(batch=, agent_id_offset=, device=, **kw)` builds
     the local engine: SingleRoomModule.SingleRoom (HIP) unless a test injects another.
@@ -171,9 +183,13 @@ class ShardedSingleRoom:
             return self.env.expand_columns(gh, gc)
 
     # ---- the same gather through the C ABI (RCCL called by the library) -----------------------
-    def comm_init_abi(self) -> None:
+    def comm_init_abi(self, unique_id: Optional[bytes] = None) -> None:
         """rcw_comm_init on this rank's engine.  Rank 0 makes the ncclUniqueId (rcw_comm_unique_id) and
-        torch.distributed carries its 128 bytes to the other ranks; a world of one needs no transport."""
+        torch.distributed carries its 128 bytes to the other ranks; a world of one needs no transport.
+
+        `unique_id`: the 128 bytes of `make_unique_id()` brought here by the CALLER's own transport (MPI, a file, a socket:
+        what a host without torch.distributed does — and how several ranks can live in one process, one engine each,
+        where torch.distributed's ranks are processes)."""
         import torch
 
         from . import _capi
@@ -182,6 +198,13 @@ class ShardedSingleRoom:
             return
         _capi.preload_rccl()
         lib = self.env._lib
+        if unique_id is not None:
+            if len(unique_id) != _capi.RCW_UNIQUE_ID_BYTES:
+                raise ValueError(f"a unique id is {_capi.RCW_UNIQUE_ID_BYTES} bytes, got {len(unique_id)}")
+            uid = (C.c_uint8 * _capi.RCW_UNIQUE_ID_BYTES)(*bytes(unique_id))
+            self.env._check(lib.rcw_comm_init(self.env._h, uid, self.rank, self.world))
+            self._abi_comm = True
+            return
         uid = (C.c_uint8 * _capi.RCW_UNIQUE_ID_BYTES)()
         if self.rank == 0:
             self.env._check(lib.rcw_comm_unique_id(uid))

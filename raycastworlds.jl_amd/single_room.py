@@ -20,6 +20,7 @@ UInt32 (H_cam, N, B).
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Optional, Sequence
 
 import numpy as np
@@ -34,6 +35,45 @@ NUM_ACTIONS = 4   # SR:19
 NUM_VIEWS = 2     # SR:237
 CAMERA_VIEW = 1   # SR:238
 TOP_VIEW = 2      # SR:239
+
+
+class _Handle:
+    """Owner of the native `rcw_handle`: whoever holds one keeps the engine's device memory alive.
+
+    It refers to nothing but the library, so it can be held from places Python's collector cannot see (the deleter of a
+    torch tensor made over engine memory, `_CudaExport` below) without tying the environment into an uncollectable
+    cycle: environment -> DeviceArray -> tensor -> export -> _Handle, and nothing leads back."""
+
+    __slots__ = ("lib", "h")
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p()
+
+    def close(self):
+        if self.h:
+            self.lib.rcw_destroy(self.h)         # waits for the handle's stream
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                        # noqa: BLE001 — interpreter shutdown
+            pass
+
+
+class _CudaExport:
+    """What `DeviceArray.torch()` hands to `torch.as_tensor`: pointer, shape and type of the device memory plus the
+    `_Handle` that keeps it allocated.  torch takes a reference to the exporting object inside the tensor's storage
+    deleter — a reference invisible to Python's collector — so the exporter must not lead back to whoever caches the
+    tensor (exporting the DeviceArray itself leaked every environment whose reward / done / state
+    tensor had been made)."""
+
+    __slots__ = ("__cuda_array_interface__", "_handle")
+
+    def __init__(self, interface: dict, handle):
+        self.__cuda_array_interface__ = interface
+        self._handle = handle
 
 
 class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
@@ -55,7 +95,6 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         self.dtype = np.dtype(dtype)
         self._owner = owner   # keeps the handle alive
         self._sync = sync
-        self._sync_on_export = True
         self._host_getter = host_getter
         self._torch = None
 
@@ -69,8 +108,10 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         # needs to read valid data).  After that the alias is NOT re-synchronised: torch work on a stream other
         # than the engine's must `wait_stream(env.torch_stream())` (or share one stream via `env.set_stream`)
         # before reading frames a later step writes — INTEGRATION.md "Streams".
-        if self._sync_on_export:
-            self._sync()
+        self._sync()
+        return self._interface()
+
+    def _interface(self) -> dict:
         # (device memory behind a Bool view is one byte per element: exported as uint8, viewed as bool by .torch())
         return {
             "shape": self.shape,
@@ -80,22 +121,26 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
             "strides": None,
         }
 
+    @staticmethod
+    def _tensor_over(export, device: int):
+        import torch
+
+        return torch.as_tensor(export, device=f"cuda:{device}")
+
     def torch(self, sync: bool = True):
         """Zero-copy torch tensor on the handle's device (made once per DeviceArray, the pointer is stable).
         `sync=False` skips the host synchronisation: for callers that order their work on the engine's stream
         themselves (a policy on the shared stream, the observation gather)."""
-        import torch
+        if sync:
+            self._sync()
+        if self._torch is None:
+            # exported through a proxy that holds the native handle, not this object: see _CudaExport
+            t = self._tensor_over(_CudaExport(self._interface(), getattr(self._owner, "_handle", None)), self._owner.device)
+            if self.dtype == np.bool_:
+                import torch
 
-        if self._torch is not None:
-            if sync:
-                self._sync()
-            return self._torch
-        self._sync_on_export = bool(sync)
-        try:
-            t = torch.as_tensor(self, device=f"cuda:{self._owner.device}")
-        finally:
-            self._sync_on_export = True
-        self._torch = t.view(torch.bool) if self.dtype == np.bool_ else t
+                t = t.view(torch.bool)
+            self._torch = t
         return self._torch
 
     # DLPack (the array-API exchange protocol: `jax.dlpack.from_dlpack(x)`, `cupy.from_dlpack(x)`, `torch.from_dlpack(x)`):
@@ -120,10 +165,21 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         return a if dtype is None else a.astype(dtype, copy=False)
 
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
-        inputs = tuple(np.asarray(x) if isinstance(x, DeviceArray) else x for x in inputs)
         if out is not None:
+            if any(isinstance(o, DeviceArray) for o in out):
+                # `x += 1`, `np.add(a, b, out=x)`: engine memory is the engine's to write (the next step overwrites it)
+                raise TypeError("a DeviceArray is read-only from the host: operate on np.asarray(x) or x.torch()")
             kwargs["out"] = out
+        inputs = tuple(np.asarray(x) if isinstance(x, DeviceArray) else x for x in inputs)
         return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __bool__(self):
+        """As ndarray: the value of a one-element array, ValueError for more (`if is_terminated(env):` with a batch)."""
+        return bool(self.numpy())
+
+    def __iter__(self):
+        """One device-to-host copy, then the host array's iterator (not one copy per element)."""
+        return iter(self.numpy())
 
     def any(self, *a, **k):
         return self.numpy().any(*a, **k)
@@ -142,6 +198,16 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
 
     def __repr__(self):
         return f"DeviceArray(ptr=0x{self.ptr:x}, shape={self.shape}, dtype={self.dtype})"
+
+
+def _torch_owns(stream) -> bool:
+    """True for a stream out of torch's own pool (`torch.cuda.Stream()`, the current / default stream): torch never
+    destroys those.  `torch.cuda.ExternalStream` is a Stream subclass with the same `.cuda_stream` attribute, but wraps
+    a hipStream_t its creator may destroy at any time — anything that is not provably torch's is the caller's."""
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return False
+    return isinstance(stream, torch.cuda.Stream) and not isinstance(stream, torch.cuda.ExternalStream)
 
 
 def _as_ptr(a: Optional[np.ndarray]):
@@ -335,21 +401,23 @@ class SingleRoom:
         self.batch = int(batch)
         self.device = int(device)
         self.seed = int(seed)
-        self._h = C.c_void_p()
-        self._check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._h)))
+        self._handle = _Handle(self._lib)    # owns the native handle; `self._h` reads it
+        self._check(self._lib.rcw_create(C.byref(cfg), self.batch, self.device, self.seed, C.byref(self._handle.h)))
         self.world = SingleRoomWorld(self)
         self._held = []          # (event, tensors): torch tensors a NON-torch stream may still be reading (_release_after_use)
         self._free_events = []
         self._torch_owned_stream = None
-        # With torch in the process the engine runs on a stream TORCH owns (never destroyed, so `Tensor.record_stream` on it
-        # is safe for tensors that outlive the engine); without torch, on the library's own stream.
-        try:
-            import torch
-
-            if torch.cuda.is_available():
-                self.set_stream(torch.cuda.Stream(device=self.device))
-        except ImportError:
-            pass
+        # In a process that already uses torch the engine runs on a stream TORCH owns (never destroyed, so
+        # `Tensor.record_stream` on it is safe for tensors that outlive the engine).  A caller that has not imported torch
+        # does not get it imported here and keeps the library's own stream (`stream_ptr()`).
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available():
+                    self.set_stream(torch.cuda.Stream(device=self.device))
+            except BaseException:
+                self._handle.close()             # nothing of a half-made environment stays allocated
+                raise
         self.host_syncs = 0      # host synchronisations / device-to-host getters issued through this object (bench.py --api rlbase)
         # colour fields of the reference struct SR:241-256
         self.floor_color = cfg.floor_color
@@ -364,18 +432,24 @@ class SingleRoom:
     def _check(self, rc: int) -> None:
         _capi.check(rc, self._lib)
 
+    @property
+    def _h(self):
+        """The native `rcw_handle*` (NULL once closed)."""
+        return self._handle.h
+
     # ---- lifetime -------------------------------------------------------------------
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.rcw_destroy(self._h)       # waits for the handle's stream
-            self._h = C.c_void_p()
-            self._held = []
+        """`rcw_destroy`.  Device aliases made earlier (`camera_view`, `reward(env).torch()`, ...) dangle from here on,
+        as any view of freed memory does; without an explicit close the memory lives as long as the last of them."""
+        handle = getattr(self, "_handle", None)
+        if handle is not None:
+            handle.close()
+        self._held = []
+        for name in ("_reward_dev", "_done_dev", "_done_dev_bool", "_state_alias", "_constant_action_buffers"):
+            self.__dict__.pop(name, None)
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    # (no __del__: an environment that is dropped without close() lets go of its _Handle, and the engine is destroyed
+    # when the last holder does — this object, or the last torch tensor made over engine memory, whichever lives longer)
 
     def __enter__(self):
         return self
@@ -602,10 +676,15 @@ class SingleRoom:
 
     def set_stream(self, stream):
         """Order the engine's work on another stream: a `torch.cuda.Stream` (kept alive here; torch never destroys its
-        streams, so tensors may be handed over with record_stream), a raw hipStream_t as an int (the caller keeps it
-        alive for as long as the engine — and any tensor it was given — lives), or None: the library's own stream."""
+        streams, so tensors may be handed over with record_stream); a `torch.cuda.ExternalStream` or a raw hipStream_t as
+        an int — a stream the CALLER owns and keeps alive for as long as the engine, and any tensor it was given, lives
+        (tensors are then held by reference until the engine has used them, never `record_stream`ed: torch would record
+        an event on that stream whenever the tensor is finally freed, possibly after the caller destroyed it); or None:
+        the library's own stream."""
+        self._torch_owned_stream = None
         if stream is not None and hasattr(stream, "cuda_stream"):
-            self._torch_owned_stream = stream
+            if _torch_owns(stream):
+                self._torch_owned_stream = stream
             stream = stream.cuda_stream
         self._check(self._lib.rcw_set_stream(self._h, C.c_void_p(stream) if stream else None))
 

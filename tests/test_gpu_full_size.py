@@ -42,17 +42,37 @@ def check_frames_against_descriptors(env, chunk=512):
         assert torch.equal(got, want), f"frames of agents {a0}..{a0 + chunk} differ from their descriptors"
 
 
-@pytest.mark.parametrize("cfg,batch,steps", [(CFG2, 4096, 24), (CFG3, 16384, 6), (CFG4, 8192, 6), (CFG5, 8192, 4)],
-                         ids=["cfg2_4096x256", "cfg3_16384x512", "cfg4_shard_8192x256", "cfg5_8192x1024"])
-def test_full_size_parity(rcw, oracle, cfg, batch, steps):
-    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=2024, out_of_bounds=1, **cfg)
-    orc = oracle.OracleBatch(batch, seed=2024, render=False, out_of_bounds=1, **cfg)
+def settle_bounds_errors(env, orc, where=""):
+    """Wait for the engine under the REFERENCE policy (out_of_bounds = 0: a forward move that lands exactly on x = H-1 or
+    y = W-1 indexes tile H+1 in is_player_colliding, CD:30-35 — a BoundsError in the reference): the agents it happened
+    to must be the oracle's, their status words equal; then clear both sides (the error is sticky).  Returns how many."""
+    try:
+        env.sync()
+        raised = False
+    except IndexError:
+        raised = True
+    status = env.world.status
+    np.testing.assert_array_equal(status, orc.status, err_msg=f"per-agent status {where}")
+    assert raised == bool((status != 0).any())
+    if raised:
+        env.clear_error()
+        orc.clear_status()
+    return int((status != 0).sum())
+
+
+@pytest.mark.parametrize("cfg,batch,steps,oob", [(CFG2, 4096, 24, 1), (CFG3, 16384, 12, 0), (CFG4, 8192, 6, 1), (CFG5, 8192, 4, 1)],
+                         ids=["cfg2_4096x256", "cfg3_16384x512_reference_policy", "cfg4_shard_8192x256", "cfg5_8192x1024"])
+def test_full_size_parity(rcw, oracle, cfg, batch, steps, oob):
+    env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=2024, out_of_bounds=oob, **cfg)
+    orc = oracle.OracleBatch(batch, seed=2024, render=False, out_of_bounds=oob, **cfg)
     rng = np.random.default_rng(1)
     sample = rng.choice(batch, 16, replace=False)
     for s in range(steps):
         a = rng.integers(1, 5, batch).astype(np.uint8)
         rcw.act_(env, a)
         assert orc.step(a) == 0
+    if oob == 0:
+        settle_bounds_errors(env, orc, "after the rollout")
     w = env.world
     np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
     np.testing.assert_array_equal(w.player_direction_au, orc.direction)
@@ -78,10 +98,59 @@ def test_full_size_parity(rcw, oracle, cfg, batch, steps):
     a = rng.integers(1, 5, batch).astype(np.uint8)
     rcw.act_(env, a)
     assert orc.step(a) == 0
+    if oob == 0:
+        settle_bounds_errors(env, orc, "after the masked reset's step")
     np.testing.assert_array_equal(env.world.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
     h, c = env.columns()
     np.testing.assert_array_equal(h, orc.col_height)
     check_frames_against_descriptors(env)
+    env.close()
+
+
+def test_bench_configuration_at_full_size(rcw, oracle):
+    """bench.py's exact configuration, parity-checked at its full size: cfg-2 (8x8, 256 columns), 4096 agents, the
+    REFERENCE policy for the reachable BoundsError (out_of_bounds = 0, CD:30-35), auto-reset on, uniform 1..4 actions
+    made on the device as bench.py makes them (bench.py:171-177), 400 steps with no host synchronisation in between.
+    Against the non-rendering oracle given the same actions: position bits, heading, goal, episode count, reward, done,
+    tile map and the descriptors of every agent — and the per-agent STATUS words: the agents that hit the reference's
+    BoundsError must be the same ones, left untouched by that action.  Frames: all of them against the expansion of
+    their descriptors, a sample (incl. agents that hit the error and agents in their third episode) against the
+    rendering oracle."""
+    B, steps = 4096, 400
+    env = rcw.SingleRoomModule.SingleRoom(batch=B, seed=0, auto_reset=True, out_of_bounds=0, **CFG2)
+    orc = oracle.OracleBatch(B, seed=0, render=False, auto_reset=1, out_of_bounds=0, **CFG2)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234)
+    actions = torch.randint(1, 5, (steps, B), dtype=torch.uint8, device="cuda", generator=gen)
+    host = actions.cpu().numpy()
+    hit = np.zeros(B, dtype=bool)
+    for half in range(2):
+        for s in range(half * steps // 2, (half + 1) * steps // 2):
+            rcw.act_(env, actions[s])                     # device actions: rcw_step_device, nothing waits
+            assert orc.step(host[s]) == 0
+        hit |= orc.status != 0
+        n = settle_bounds_errors(env, orc, f"after {(half + 1) * steps // 2} steps")
+        w = env.world
+        np.testing.assert_array_equal(w.player_position_wu.view(np.uint32), orc.position.view(np.uint32))
+        np.testing.assert_array_equal(w.player_direction_au, orc.direction)
+        np.testing.assert_array_equal(w.goal_position, orc.goal)
+        np.testing.assert_array_equal(w.episode, orc.episode)
+        np.testing.assert_array_equal(w.reward, orc.reward)
+        np.testing.assert_array_equal(w.done.astype(np.uint8), orc.done)
+        np.testing.assert_array_equal(w.tile_map_chunks, orc.tile_map_chunks())
+        h, c = env.columns()
+        np.testing.assert_array_equal(h, orc.col_height)
+        np.testing.assert_array_equal(c, orc.col_colour)
+        check_frames_against_descriptors(env)
+    assert hit.any(), "no agent reached the reference's BoundsError in 400 steps x 4096 agents: the policy went untested"
+    assert (orc.episode >= 3).any(), "no agent got into a third episode"
+    rng = np.random.default_rng(0)
+    sample = np.unique(np.concatenate([np.flatnonzero(hit)[:6], np.flatnonzero(orc.episode >= 3)[:6], [0, B - 1],
+                                       rng.choice(B, 12, replace=False)]))
+    small = oracle.OracleBatch(len(sample), seed=0, **CFG2)
+    small.set_state(orc.goal[sample], orc.position[sample], orc.direction[sample])
+    got = np.stack([env.camera_view_host(int(i), 1)[0] for i in sample])
+    np.testing.assert_array_equal(got, small.camera_view)
     env.close()
 
 

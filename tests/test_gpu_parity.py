@@ -898,6 +898,66 @@ def test_create_destroy_cycles_leave_device_memory_unchanged(rcw):
     assert abs(free1 - free0) <= 8 << 20, f"device memory drifted by {(free0 - free1) / 2**20:.1f} MiB over 25 cycles"
 
 
+def test_dropped_environment_is_finalised_and_its_memory_returned(rcw):
+    """with the RLBase tensors made (reward / is_terminated / state, the cached aliases), an environment
+    that is simply dropped — no close() — is collected and its device memory returned; while one of its tensors lives,
+    the engine's memory stays valid (the tensor's exporter holds the native handle, nothing holds the environment)."""
+    import gc
+    import weakref
+
+    torch = pytest.importorskip("torch")
+    RL = rcw.RLBase
+    torch.cuda.synchronize()
+
+    def make():
+        env = rcw.SingleRoomModule.SingleRoom(batch=1024, seed=1, **CFG2)          # 256 MiB of frames
+        rl = rcw.RLBaseEnv(env)
+        r = RL.reward(rl).torch(sync=False)
+        d = RL.is_terminated(rl).torch(sync=False)
+        s = RL.state(rl).torch(sync=False)
+        rl(3)
+        return env, r, d, s
+
+    env, r, d, s = make()
+    env.close(); del env, r, d, s                       # code objects loaded, allocator warm
+    gc.collect(); torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    env, r, d, s = make()
+    ref = weakref.ref(env)
+    assert torch.cuda.mem_get_info()[0] < free0 - (200 << 20)
+    del env, d, s
+    gc.collect()
+    assert ref() is None, "the environment is kept alive by its cached tensors"
+    assert torch.cuda.mem_get_info()[0] < free0 - (200 << 20), "the engine was destroyed under a live tensor"
+    assert float(r.sum()) == 0.0                        # still readable: turning left earns nothing
+    del r
+    gc.collect(); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free1 - free0) <= 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB not returned"
+
+
+def test_external_stream_is_not_record_streamed(rcw, oracle):
+    """a torch.cuda.ExternalStream wraps a stream its CREATOR owns; the engine must hold tensors by
+    reference there (the event ring), never Tensor.record_stream — torch would touch the stream again whenever the
+    tensor is freed, possibly after its owner destroyed it (profiles/r03_record_stream_abort.txt)."""
+    torch = pytest.importorskip("torch")
+    env, orc = _make(rcw, oracle, 64, seed=23, **CFG1)
+    own = torch.cuda.Stream()
+    env.set_stream(own)
+    assert env._stream_is_torch_owned()
+    ext = torch.cuda.ExternalStream(own.cuda_stream)    # the same stream, seen as somebody else's
+    env.set_stream(ext)
+    assert env.stream_ptr() == own.cuda_stream and not env._stream_is_torch_owned()
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        a = rng.integers(1, 5, 64).astype(np.uint8)
+        rcw.act_(env, torch.from_numpy(a).cuda())       # a temporary on torch's current stream: cross-stream hand-over
+        orc.step(a)
+    assert 0 < len(env._held) <= 16, "the temporaries were not held by reference"
+    assert_state_equal(env, orc, where="on an ExternalStream")
+    env.close()
+
+
 def test_play_keys_replays_the_keyboard_callback(rcw, oracle, tmp_path):
     """Headless `play!` (SR:488-568): a scripted key sequence — W/S/A/D act, R resets, V toggles the view, an unbound
     key warns, Q closes — with the frame buffer after every key compared with the oracle's views blitted the

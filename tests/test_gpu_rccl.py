@@ -38,13 +38,7 @@ def test_library_transport_with_two_ranks(rcw, oracle, tmp_path):
     """rcw_comm_init(rank = 1, world = 2), the uid hand-over of sharded.py and the library's gather with TWO ranks: both on
     the box's one GPU, the real engine, tests/stub_rccl.c in place of librccl (RCW_RCCL_LIBRARY).  Each rank compares the
     gathered global batch with the unsharded CPU oracle; the stub's log shows who initialised what."""
-    stub = str(tmp_path / "librccl_stub.so")
-    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", stub, os.path.join(ROOT, "tests", "stub_rccl.c"),
-                    "-ldl", "-lrt"], check=True)
-    log = str(tmp_path / "stub.log")
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    stub, log, port = _build_stub(tmp_path), str(tmp_path / "stub.log"), _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0",
@@ -68,3 +62,79 @@ def test_library_transport_with_two_ranks(rcw, oracle, tmp_path):
     assert len(uid) == 2 and uid[0] == uid[1]                                 # ... and the same 128 bytes reached both ranks
     assert "comm_init rank=1 world=2" in text and "comm_init rank=0 world=2" in text
     assert text.count("all_gather rank=1") >= 4
+
+
+def _build_stub(tmp_path):
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", stub, os.path.join(ROOT, "tests", "stub_rccl.c"),
+                    "-ldl", "-lrt"], check=True)
+    return stub
+
+
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def test_cfg4_as_stated_eight_ranks_with_the_gather(rcw, oracle, tmp_path):
+    """BASELINE.json configs[3] in its own shape: 16x16, 256 columns, 65,536 agents over EIGHT ranks with the observation
+    gather — on the one GPU a box has.  Eight ranks = four processes of two rank-threads (a box admits six processes on
+    its card, this one included); tests/rccl_stub_cfg4_world8.py says what each rank checks.  Here: every process ends
+    green, the stand-in's log shows ONE unique id and eight rcw_comm_init calls with it, ranks 0..7 of world 8."""
+    torch = pytest.importorskip("torch")
+    free, _ = torch.cuda.mem_get_info()
+    if free < (60 << 30):
+        pytest.skip(f"needs about 45 GiB of device memory, {free / 2**30:.0f} GiB are free")
+    stub, log, port = _build_stub(tmp_path), str(tmp_path / "stub.log"), _free_port()
+    procs = []
+    for p in range(4):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(p), WORLD_SIZE="4", LOCAL_RANK="0",
+                   RCW_RCCL_LIBRARY=stub, RCW_STUB_LOG=log, OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_stub_cfg4_world8.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, so[-2000:] + "\n" + se[-6000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    assert sorted(r for o in outs for r in o["ranks"]) == list(range(8)) and all(o["parity"] == "ok" and o["world"] == 8 for o in outs)
+    rank0 = [q for o in outs for q in o["per_rank"] if q["rank"] == 0][0]
+    assert rank0["global_frames_bytes"] == 65536 * 256 * 256 * 4                      # 17 GB: the whole observation batch
+    text = open(log).read()
+    assert text.count("unique_id") == 1
+    inits = [l for l in text.splitlines() if l.startswith("comm_init")]
+    assert len(inits) == 8 and len({l.split("uid=")[1].split()[0] for l in inits}) == 1
+    assert sorted(int(l.split("rank=")[1].split()[0]) for l in inits) == list(range(8)) and all("world=8" in l for l in inits)
+    for r in range(8):
+        assert text.count(f"all_gather rank={r} ") == 4, f"rank {r}: two gathers of two all-gathers each"
+    dst = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(dst, exist_ok=True)
+    with open(os.path.join(dst, "cfg4_world8.json"), "w") as f:
+        json.dump(outs, f, indent=1)
+
+
+def test_bench_rehearsal_with_four_ranks(rcw, tmp_path):
+    """bench.py as the driver launches it for N > 1 — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+    — rehearsed with every rank on the box's one GPU (--rehearse-on-one-gpu: gloo rendezvous, the gather block staged
+    through the host).  N = 4: a box admits six processes on its card and this test process is one of them.  ONE JSON
+    line on stdout, n_gpus 4, global batch 4 x 4096, a gather block without an error, exit code 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2",
+                          "--rehearse-on-one-gpu"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + "\n" + res.stderr[-6000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 4 * 4096 and out["steps"] == 5 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out          # rank 0 at N = 1 only
+    g = out["gather"]
+    assert "error" not in g and g["ranks"] == 4 and g["columns_us"] > 0 and g["frames_us"] > 0 and "rehearsal" in g

@@ -245,3 +245,156 @@ def test_flat_plane_layout_makes_chunks_whole_words():
             seg = flat[256 * c:256 * c + 256]
             want[:seg.size] = seg
             np.testing.assert_array_equal(got, want, err_msg=f"{Ht}x{Wt} chunk {c}")
+
+
+# ---- DeviceArray / stream ownership: host logic of single_room.py that needs no GPU ----------------------------
+class _HiddenRefTensor:
+    """Stands in for the tensor `torch.as_tensor(exporter)` makes: it keeps the exporting object alive through a
+    reference Python's collector cannot see (torch takes a Py_INCREF inside the storage's deleter)."""
+
+    def __init__(self, export):
+        import ctypes
+
+        self._id = id(export)
+        self.interface = export.__cuda_array_interface__
+        ctypes.pythonapi.Py_IncRef(ctypes.py_object(export))
+
+    def __del__(self):
+        import ctypes
+
+        ctypes.pythonapi.Py_DecRef(ctypes.cast(self._id, ctypes.py_object))
+
+
+class _FakeLib:
+    def __init__(self):
+        self.destroyed = 0
+
+    def rcw_destroy(self, h):
+        self.destroyed += 1
+        return 0
+
+
+def _bare_env(rcw, lib):
+    """A SingleRoom object with everything but the native calls: enough for the lifetime logic."""
+    import ctypes
+
+    SR = rcw.SingleRoomModule
+    env = SR.SingleRoom.__new__(SR.SingleRoom)
+    env._lib, env.batch, env.device, env.R = lib, 4, 0, np.float32
+    env._handle = SR._Handle(lib)
+    env._handle.h = ctypes.c_void_p(0x1000)
+    env._held, env._free_events, env._torch_owned_stream, env.host_syncs = [], [], None, 0
+    return env
+
+
+def test_cached_device_tensors_do_not_keep_the_environment_alive(rcw, monkeypatch):
+    """DeviceArray.torch() caches its tensor; torch's hidden reference to the exporter must not close a
+    cycle through the environment, or no environment whose reward tensor was ever made is finalised (GiBs leaked)."""
+    import gc
+    import weakref
+
+    SR = rcw.SingleRoomModule
+    monkeypatch.setattr(SR.DeviceArray, "_tensor_over", staticmethod(lambda export, device: _HiddenRefTensor(export)))
+    lib = _FakeLib()
+    env = _bare_env(rcw, lib)
+    env._reward_dev = SR.DeviceArray(0x2000, (4,), np.float32, env, lambda: None)     # what reward_device() caches
+    t = env._reward_dev.torch(sync=False)
+    assert env._reward_dev.torch(sync=False) is t                                    # made once
+    assert t.interface["data"] == (0x2000, False) and t.interface["shape"] == (4,)
+    ref = weakref.ref(env)
+    del env
+    gc.collect()
+    assert ref() is None, "the environment is kept alive by its own cached tensor"
+    assert lib.destroyed == 0, "a live tensor over engine memory keeps the engine allocated"
+    del t
+    gc.collect()
+    assert lib.destroyed == 1                                                         # the last holder destroys it
+
+    # without any tensor outstanding, dropping the environment alone destroys the engine; close() does so at once
+    env = _bare_env(rcw, lib)
+    env._reward_dev = SR.DeviceArray(0x2000, (4,), np.float32, env, lambda: None)
+    env._reward_dev.torch(sync=False)
+    del env
+    gc.collect()
+    assert lib.destroyed == 2
+    env = _bare_env(rcw, lib)
+    env._reward_dev = SR.DeviceArray(0x2000, (4,), np.float32, env, lambda: None)
+    env.close()
+    assert lib.destroyed == 3 and not env._h and "_reward_dev" not in env.__dict__
+    env.close()
+    assert lib.destroyed == 3
+
+
+def test_only_streams_torch_owns_are_record_streamed(rcw, monkeypatch):
+    """torch.cuda.ExternalStream has .cuda_stream like torch.cuda.Stream but wraps a stream its
+    creator may destroy; Tensor.record_stream on it is the use-after-free of profiles/r03_record_stream_abort.txt.
+    (torch's stream classes cannot be instantiated without a device: two classes with the same inheritance stand in;
+    tests/test_gpu_parity.py::test_external_stream_is_not_record_streamed does it with the real ones.)"""
+    import torch
+
+    SR = rcw.SingleRoomModule
+
+    class Lib(_FakeLib):
+        def __init__(self):
+            super().__init__()
+            self.stream = 0
+
+        def rcw_set_stream(self, h, s):
+            self.stream = 0 if s is None else int(s.value or 0)
+            return 0
+
+        def rcw_get_stream(self, h, out):
+            out._obj.value = self.stream
+            return 0
+
+        def rcw_last_error(self):
+            return b""
+
+    assert issubclass(torch.cuda.ExternalStream, torch.cuda.Stream)     # why hasattr / isinstance(Stream) is not enough
+
+    class Owned:
+        cuda_stream = 0x51
+
+    class External(Owned):
+        cuda_stream = 0x52
+
+    monkeypatch.setattr(torch.cuda, "Stream", Owned)
+    monkeypatch.setattr(torch.cuda, "ExternalStream", External)
+
+    class Foreign:                                  # any other object with the attribute (cupy, a user's wrapper)
+        cuda_stream = 0x53
+
+    assert SR._torch_owns(Owned()) and not SR._torch_owns(External()) and not SR._torch_owns(Foreign())
+    env = _bare_env(rcw, Lib())
+    for stream, owned in ((Owned(), True), (External(), False), (Foreign(), False), (0x54, False), (Owned(), True), (None, False)):
+        env.set_stream(stream)
+        assert env.stream_ptr() == (getattr(stream, "cuda_stream", stream) or 0)
+        assert env._stream_is_torch_owned() is owned, stream
+
+
+def test_device_array_host_protocol(rcw):
+    """truth value, iteration and `out=` of the arrays RLBase.reward / is_terminated return."""
+    SR = rcw.SingleRoomModule
+    copies = []
+
+    def getter(vals):
+        def g():
+            copies.append(1)
+            return np.array(vals)
+        return g
+
+    one = SR.DeviceArray(0x10, (1,), np.bool_, None, lambda: None, host_getter=getter([True]))
+    many = SR.DeviceArray(0x10, (3,), np.bool_, None, lambda: None, host_getter=getter([False, True, False]))
+    assert bool(one) is True
+    with pytest.raises(ValueError):
+        bool(many)                                  # as ndarray: ambiguous for more than one element
+    copies.clear()
+    assert list(many) == [False, True, False] and any(many) and len(copies) == 2     # one copy per iteration, not per element
+    r = SR.DeviceArray(0x10, (3,), np.float32, None, lambda: None, host_getter=getter([0.0, 1.0, 0.0]))
+    total = np.zeros(3)
+    total += r                                      # host array on the left: fine
+    assert total.tolist() == [0.0, 1.0, 0.0]
+    with pytest.raises(TypeError):
+        r += 1                                      # engine memory is not the host's to write
+    with pytest.raises(TypeError):
+        np.add(total, 1, out=r)
