@@ -112,12 +112,14 @@ mutable struct BatchedSingleRoom{T, R} <: RCW.AbstractGame
     camera_view::Array{UInt32, 3}     # (H_cam, N, B) host mirror: THE array RLBase.state returns, every call
     stale::Bool                       # the mirror is older than the device frames
     seed::UInt64
+    rng::Any                          # the reference's `rng` keyword (single_room.jl:49,265): nothing (resets are sampled on the
+                                      # device, keyed by `seed`), an AbstractRNG, or a vector of them, one per agent
     gather_buffer::Ptr{Cvoid}         # device memory for gather_observations (allocated on first use)
     gather_frames::Int                # agents the gather buffer holds
 
     # SingleRoom(; T, R, kwargs...) single_room.jl:258-272 for `batch` agents on HIP device `device`
     function BatchedSingleRoom(batch::Integer; T::Type = Float32, R::Type = Float32, device::Integer = 0,
-                               seed::Integer = 0, kwargs...)
+                               seed::Integer = 0, rng = nothing, kwargs...)
         T in (Float32, Float64) || throw(ArgumentError("T must be Float32 or Float64"))
         R in REWARD_TYPES || throw(ArgumentError("R must be one of $(REWARD_TYPES)"))
         cfg = RcwConfig(; kwargs...)
@@ -133,8 +135,10 @@ mutable struct BatchedSingleRoom{T, R} <: RCW.AbstractGame
         check(ccall((:rcw_create, librcw), Cint, (Ref{RcwConfig}, Int32, Int32, UInt64, Ref{Ptr{Cvoid}}),
                     cfg, batch, device, seed, handle))
         view = Array{UInt32, 3}(undef, cfg.height_camera_view_pu, cfg.num_rays, batch)
-        env = new{T, R}(handle[], batch, cfg, view, true, seed, C_NULL, 0)
+        env = new{T, R}(handle[], batch, cfg, view, true, seed, rng, C_NULL, 0)
         finalizer(destroy!, env)
+        # the reference's constructor consumes its rng twice: the draws of single_room.jl:62-74, then reset!(world) :105
+        rng === nothing || reset_from_rng!(env, rng; construction = true)
         return env
     end
 end
@@ -152,9 +156,45 @@ end
 ##### the generic functions of RayCastWorlds.jl:7-14 on the path
 #####
 
-# RCW.reset!(env)  — single_room.jl:326-331 (all agents, or those whose mask byte is non-zero)
-function RCW.reset!(env::BatchedSingleRoom; mask::Union{Nothing, Vector{UInt8}} = nothing, seed::Integer = env.seed)
-    env.seed = seed
+# reset!(world) single_room.jl:110-137 with the CALLER's generator — the reference's `rng` keyword (single_room.jl:49,265).
+# The draws are made on the host by the reference's own statements, in its order: `rand(rng, 2:H-1)`, `rand(rng, 2:W-1)`
+# (:120), `RCW.sample_empty_position(rng, tile_map)` (:124 — the package's own function on a host tile map with the wall ring
+# and the new goal, utils.jl:23-58), `rand(rng, 0:nd-1)` (:128) — agent after agent from one generator (B reference worlds
+# sharing it, reset in order), or agent a from `rng[a]` (each agent IS the reference world built with that generator: its
+# stream is the reference's, draw for draw).  The state goes to the engine with one rcw_set_state.
+function reset_from_rng!(env::BatchedSingleRoom{T}, rng; mask::Union{Nothing, Vector{UInt8}} = nothing,
+                         construction::Bool = false) where {T}
+    H, W, nd, B = Int(env.config.height_tile_map_tu), Int(env.config.width_tile_map_tu), Int(env.config.num_directions), env.batch
+    rng isa AbstractVector && length(rng) != B && throw(DimensionMismatch("expected one generator or $(B) of them"))
+    goal = fill(Int32(2), 2, B); position = fill(T(1.5), 2, B); direction = zeros(Int32, B)
+    tile_map = falses(2, H, W)                                                   # NUM_OBJECTS = 2, WALL = 1, GOAL = 2 (:16-18)
+    tile_map[1, :, 1] .= true; tile_map[1, :, W] .= true; tile_map[1, 1, :] .= true; tile_map[1, H, :] .= true   # :57-60
+    for a in 1:B
+        (mask !== nothing && mask[a] == 0) && continue
+        g = rng isa AbstractVector ? rng[a] : rng
+        for pass in (construction ? (1, 2) : (2,))                              # (the constructor's own draws :62-74 come first)
+            goal_position = CartesianIndex(rand(g, 2 : H - 1), rand(g, 2 : W - 1))                    # :62 / :120
+            tile_map[2, goal_position] = true                                                         # :63 / :122
+            player_position_tu = RCW.sample_empty_position(g, tile_map)                               # :71 / :124
+            player_direction_au = rand(g, 0 : nd - 1)                                                 # :74 / :128
+            tile_map[2, goal_position] = false                                                        # (:118 of the next reset!)
+            goal[1, a] = goal_position[1]; goal[2, a] = goal_position[2]
+            position[1, a] = convert(T, player_position_tu[1] - 0.5); position[2, a] = convert(T, player_position_tu[2] - 0.5)   # :125
+            direction[a] = player_direction_au
+        end
+    end
+    set_state!(env, goal, position, direction; mask = mask)
+    return nothing
+end
+
+# RCW.reset!(env)  — single_room.jl:326-331 (all agents, or those whose mask byte is non-zero).  With `rng` (or an
+# environment built with one): the caller's generator, as the reference; else sampled on the device, keyed by `seed`.
+function RCW.reset!(env::BatchedSingleRoom; mask::Union{Nothing, Vector{UInt8}} = nothing, rng = env.rng,
+                    seed::Union{Nothing, Integer} = nothing)
+    if rng !== nothing && seed === nothing
+        return reset_from_rng!(env, rng; mask = mask)
+    end
+    env.seed = seed === nothing ? env.seed : seed
     GC.@preserve mask check(ccall((:rcw_reset, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt8}, UInt64),
                                   env.handle, mask === nothing ? Ptr{UInt8}(C_NULL) : pointer(mask), env.seed))
     env.stale = true

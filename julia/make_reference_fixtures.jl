@@ -11,6 +11,9 @@
 #                                         ray_distance_wu (floats as IEEE-754 bit patterns), a 64-step rollout trace
 #     <outdir>/<case>.camera_view.u32     env.camera_view, raw little-endian UInt32, Julia column-major (H_cam, N)
 #     <outdir>/<case>.top_view.u32        env.top_view, raw (H*pu, W*pu) — pins SimpleDraw's Line / Circle too
+#     <outdir>/seeded_rng_mt1_resets.txt  the `rng` keyword (single_room.jl:49,265): SingleRoom(; rng = MersenneTwister(1)), a 64-step
+#                                         rollout with two reset!(env) in it; the state after construction and after every reset!
+#                                         is dumped, so a consumer without Julia's generator can replay the trajectory
 #     <outdir>/manifest.tsv               the cases written + package versions
 #
 # Default outdir: tests/golden/reference (next to this repository's other fixtures).  Then
@@ -28,6 +31,7 @@
 # src/single_room.jl:118-132 are assigned directly, then cast_rays! (SR:134) and the two renderers (SR:328-329) run.
 
 import RayCastWorlds as RCW
+import Random
 
 const SRM = RCW.SingleRoomModule
 const HERE = @__DIR__
@@ -71,6 +75,61 @@ function pkg_version(m)
     catch
         return "unknown"
     end
+end
+
+# The seeded case: the reference's own `rng` keyword.  The post-reset states are written out (goal tile, position bits,
+# heading), because no consumer outside Julia can reproduce MersenneTwister's stream: tests/reference_pin.py injects them
+# (rcw_set_state) where this script calls reset!(env), and everything between two resets must then agree step for step —
+# which also pins that a reset leaves reward = 0, done = false and freshly cast rays (single_room.jl:131-134).
+const SEEDED_NAME = "seeded_rng_mt1_resets"
+const SEEDED_RESET_STEPS = (20, 45)              # reset!(env) is called BEFORE the action of these (1-based) steps
+function seeded_case(versions)
+    rng = Random.MersenneTwister(1)
+    H, W, N = 8, 8, 64
+    env = SRM.SingleRoom(height_tile_map_tu = H, width_tile_map_tu = W, num_rays = N, rng = rng)
+    world = env.world
+    state() = (world.goal_position[1], world.goal_position[2], bits(world.player_position_wu[1]), bits(world.player_position_wu[2]),
+               world.player_direction_au)
+    states = Int[]; append!(states, state())                                     # after construction (rng consumed twice)
+    write(joinpath(OUT, SEEDED_NAME * ".camera_view.u32"), env.camera_view)
+    write(joinpath(OUT, SEEDED_NAME * ".top_view.u32"), env.top_view)
+    actions = lcg_actions(64, UInt64(7))
+    pos, dirs, rew, done, goals = Int[], Int[], Int[], Int[], Int[]
+    error_step = 0
+    for (k, a) in enumerate(actions)
+        if k in SEEDED_RESET_STEPS
+            RCW.reset!(env)                                                      # single_room.jl:326-331, draws from rng
+            append!(states, state())
+        end
+        try
+            RCW.act!(env, a)
+        catch err
+            err isa BoundsError || rethrow()
+            error_step = k
+            break
+        end
+        append!(pos, (bits(world.player_position_wu[1]), bits(world.player_position_wu[2])))
+        push!(dirs, world.player_direction_au); push!(rew, bits(Float32(world.reward))); push!(done, world.done ? 1 : 0)
+        append!(goals, (world.goal_position[1], world.goal_position[2]))
+    end
+    open(joinpath(OUT, SEEDED_NAME * ".txt"), "w") do io
+        println(io, "name ", SEEDED_NAME)
+        println(io, "versions ", versions)
+        println(io, "rng MersenneTwister(1) passed as SingleRoom(; rng)")
+        println(io, "shape ", join_ints((H, W, N, world.num_directions, size(env.camera_view, 1), size(env.top_view, 1), size(env.top_view, 2))))
+        println(io, "directions_wu_bits ", join_ints([bits(v[k]) for v in world.directions_wu for k in 1:2]))
+        println(io, "reset_steps ", join_ints(SEEDED_RESET_STEPS))
+        println(io, "reset_states ", join_ints(states))                          # (goal_i goal_j x_bits y_bits heading) x (1 + resets)
+        println(io, "rollout_actions ", join_ints(actions))
+        println(io, "rollout_error_step ", error_step)
+        println(io, "rollout_position_bits ", join_ints(pos))
+        println(io, "rollout_direction_au ", join_ints(dirs))
+        println(io, "rollout_reward_bits ", join_ints(rew))
+        println(io, "rollout_done ", join_ints(done))
+        println(io, "rollout_goal ", join_ints(goals))
+    end
+    write(joinpath(OUT, SEEDED_NAME * ".camera_view_after_rollout.u32"), env.camera_view)
+    println("wrote ", SEEDED_NAME)
 end
 
 function main()
@@ -130,7 +189,8 @@ function main()
             println("wrote ", name)
         end
     end
-    println("done: ", length(cases), " cases in ", abspath(OUT))
+    seeded_case(versions)
+    println("done: ", length(cases), " cases + the seeded one in ", abspath(OUT))
 end
 
 main()

@@ -93,7 +93,7 @@ constexpr int kProfileSlots = 256;
 // the draw kernel runs on the side stream: fork after what is already queued (the cast kernel), join before the store.
 // The stand-alone call (`beside` = false) has no camera fill to run beside and takes the one-kernel form.
 template <typename Between>
-hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between)
+hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between, hipEvent_t fused_event = nullptr)
 {
     const RcwDev& d = h->dev;
     hipError_t e;
@@ -105,6 +105,14 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
         if ((e = rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
         return between();
+    }
+    if (d.top_fused) {
+        // the camera fill and the drawing in ONE launch (rcw_fill256_draw_kernel), then the store: three launches on one
+        // stream, no fork / join.  `between` — the camera fill of the caller — is replaced by that launch; its profiling
+        // event (behind the fill, in front of the store kernel) is recorded here.
+        if ((e = rcw_launch_fill256_draw(d, mask_dev, h->stream)) != hipSuccess) return e;
+        if (fused_event && (e = hipEventRecord(fused_event, h->stream)) != hipSuccess) return e;
+        return rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream);
     }
     if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
@@ -177,7 +185,7 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
         if (prof && d.top_split && (f = hipEventRecord(ev[2], h->stream)) != hipSuccess) return f;
         return hipSuccess;
     };
-    if (d.top_view) { if ((e = launch_top_view(h, mask_dev, true, fill)) != hipSuccess) return e; }   // SR:337
+    if (d.top_view) { if ((e = launch_top_view(h, mask_dev, true, fill, prof ? ev[2] : nullptr)) != hipSuccess) return e; }   // SR:337
     else {
         if (prof && (e = hipEventRecord(ev[2], h->stream)) != hipSuccess) return e;
         if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
@@ -318,7 +326,7 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr;
     d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
-    d.top_alone_split = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256;
+    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256;
     if (!cfg->render_top_view) {
         if (want_form != 0 && !lenient) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
         return RCW_OK;
@@ -385,6 +393,10 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         d.top_runs = gib >= 4 ? 4 : (gib >= 2 ? 2 : 1);
     }
     if (want_runs >= 1) d.top_runs = want_runs <= 8 ? (want_runs <= h->B ? want_runs : h->B) : 8;
+    // a step's camera fill and the drawing in one launch where the geometry allows (256-row camera view, one run, planes of a
+    // 256-thread draw workgroup): no side stream in the step
+    d.top_fused = rcw_fill_draw_fusable(d) ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_FUSED")) d.top_fused = d.top_fused && std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
     if (d.top_split) {
         hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));
@@ -738,10 +750,11 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // with two a lane, 256 columns 12.3 vs 12.7; 1024 columns take 256 lanes either way), two a lane for small batches, where
     // an agent's own latency is what counts
     { const int lanes = h->B >= 1024 ? (N + 3) / 4 : (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
-    d.cast_ballot = 0; d.cast_table_lds = 0; d.top_debug = 0;
+    d.cast_ballot = 0; d.cast_table_lds = 0; d.cast_r3 = 0; d.top_debug = 0;
     // development builds (make dev: -DRCW_DEV_SWITCHES -> librcw_hip_dev.so) read tuning knobs and the measured-and-rejected
     // kernel variants from the environment; the shipped library reads nothing but RCW_RCCL_LIBRARY
     if (const char* v = RCW_DEV_ENV("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
+    if (const char* v = RCW_DEV_ENV("RCW_CAST_KERNEL")) d.cast_r3 = std::strcmp(v, "r3") == 0 ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_CAST_TABLE"))   // only where tile bytes + 5 N table values fit the default 64 KiB
         d.cast_table_lds = std::strcmp(v, "lds") == 0 && rcw_step_lds_bytes(d) + 2 * (size_t)H + (size_t)RCW_TABLE_ROWS * N * h->real_size + 128 <= 64 * 1024 ? 1 : 0;

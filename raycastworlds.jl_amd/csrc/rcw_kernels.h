@@ -34,6 +34,7 @@ struct RcwDev {
     int32_t cast_block;      // threads per agent in the cast kernel (multiple of 64, <= 256)
     int32_t cast_ballot;     // development only (RCW_CAST_MARCH=ballot): the ballot-bounded march instead of the exec-masked one
     int32_t cast_table_lds;  // development only (RCW_CAST_TABLE=lds): stage the heading's ray-table slice in LDS first
+    int32_t cast_r3;         // development only (RCW_CAST_KERNEL=r3): the round-3 cast kernel (five dependent round trips), for the comparison
     int64_t agent_id_offset;
     uint64_t seed;
     // state (SR:21-40), one entry per agent
@@ -65,6 +66,7 @@ struct RcwDev {
     int32_t top_plane_words; // ... and the words of one agent's region of top_plane in that form
     int32_t top_alone_split; // rcw_update_top_view alone (no camera fill beside it) also takes the two-kernel form, back to back
     int32_t top_runs;        // the batch is drawn and stored in this many runs of agents (store of run r beside the drawing of run r + 1)
+    int32_t top_fused;       // a step's camera fill and top-view drawing go in ONE launch (rcw_fill256_draw_kernel) instead of two streams
     int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU
     int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
     int32_t top_store_grid;  // ... and its workgroups (the moving window = top_store_grid KiB x 4)
@@ -107,6 +109,8 @@ size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);    // agents [first, first + count)
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
+int rcw_fill_draw_fusable(const RcwDev& p);   // a step's camera fill + top-view drawing in one launch: this geometry takes it
+hipError_t rcw_launch_fill256_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);   // (fills p.obs from p.col_h / p.col_c, draws every agent)
 hipError_t rcw_prepare_top_view(const RcwDev& p, int device);
 hipError_t rcw_launch_reset(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);
 hipError_t rcw_launch_set_state(const RcwDev& p, const int2* goal, const void* pos /* float2* or double2* */,

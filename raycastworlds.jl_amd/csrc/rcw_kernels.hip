@@ -107,6 +107,7 @@ __device__ __forceinline__ int floor_to_int32(double f) { return (int)fmin(fmax(
 // HBM holds: cast_ray's march reads it for any index outside the map and relies on it to stop (see there).
 __device__ __forceinline__ void stage_tile_bytes(uint8_t* tb, const uint32_t* tm_hbm, int HW, int tid, int nthreads)
 {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int t = tid; t < HW; t += nthreads) {
         const uint32_t b = (tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u;
         tb[t] = (uint8_t)(t == HW - 1 ? (b | 1u) : b);
@@ -391,13 +392,18 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d)
     return q;
 }
 
-// ---- kernel 1 of a step: dynamics + ray cast + projection --------------------------------
+#ifdef RCW_DEV_SWITCHES
+// ---- the ROUND-3 form of kernel 1 (development build only: RCW_CAST_KERNEL=r3, and the carrier of the two measured-and-rejected
+// variants RCW_CAST_MARCH=ballot / RCW_CAST_TABLE=lds).  Its loads are written "up front" but the compiler serialises them: the
+// tile-map staging loop waits for its own loads before the action byte is requested, the pose and heading come after that,
+// the heading's direction vector after those, the ray-table row after the dynamics — five dependent round trips.  rcw_cast_kernel
+// below issues them in two. --------------------------------
 // One workgroup per agent.  Output: the agent's new state and one compact descriptor per
 // image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
 // of pixels the fill kernel then writes for it.
 // TIE_LE / DIST_PRE: the UNPINNED cast_ray choices (include/rcw.h), compiled in.
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
+__global__ __launch_bounds__(kBlock) void rcw_cast_kernel_r3(const RcwDev p,
                                                           const uint8_t* __restrict__ actions,
                                                           const uint8_t* __restrict__ mask, int first)
 {
@@ -506,6 +512,261 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         p.col_c[(size_t)a * p.N + k] = (uint8_t)cid;
     }
 }
+#endif   // RCW_DEV_SWITCHES (rcw_cast_kernel_r3)
+
+// ---- kernel 1 of a step: dynamics + ray cast + projection --------------------------------
+// One workgroup per agent.  Output: the agent's new state and one compact descriptor per
+// image column (height_line_pu, colour id) — 5 bytes per column, against the 4·H_cam bytes
+// of pixels the fill kernel then writes for it.
+// TIE_LE / DIST_PRE: the UNPINNED cast_ray choices (include/rcw.h), compiled in.
+//
+// The kernel is bound by its chain of dependent memory round trips and by its instruction count together (a wavefront lives
+// ~6 us at cfg-2, most of it waiting: profiles/r03_cast_cfg2_sq.txt), so the loads are arranged in TWO batches, each issued
+// back to back and awaited once:
+//   1  mask byte, action byte, pose, heading, done flag and this lane's tile-map words (nothing depends on anything);
+//   2  what depends on the heading AFTER the action — known as soon as batch 1 is back: turn_left / turn_right touch
+//      nothing else (UT:13-14) —: the old heading's direction vector (move_forward / move_backward, UT:16-17) and the new
+//      heading's ray-table entries of this lane's first kCastCols view columns (20 registers), in flight while the tile
+//      bytes are unpacked into LDS and the dynamics run.
+// (The round-3 kernel asked for the same loads in the same order of SOURCE lines; its ISA waited five times:
+// rcw_cast_kernel_r3 above, kept in the development build for the comparison.)
+// Batch 1 of the cast kernel's loads — mask byte, action byte, done flag, heading, pose: five wave-uniform addresses, five
+// SCALAR loads issued back to back and awaited ONCE.  Written as one asm statement because the compiler, left to itself,
+// puts each load's first use (a shift, a compare) right behind it and therefore a `s_waitcnt lgkmcnt(0)` after every single
+// load (scalar loads return out of order: the counter can only be waited to zero) — five round trips instead of one; as
+// vector loads of a uniform address it follows each with v_readfirstlane, with the same effect.
+// gfx9 has no scalar byte load: a byte comes as the aligned 32-bit word that holds it (the hardware drops the address's two
+// low bits); the word never leaves the byte's page, so it is readable whenever the byte is, and the other three bytes —
+// neighbouring agents' — are discarded.  The statement ends with the wait, so nothing is in flight when it returns.
+typedef uint32_t su32x4 __attribute__((ext_vector_type(4)));
+struct CastState { uint32_t mask_w, act_w, done_w; int d; };
+__device__ __forceinline__ CastState load_cast_state(const uint8_t* mask_q, const uint8_t* act_q, const uint8_t* done_q, const int32_t* dir_q,
+                                                     const float2* pos_q, float2& pos)
+{
+    CastState c; uint64_t pw;
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %6, 0x0\n\ts_load_dword %2, %7, 0x0\n\ts_load_dword %3, %8, 0x0\n\t"
+                 "s_load_dwordx2 %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(c.mask_w), "=&s"(c.act_w), "=&s"(c.done_w), "=&s"(c.d), "=&s"(pw)
+                 : "s"(mask_q), "s"(act_q), "s"(done_q), "s"(dir_q), "s"(pos_q) : "memory");
+    pos.x = __uint_as_float((uint32_t)pw); pos.y = __uint_as_float((uint32_t)(pw >> 32));
+    return c;
+}
+__device__ __forceinline__ CastState load_cast_state(const uint8_t* mask_q, const uint8_t* act_q, const uint8_t* done_q, const int32_t* dir_q,
+                                                     const double2* pos_q, double2& pos)
+{
+    CastState c; su32x4 pw;
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %6, 0x0\n\ts_load_dword %2, %7, 0x0\n\ts_load_dword %3, %8, 0x0\n\t"
+                 "s_load_dwordx4 %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(c.mask_w), "=&s"(c.act_w), "=&s"(c.done_w), "=&s"(c.d), "=&s"(pw)
+                 : "s"(mask_q), "s"(act_q), "s"(done_q), "s"(dir_q), "s"(pos_q) : "memory");
+    pos.x = __longlong_as_double((long long)(((uint64_t)pw.y << 32) | pw.x)); pos.y = __longlong_as_double((long long)(((uint64_t)pw.w << 32) | pw.z));
+    return c;
+}
+__device__ __forceinline__ int byte_of_word(uint32_t w, const uint8_t* q) { return (int)((w >> (8u * (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3u))) & 0xffu); }
+// base[byte_offset] with a 32-bit byte offset: the uniform base stays in scalar registers and the lane's part of the address
+// is one register (global_load ... v_off, s[base]); indexed in C the offset is sign-extended and the address built per lane in
+// 64 bits — two more registers and two more instructions for every load.
+template <typename T>
+__device__ __forceinline__ T load_at(const T* base, uint32_t byte_offset)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
+}
+
+#ifdef RCW_TRACE_WAVES
+// Measurement build only (make trace, tools/cast_trace.py): the first wavefront of each of the first 4096 workgroups of
+// rcw_cast_kernel leaves s_memrealtime (100 MHz) at eight points of its life, and where it ran.
+__device__ unsigned long long g_cast_trace[4096 * 10];
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int rcw_cast_trace_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cast_trace), sizeof(unsigned long long) * 4096 * 10);
+}
+namespace {
+#define RCW_CAST_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) g_cast_trace[blockIdx.x * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RCW_CAST_STAMP(k) do { } while (0)
+#endif
+
+constexpr int kCastCols = 4;    // view columns a lane keeps in registers (cast_block is chosen so that a lane has at most 4)
+constexpr int kCastTiles = 4;   // tiles a lane unpacks from words requested in batch 1 (a 32x32 map on 256 lanes); larger maps loop
+
+// One view column: march, projection, descriptor.  Returns whether the ray left the map (the caller reports it once per lane:
+// a branch around two stores in every column costs the issue-bound kernel eight instructions a column).  The descriptor arrays
+// are addressed as uniform base (the agent's row) + 32-bit lane offset.
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, int32_t* col_h_a, uint8_t* col_c_a, int i, T x, T y, T dx, T dy, T ddx, T ddy, T dot)
+{
+    const RayHit<T> r = cast_ray_guarded<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+    const int hl = height_line_pu<T>(p, r.dist, dot);
+    const int h = r.oob ? p.Hc : hl;
+    // SR:417-429: wall / goal by the WALL bit of the stop tile, shade by hit dimension
+    const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);
+    const uint32_t k = (uint32_t)(p.N - 1 - i);                             // SR:431 (0-based)
+    *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(col_h_a) + k * 4u) = h;
+    *(col_c_a + k) = (uint8_t)cid;
+    return r.oob;
+}
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
+                                                          const uint8_t* __restrict__ actions,
+                                                          const uint8_t* __restrict__ mask, int first)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typedef typename Real<T>::vec2 vec2;
+    const int a = first + (int)blockIdx.x;                  // agents [first, first + gridDim.x)
+    const int tid = threadIdx.x, nthr = (int)blockDim.x;
+    const int H = p.H, HW = p.H * p.W, N = p.N;
+    RCW_CAST_STAMP(0);
+
+    // ---- batch 1: the agent's state (all addresses known from the kernel arguments) ------------------------
+    // No load sits under a branch (a conditional load is a basic block of its own, and the compiler waits for it at the
+    // block's end): absent arrays read a harmless stand-in (the done flag), lanes past the map's end re-read its last word.
+    // The three bytes, heading and pose: load_cast_state.
+    uint32_t* const tm_hbm = p.tile_map + (size_t)a * p.nwords;
+    uint32_t tw[kCastTiles];
+#pragma unroll
+    for (int k = 0; k < kCastTiles; ++k) {                                  // (vector loads: issued here, awaited below)
+        const int t = tid + k * nthr;
+        tw[k] = load_at(tm_hbm, (uint32_t)((t < HW ? t : HW - 1) >> 4) * 4u);
+    }
+    const uint8_t* const mask_q = mask != nullptr ? mask + a : p.done + a;
+    const uint8_t* const act_q = actions != nullptr ? actions + a : p.done + a;
+    vec2 pos;
+    const CastState st = load_cast_state(mask_q, act_q, p.done + a, p.dir + a, Real<T>::pos(p) + a, pos);
+    const int m = byte_of_word(st.mask_w, mask_q), was_done = byte_of_word(st.done_w, p.done + a), d = st.d;
+    int act = byte_of_word(st.act_w, act_q);
+    // the tile words too (and every wavefront of the workgroup has READ the state before lane 0 overwrites it below)
+    asm volatile("" :: "v"(tw[0]), "v"(tw[1]), "v"(tw[2]), "v"(tw[3]));
+    RCW_CAST_STAMP(1);
+    if (mask != nullptr && m == 0) return;
+    if (actions == nullptr) act = 0;
+
+    const bool invalid = actions != nullptr && (act < 1 || act > RCW_NUM_ACTIONS);   // @assert SR:140
+    if (invalid) act = 0;                                                   // this agent is not stepped
+    const bool resample = act != 0 && p.auto_reset != 0 && was_done != 0;
+    int d_new = d;
+    if (!resample && act == 3) d_new = d + 1 >= p.nd ? 0 : d + 1;          // turn_left  UT:13
+    if (!resample && act == 4) d_new = d - 1 < 0 ? p.nd - 1 : d - 1;       // turn_right UT:14
+
+    // ---- batch 2: what depends on the heading ---------------------------------------------------------------
+    // (with a re-sampled heading — rare — the row of the OLD heading is fetched for nothing and the right one again below)
+    const vec2 dv = Real<T>::dir_table(p)[d];                               // SR:153
+    T r_dx[kCastCols], r_dy[kCastCols], r_ddx[kCastCols], r_ddy[kCastCols], r_dot[kCastCols];
+    {
+        const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
+#pragma unroll
+        for (int k = 0; k < kCastCols; ++k) {                               // (five uniform row bases, one lane offset per column)
+            const int i = tid + k * nthr;
+            const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);   // (lanes past the last column re-read it)
+            r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o);
+            r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+        }
+    }
+
+    // LDS: [H guard bytes | H*W tile bytes, the agent's tile map | H guard bytes] (cast_ray_guarded) | the re-sampled pose
+    uint8_t* const tb = reinterpret_cast<uint8_t*>(lds) + H;
+    // (the loops below run zero times at every BASELINE configuration; `nounroll` keeps the compiler from computing their
+    // trip counts — an integer division by blockDim, two dozen instructions each — and from unrolling them by eight)
+    if (tid < 2 * H) (tid < H ? tb - H + tid : tb + HW + (tid - H))[0] = 1;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int k = tid + nthr; k < 2 * H; k += nthr) (k < H ? tb - H + k : tb + HW + (k - H))[0] = 1;
+    T* const s_pose = reinterpret_cast<T*>(lds + ((HW + 2 * H + 15) / 16) * 4);       // [2] + the heading (auto-reset)
+    int& s_pose_d = *reinterpret_cast<int*>(s_pose + 2);
+#pragma unroll
+    for (int k = 0; k < kCastTiles; ++k) {                                  // (as stage_tile_bytes: the last tile reads as an obstacle)
+        const int t = tid + k * nthr;
+        if (t < HW) { const uint32_t b = (tw[k] >> ((t & 15) * 2)) & 3u; tb[t] = (uint8_t)(t == HW - 1 ? (b | 1u) : b); }
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int t = tid + kCastTiles * nthr; t < HW; t += nthr) {              // maps of more than kCastTiles * blockDim tiles
+        const uint32_t b = (tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u;
+        tb[t] = (uint8_t)(t == HW - 1 ? (b | 1u) : b);
+    }
+    __syncthreads();
+    RCW_CAST_STAMP(2);
+
+    // ---- phase 0: dynamics, computed redundantly by every lane (no broadcast needed) --------
+    T x = pos.x, y = pos.y;
+    if (resample) {                                                         // wave-uniform, rare
+        if (tid == 0) {
+            const Pose<T> np = reset_agent<T>(p, a, tm_hbm, nullptr);
+            s_pose[0] = np.x; s_pose[1] = np.y; s_pose_d = np.d;
+        }
+        __syncthreads();
+        stage_tile_bytes(tb, tm_hbm, HW, tid, nthr);                        // the goal moved
+        __syncthreads();
+        x = s_pose[0]; y = s_pose[1];
+        d_new = __builtin_amdgcn_readfirstlane(s_pose_d);
+        const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
+#pragma unroll
+        for (int k = 0; k < kCastCols; ++k) {
+            const int i = tid + k * nthr;
+            const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);
+            r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o);
+            r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+        }
+    } else if (act != 0) {
+        int done = 0;                                                       // reward = done ? goal_reward : zero(R)
+        bool oob = false;
+        if (act <= 2) {                                                     // SR:150
+            const T ix = Real<T>::inc(p) * dv.x, iy = Real<T>::inc(p) * dv.y;
+            const T nx = act == 1 ? pos.x + ix : pos.x - ix;                // UT:16-17
+            const T ny = act == 1 ? pos.y + iy : pos.y - iy;
+            const Collide c = player_colliding<T>(tb, p.H, p.W, nx, ny, Real<T>::radius_sq(p), p.oob_empty);   // SR:162-163
+            if (c.wall == 2 || c.goal == 2) oob = true;                     // BoundsError: no mutation
+            else if (c.goal) { done = 1; }                                  // SR:166-168
+            else if (c.wall) { }                                            // SR:170-171
+            else { x = nx; y = ny; }                                        // SR:174
+        }
+        if (tid == 0) {
+            if (oob) {
+                p.err[0] = RCW_ERR_OUT_OF_BOUNDS;
+                p.status[a] = RCW_ERR_OUT_OF_BOUNDS;
+            } else {
+                Real<T>::pos(p)[a] = Real<T>::make(x, y);                   // SR:174
+                p.dir[a] = d_new;                                           // SR:185
+                store_reward(p, a, done != 0); p.done[a] = (uint8_t)done;   // SR:167-176, SR:186-187
+            }
+        }
+    }
+    if (invalid && tid == 0) { p.err[0] = RCW_ERR_INVALID_ACTION; p.status[a] = RCW_ERR_INVALID_ACTION; }
+
+    // ---- phase 1: one lane per view column (SR:220, SR:401) --------------------------------------------------
+    RCW_CAST_STAMP(3);
+#ifdef RCW_TRACE_WAVES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (measurement build: when is the table row here?)
+    RCW_CAST_STAMP(4);
+#endif
+    int32_t* const col_h_a = p.col_h + (size_t)a * N;
+    uint8_t* const col_c_a = p.col_c + (size_t)a * N;
+    bool left_the_map = false;
+#pragma unroll
+    for (int k = 0; k < kCastCols; ++k) {
+        const int i = tid + k * nthr;
+        if (i < N) left_the_map |= cast_column<T, TIE_LE, DIST_PRE>(p, tb, col_h_a, col_c_a, i, x, y, r_dx[k], r_dy[k], r_ddx[k], r_ddy[k], r_dot[k]);
+#ifdef RCW_TRACE_WAVES
+        if (k == 0) RCW_CAST_STAMP(5);
+#endif
+    }
+    RCW_CAST_STAMP(6);
+#ifdef RCW_TRACE_WAVES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (the descriptor stores acknowledged)
+    RCW_CAST_STAMP(7);
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        g_cast_trace[blockIdx.x * 10 + 8] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
+    if (N > kCastCols * nthr) {                                             // more than kCastCols columns a lane (N > 1024)
+        const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int i = tid + kCastCols * nthr; i < N; i += nthr)
+            left_the_map |= cast_column<T, TIE_LE, DIST_PRE>(p, tb, col_h_a, col_c_a, i, x, y, tab[i], tab[N + i], tab[2 * N + i], tab[3 * N + i], tab[4 * N + i]);
+    }
+    if (left_the_map) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }   // (Julia: BoundsError in cast_ray)
+}
 
 // ---- kernel 2 of a step: column descriptors -> pixels -------------------------------------
 // The bandwidth kernel: B·N·H_cam·4 bytes, written once.  HBM on MI355X takes writes fastest
@@ -535,16 +796,16 @@ __device__ __forceinline__ void store16(u32x4* dst, u32x4 v)
     if (PLAIN) *dst = v; else __builtin_nontemporal_store(v, dst);
 }
 
+// (the body is a function of its own — workgroup `block` of `blocks` — because rcw_fill256_draw_kernel below runs it in the
+// first `blocks` workgroups of a larger launch)
 template <bool PLAIN>
-__global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
-                                                             const int32_t* __restrict__ col_h,
-                                                             const uint8_t* __restrict__ col_c,
-                                                             u32x4* __restrict__ out, long long total_cols,
-                                                             const uint8_t* __restrict__ mask)
+__device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __restrict__ col_h, const uint8_t* __restrict__ col_c,
+                                             u32x4* __restrict__ out, long long total_cols, const uint8_t* __restrict__ mask,
+                                             int block, int blocks)
 {
     const int lane = threadIdx.x & 63;
-    const long long G = (long long)gridDim.x * (kBlock / 64);
-    const long long g = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const long long G = (long long)blocks * (kBlock / 64);
+    const long long g = (long long)block * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
     const int r0 = lane * 4;
 #ifdef RCW_TRACE_WAVES
@@ -589,6 +850,16 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
         g_wave_trace[(g * 20 + 18) * 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
     }
 #endif
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
+                                                             const int32_t* __restrict__ col_h,
+                                                             const uint8_t* __restrict__ col_c,
+                                                             u32x4* __restrict__ out, long long total_cols,
+                                                             const uint8_t* __restrict__ mask)
+{
+    fill256_body<PLAIN>(p, col_h, col_c, out, total_cols, mask, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of
@@ -1612,10 +1883,9 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
 // out unpadded, with the player's pixel (SR:468) and, per (tile column, row block), the 2-bit fill codes of the
 // chunk's tiles packed into 64 bits.
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask, int first)
+__device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __restrict__ mask, int a, uint32_t* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int a = first + (int)blockIdx.x, tid = threadIdx.x, group = blockDim.x;         // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
+    const int tid = threadIdx.x, group = blockDim.x;                          // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
     if (mask != nullptr && mask[a] == 0) return;                             // workgroup-uniform
     const TopBuf b = top_buf(p, lds);
     top_prepare(p, a, b, tid, group);
@@ -1675,6 +1945,30 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
         }
         p.top_codes[((size_t)a * p.W + tj) * k + rb] = make_uint2(lo, hi);
     }
+}
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask, int first)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x, lds);
+}
+
+// The camera fill and the top view's drawing in ONE launch (a step that renders both images, H_cam = 256, planes that fit a
+// 256-thread draw workgroup): workgroups 0 .. fill_blocks - 1 are rcw_fill256_kernel's — dispatched first, onto an empty device,
+// one per CU as in a launch of their own —, workgroup fill_blocks + q draws agent first + q.  What the side stream gave — an
+// HBM-bound kernel and a VALU/LDS-bound one sharing the CUs — without its event record / wait pairs on two streams (DESIGN.md
+// §4.4: ≈ 7–10 µs a step, and the reason small batches stayed on the one-kernel form).  The fill workgroups reserve the draw's
+// LDS (one workgroup per CU: nothing else wanted it) and run at the draw's register count (they are one wavefront per SIMD).
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_fill256_draw_kernel(const RcwDev p, const int32_t* __restrict__ col_h,
+                                                                  const uint8_t* __restrict__ col_c, u32x4* __restrict__ out,
+                                                                  long long total_cols, const uint8_t* __restrict__ mask,
+                                                                  int fill_blocks, int first)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if ((int)blockIdx.x < fill_blocks) { fill256_body<false>(p, col_h, col_c, out, total_cols, mask, (int)blockIdx.x, fill_blocks); return; }
+    top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x - fill_blocks, lds);
 }
 
 // Store kernel: the moving window of rcw_fill256_kernel over the top view's 1 KiB chunks (chunk id = flat pixel
@@ -2484,6 +2778,12 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
                            hipStream_t s, int first, int count)
 {
     if (count < 0) count = p.B - first;
+#ifdef RCW_DEV_SWITCHES
+    if (p.cast_ballot || p.cast_table_lds || p.cast_r3) {                  // the round-3 kernel and its two rejected variants
+        RCW_DISPATCH(rcw_cast_kernel_r3, dim3(count), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev, first);
+        return hipGetLastError();
+    }
+#endif
     RCW_DISPATCH(rcw_cast_kernel, dim3(count), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev, first);
     return hipGetLastError();
 }
@@ -2560,6 +2860,20 @@ size_t rcw_top_codes_bytes(const RcwDev& p)
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
 {
     RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(p.top_draw_block), 4 * top_buf_words(p), p, mask_dev, first);
+    return hipGetLastError();
+}
+// the camera fill of the whole batch + the drawing of every agent in one launch (rcw_fill256_draw_kernel): whether this handle's
+// geometry takes it, and the launch
+int rcw_fill_draw_fusable(const RcwDev& p)
+{
+    return p.top_split && p.top_runs <= 1 && p.top_draw_block == kBlock && !p.fill_plain && 4 * top_buf_words(p) <= 64 * 1024 &&
+           fill_choice(p, (long long)p.B * p.N) == kFill256 && (long long)p.fill_grid + p.B < (1ll << 31);
+}
+hipError_t rcw_launch_fill256_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
+{
+    u32x4* const frames4 = reinterpret_cast<u32x4*>(p.obs);
+    RCW_DISPATCH(rcw_fill256_draw_kernel, dim3(p.fill_grid + p.B), dim3(kBlock), 4 * top_buf_words(p), p, p.col_h, p.col_c, frames4,
+                 (long long)p.B * p.N, mask_dev, p.fill_grid, 0);
     return hipGetLastError();
 }
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)

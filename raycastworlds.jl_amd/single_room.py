@@ -322,8 +322,10 @@ class SingleRoom:
 
     Keyword arguments and defaults are the reference's (SR:258-272). `T` is "Float32" (default)
     or "Float64"; `R` (the reward type, SR:266) is "Float32" (default), "Float64", "Int32" or "Int64";
-    a caller-supplied Julia `rng` is replaced by `seed`, which keys the device generator. `device` is
-    the HIP device index.
+    `seed` keys the device generator (the default: resets are sampled on the GPU, reproducibly, in the reference's
+    distribution).  `rng` (SR:49,265) gives the reference's keyword back: a `numpy.random.Generator` — or one per agent —
+    from which construction and every `reset_(env, rng=...)` draw goal, player tile and heading on the HOST in exactly
+    the reference's order (`reference_reset_draws`), injected with `rcw_set_state`.  `device` is the HIP device index.
     """
 
     def __init__(
@@ -337,6 +339,7 @@ class SingleRoom:
         player_radius_wu: float = 1 / 8,
         position_increment_wu: float = 1 / 8,
         seed: int = 0,
+        rng=None,
         R="Float32",
         semi_field_of_view_wu: float = 2 / 3,
         num_rays: int = 512,
@@ -419,6 +422,14 @@ class SingleRoom:
                 self._handle.close()             # nothing of a half-made environment stays allocated
                 raise
         self.host_syncs = 0      # host synchronisations / device-to-host getters issued through this object (bench.py --api rlbase)
+        self.rng = rng
+        if rng is not None:
+            # the reference's constructor consumes its rng TWICE: the draws of SR:62-74, then reset!(world) SR:105 -> SR:120-128
+            try:
+                _reset_from_rng(self, rng, None, construction=True)
+            except BaseException:
+                self._handle.close()
+                raise
         # colour fields of the reference struct SR:241-256
         self.floor_color = cfg.floor_color
         self.ceiling_color = cfg.ceiling_color
@@ -737,8 +748,75 @@ class SingleRoom:
 
 
 # ---- the generic functions of RayCastWorlds.jl:7-14 that are on the path ------------------
-def reset_(env: SingleRoom, mask=None, seed: Optional[int] = None) -> None:
-    """`RCW.reset!(env)` SR:326-331 — all agents, or those with a non-zero `mask` byte."""
+def reference_reset_draws(rng, H: int, W: int, nd: int, old_goal=None):
+    """The random draws of ONE `reset!(world)` (SR:110-137) from `rng` (a `numpy.random.Generator`: `integers(lo, hi)`,
+    `hi` exclusive), in the reference's order and number:
+
+        rand(rng, 2:H-1), rand(rng, 2:W-1)                     the goal tile                      SR:120
+        rand(rng, CartesianIndices((1:H, 1:W)))                the player's tile; drawn AGAIN while the tile is occupied
+                                                               (wall ring or the new goal), at most 1024 H W times  UT:23-37
+        rand(rng, 0:nd-1)                                      the heading                        SR:128
+
+    A position is ONE draw of a linear index into the column-major region (i = lin mod H + 1, j = lin div H + 1), as
+    `rand(rng, ::AbstractArray)` indexes its argument with one `rand(rng, 1:length)`.  Returns (goal_i, goal_j, tile_i,
+    tile_j, heading), tiles 1-based.  `old_goal` is not needed: reset! clears the old goal bit before it draws (SR:118)."""
+    gi = int(rng.integers(2, H))                     # 2 : H - 1
+    gj = int(rng.integers(2, W))
+
+    def occupied(lin):
+        i, j = lin % H + 1, lin // H + 1
+        return i == 1 or i == H or j == 1 or j == W or (i == gi and j == gj)      # any(@view tile_map[:, position]) UT:27
+
+    lin = int(rng.integers(0, H * W))                # UT:24
+    for _ in range(1024 * H * W):                    # UT:26
+        if occupied(lin):
+            lin = int(rng.integers(0, H * W))        # UT:28
+        else:
+            break
+    d = int(rng.integers(0, nd))                     # 0 : nd - 1
+    return gi, gj, lin % H + 1, lin // H + 1, d
+
+
+def _reset_from_rng(env: "SingleRoom", rng, mask, construction: bool = False) -> None:
+    """reset!(world) for every (unmasked) agent with the caller's generator(s): agent after agent from ONE generator —
+    B reference worlds sharing an rng, reset in order — or agent a from `rng[a]` — each agent the reference world built
+    with that rng.  The state goes to the engine with one rcw_set_state (tile_map goal bit, pose, heading, reward 0,
+    done false, rays cast, views rendered: SR:118-134, SR:328-329)."""
+    H, W, nd, B = env.cfg.height_tile_map_tu, env.cfg.width_tile_map_tu, env.cfg.num_directions, env.batch
+    per_agent = not hasattr(rng, "integers")
+    if per_agent and len(rng) != B:
+        raise ValueError(f"expected one generator or {B} of them, got {len(rng)}")
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(B)
+    goal = np.ones((B, 2), dtype=np.int32)
+    pos = np.ones((B, 2), dtype=env.T)
+    head = np.zeros(B, dtype=np.int32)
+    for a in range(B):
+        if m is not None and not m[a]:
+            continue
+        g = rng[a] if per_agent else rng
+        if construction:
+            reference_reset_draws(g, H, W, nd)       # SR:62-74: drawn, then overwritten by reset!(world) SR:105
+        gi, gj, ti, tj, d = reference_reset_draws(g, H, W, nd)
+        goal[a] = (gi, gj)
+        pos[a] = (env.T(ti - 0.5), env.T(tj - 0.5))  # convert(T, tile - 0.5) SR:125
+        head[a] = d
+    if m is not None:
+        # masked-out agents keep their state: rcw_set_state skips them, the placeholders above are never read
+        pass
+    env.set_state(goal, pos, head, mask=m)
+
+
+def reset_(env: SingleRoom, mask=None, seed: Optional[int] = None, rng=None) -> None:
+    """`RCW.reset!(env)` SR:326-331 — all agents, or those with a non-zero `mask` byte.
+
+    Default: sampled on the device by the engine's counter-based generator keyed (seed, global agent id, episode).
+    `rng` (or an environment constructed with one, SR:49): the reference's own keyword — the draws come from the caller's
+    generator on the host, in the reference's order (`reference_reset_draws`)."""
+    if rng is None and seed is None:
+        rng = getattr(env, "rng", None)
+    if rng is not None:
+        _reset_from_rng(env, rng, mask)
+        return None
     if seed is not None:
         env.seed = int(seed)
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(env.batch)

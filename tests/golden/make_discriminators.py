@@ -135,7 +135,14 @@ def main():
             goal=[6, 3], position=[3.71875, 5.40625], direction=23,
             why="not a switch discriminator: pins SimpleDraw's Line / Circle (top_view) on a pixel scale that is not a power of two — "
                 "12 pixels a tile: wu_to_pu end points, Bresenham lines and the midpoint circle (radius_pu = 2) on a 96 x 96 image, "
-                "where the engine's flat store kernel (any pixel scale from 9) renders; compared through <name>.top_view.u32")])
+                "where the engine's flat store kernel (any pixel scale from 9) renders; compared through <name>.top_view.u32"),
+            dict(
+            name="top_view_pu13_rasterisers",
+            config=dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64, pu_per_tu=13),
+            goal=[3, 6], position=[5.28125, 2.65625], direction=101,
+            why="not a switch discriminator: SimpleDraw's Line / Circle at 13 pixels a tile — a scale that is not a multiple of 4, "
+                "so a lane's four pixels straddle tiles and the 104 x 104 image is 42.25 chunks (the flat store kernel's STRADDLE "
+                "path); wu_to_pu(x) = ceil(13 x) lands off the Float32 grid's round numbers; compared through <name>.top_view.u32")])
     with open(os.path.join(HERE, "discriminators.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
         f.write("\n")

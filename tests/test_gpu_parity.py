@@ -958,6 +958,50 @@ def test_external_stream_is_not_record_streamed(rcw, oracle):
     env.close()
 
 
+def test_rng_keyword_resets_from_the_callers_generator(rcw, oracle):
+    """SingleRoom(; rng) / reset!(env) with the caller's generator (SR:49,265; draws at SR:62-74, SR:120-128, UT:24-28): the
+    engine's state after construction, after reset_(env), after a masked reset and after a reset from per-agent generators
+    equals the oracle given the draws a TWIN generator (same seed) yields in the reference's order."""
+    SR = rcw.SingleRoomModule
+    B, H, W, nd = 48, 8, 16, 128
+
+    def expect(orc, gens, mask=None, construction=False):
+        goal, pos, head = orc.goal.copy(), orc.position.copy(), orc.direction.copy()
+        for a in range(B):
+            if mask is not None and not mask[a]:
+                continue
+            g = gens[a] if isinstance(gens, list) else gens
+            if construction:
+                SR.reference_reset_draws(g, H, W, nd)
+            gi, gj, ti, tj, d = SR.reference_reset_draws(g, H, W, nd)
+            goal[a], pos[a], head[a] = (gi, gj), (ti - 0.5, tj - 0.5), d
+        orc.set_state(goal, pos, head, mask=mask)
+
+    env = SR.SingleRoom(batch=B, rng=np.random.default_rng(42), out_of_bounds=1, num_rays=64)     # the reference's default 8 x 16 room
+    twin = np.random.default_rng(42)
+    orc = oracle.OracleBatch(B, out_of_bounds=1, num_rays=64)
+    expect(orc, twin, construction=True)
+    assert_state_equal(env, orc, rays=True, where="after construction with rng")
+    rng = np.random.default_rng(3)
+    _rollout(rcw, env, orc, 30, rng, check_every=10)
+    rcw.reset_(env)                                      # the environment's own rng goes on where it stopped
+    expect(orc, twin)
+    assert_state_equal(env, orc, where="after reset!(env) with the environment's rng")
+    assert (env.world.reward == 0).all() and not env.world.done.any()
+    mask = (rng.random(B) < 0.4).astype(np.uint8); mask[5] = 1
+    rcw.reset_(env, mask=mask)
+    expect(orc, twin, mask=mask)
+    assert_state_equal(env, orc, where="after a masked reset with rng")
+    _rollout(rcw, env, orc, 10, rng, check_every=5)
+    rcw.reset_(env, rng=[np.random.default_rng(100 + a) for a in range(B)])       # one generator per agent
+    expect(orc, [np.random.default_rng(100 + a) for a in range(B)])
+    assert_state_equal(env, orc, where="after a reset from per-agent generators")
+    # agent a is then the reference world built with rng[a]: agents with equal generators are equal
+    rcw.reset_(env, rng=[np.random.default_rng(7) for _ in range(B)])
+    assert len({tuple(r) for r in env.world.goal_position.tolist()}) == 1
+    env.close()
+
+
 def test_play_keys_replays_the_keyboard_callback(rcw, oracle, tmp_path):
     """Headless `play!` (SR:488-568): a scripted key sequence — W/S/A/D act, R resets, V toggles the view, an unbound
     key warns, Q closes — with the frame buffer after every key compared with the oracle's views blitted the

@@ -247,6 +247,41 @@ def test_flat_plane_layout_makes_chunks_whole_words():
             np.testing.assert_array_equal(got, want, err_msg=f"{Ht}x{Wt} chunk {c}")
 
 
+def test_flat_store_kernel_reads_stay_inside_their_allocations():
+    """rcw_top_store_flat_kernel's loads are CLAMPED into their arrays, not predicated (rcw_kernels.hip, `issue`), and two of
+    them reach past the element they name: three tile_map words from any word of a map (12-byte load), eight plane words
+    from a chunk's first word (two 16-byte loads).  Restated here with the allocation sizes of rcw_api.hip /
+    rcw_kernels.hip — tile_map: B * nwords words + 16 bytes; top_plane: B * PW words + 64 bytes, PW = ((Ht Wt + 510) div
+    256) * 8 — and checked for the EXTREME addresses over geometries whose images are not a whole number of chunks
+    (profiles/r04_exp5_fault.txt: one of the three candidate causes of round 3's unexplained memory access fault)."""
+    rng = np.random.default_rng(4)
+    geometries = [(8, 8, 13), (8, 8, 10), (24, 24, 12), (9, 7, 19), (3, 3, 14), (5, 33, 9)] + \
+                 [(int(rng.integers(3, 40)), int(rng.integers(3, 40)), int(rng.integers(9, 40))) for _ in range(60)]
+    for H, W, pu in geometries:
+        Ht, Wt = H * pu, W * pu
+        if Ht % 4:
+            continue                                           # (the flat kernel takes image heights that are a multiple of 4)
+        px = Ht * Wt
+        for B in (1, 2, 3, int(rng.integers(4, 50))):
+            nwords = 2 * ((2 * H * W + 63) // 64)
+            tile_alloc_words = B * nwords + 4                  # (+ 16 bytes)
+            PW = ((px + 510) // 256) * 8
+            plane_alloc_words = B * PW + 16                    # (+ 64 bytes)
+            # tile_map: the furthest 12-byte load starts at the last word of the last agent's map
+            assert (B - 1) * nwords + (nwords - 1) + 3 <= tile_alloc_words
+            # plane words: chunk id of the flat batch, relative to the first chunk of its first pixel's agent
+            total_chunks = (B * px + 255) // 256
+            ids = np.unique(np.concatenate([np.arange(min(total_chunks, 4096)), np.arange(max(0, total_chunks - 4096), total_chunks),
+                                            ((np.arange(1, B + 1) * px - 1) // 256)]))       # every agent's last chunk
+            a0 = np.minimum((256 * ids) // px, B - 1)
+            rel = ids - (a0 * px) // 256
+            assert (rel >= 0).all()
+            assert (rel * 8 + 8 <= PW).all(), (H, W, pu, B, int(rel.max()), PW)       # inside the agent's own region
+            assert int((a0 * PW + rel * 8 + 8).max()) <= plane_alloc_words
+            # the following agent's first eight words (clamped to the last agent)
+            assert min(B - 1, int(a0.max()) + 1) * PW + 8 <= plane_alloc_words
+
+
 # ---- DeviceArray / stream ownership: host logic of single_room.py that needs no GPU ----------------------------
 class _HiddenRefTensor:
     """Stands in for the tensor `torch.as_tensor(exporter)` makes: it keeps the exporting object alive through a
@@ -398,3 +433,72 @@ def test_device_array_host_protocol(rcw):
         r += 1                                      # engine memory is not the host's to write
     with pytest.raises(TypeError):
         np.add(total, 1, out=r)
+
+
+# ---- the `rng` keyword (SR:49,265): draws on the host in the reference's order ---------------------------------
+class _ScriptedRng:
+    """A generator whose draws are scripted and whose calls are logged: what `reference_reset_draws` asks for, in order."""
+
+    def __init__(self, values):
+        self.values, self.calls = list(values), []
+
+    def integers(self, lo, hi):
+        self.calls.append((lo, hi))
+        v = self.values.pop(0)
+        assert lo <= v < hi, (lo, v, hi)
+        return v
+
+
+def test_reference_reset_draws_follow_the_reference_order(rcw):
+    """reset!(world) SR:110-137 + sample_empty_position UT:23-37, draw by draw: goal row, goal column, then ONE linear
+    index per position trial — drawn again exactly while the tile is a wall or the new goal — then the heading."""
+    draws = rcw.SingleRoomModule.reference_reset_draws
+    H, W, nd = 8, 16, 128
+    lin = lambda i, j: (i - 1) + H * (j - 1)
+    # goal (3, 7); first trial a wall of the left column (5, 1), second the goal tile itself, third a wall of the bottom row, fourth free
+    rng = _ScriptedRng([3, 7, lin(5, 1), lin(3, 7), lin(8, 4), lin(6, 12), 77])
+    assert draws(rng, H, W, nd) == (3, 7, 6, 12, 77)
+    assert rng.calls == [(2, H), (2, W), (0, H * W), (0, H * W), (0, H * W), (0, H * W), (0, nd)] and not rng.values
+    # a free tile at once: exactly four draws; the OLD goal tile is free again (reset! clears it before drawing, SR:118)
+    rng = _ScriptedRng([7, 15, lin(3, 7), 0])
+    assert draws(rng, H, W, nd) == (7, 15, 3, 7, 0)
+    assert rng.calls == [(2, H), (2, W), (0, H * W), (0, nd)]
+    # every interior tile but the goal is reachable, none of the ring: distribution check with a real generator
+    g = np.random.default_rng(1)
+    seen = set()
+    for _ in range(4000):
+        gi, gj, ti, tj, d = draws(g, 5, 6, 4)
+        assert 2 <= gi <= 4 and 2 <= gj <= 5 and 2 <= ti <= 4 and 2 <= tj <= 5 and (ti, tj) != (gi, gj) and 0 <= d < 4
+        seen.add((gi, gj, ti, tj))
+    assert len(seen) == 12 * 11
+
+
+def test_reset_from_rng_injects_the_draws(rcw):
+    """reset_(env, rng=...): one generator serves the agents in order (B reference worlds sharing it), a list serves agent
+    a from rng[a]; masked-out agents draw nothing; construction draws twice per agent (SR:62-74, then SR:105 -> reset!)."""
+    SR = rcw.SingleRoomModule
+    captured = {}
+
+    class Env:
+        batch, T = 3, np.float32
+
+        class cfg:
+            height_tile_map_tu, width_tile_map_tu, num_directions = 8, 8, 128
+
+        def set_state(self, goal, pos, head, mask=None):
+            captured.update(goal=goal.copy(), pos=pos.copy(), head=head.copy(), mask=None if mask is None else mask.copy())
+
+    lin = lambda i, j: (i - 1) + 8 * (j - 1)
+    one = _ScriptedRng([2, 2, lin(4, 4), 1,   3, 3, lin(5, 5), 2,   4, 4, lin(6, 6), 3])
+    SR._reset_from_rng(Env(), one, None)
+    assert captured["goal"].tolist() == [[2, 2], [3, 3], [4, 4]] and captured["head"].tolist() == [1, 2, 3]
+    assert captured["pos"].tolist() == [[3.5, 3.5], [4.5, 4.5], [5.5, 5.5]] and captured["pos"].dtype == np.float32
+    per = [_ScriptedRng([2, 2, lin(4, 4), 1]), _ScriptedRng([]), _ScriptedRng([4, 4, lin(6, 6), 3])]
+    SR._reset_from_rng(Env(), per, np.array([1, 0, 1], np.uint8))
+    assert captured["mask"].tolist() == [1, 0, 1] and captured["goal"][[0, 2]].tolist() == [[2, 2], [4, 4]]
+    assert all(not g.values for g in per) and per[1].calls == []
+    twice = _ScriptedRng([7, 7, lin(2, 2), 9, 2, 2, lin(4, 4), 1] * 3)
+    SR._reset_from_rng(Env(), twice, None, construction=True)
+    assert not twice.values and captured["goal"].tolist() == [[2, 2]] * 3 and captured["head"].tolist() == [1, 1, 1]
+    with pytest.raises(ValueError):
+        SR._reset_from_rng(Env(), [one, one], None)

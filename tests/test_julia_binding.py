@@ -154,3 +154,20 @@ def test_config_struct_mirror():
         off = (off + size[t] - 1) // size[t] * size[t] + size[t] * n
     assert off == 160
     assert re.search(r"const RCW_ABI_VERSION = (\d+)", jl).group(1) == re.search(r"#define RCW_ABI_VERSION (\d+)", text).group(1)
+
+
+def test_rng_keyword_draws_in_the_reference_order():
+    """The `rng` keyword (src/single_room.jl:49,265) of the binding: constructor and reset! take it, and reset_from_rng!
+    makes the reference's draws with the reference's own statements in the reference's order — goal row, goal column,
+    RCW.sample_empty_position on a host tile map that holds the wall ring and the NEW goal, heading — before ONE set_state!."""
+    text = open(BINDING).read()
+    assert re.search(r"function BatchedSingleRoom\(batch::Integer;[^)]*\brng = nothing", text)
+    assert re.search(r"function RCW\.reset!\(env::BatchedSingleRoom;[^)]*\brng = env\.rng", text)
+    body = text[text.index("function reset_from_rng!"):]
+    body = body[:body.index("\nend\n")]
+    order = [body.index(k) for k in ("rand(g, 2 : H - 1), rand(g, 2 : W - 1)", "tile_map[2, goal_position] = true",
+                                     "RCW.sample_empty_position(g, tile_map)", "rand(g, 0 : nd - 1)", "set_state!(env, goal, position, direction")]
+    assert order == sorted(order)
+    assert "tile_map[1, :, 1] .= true" in body and "construction ? (1, 2) : (2,)" in body      # wall ring; the constructor draws twice
+    fixtures = open(os.path.join(ROOT, "julia", "make_reference_fixtures.jl")).read()
+    assert "Random.MersenneTwister(1)" in fixtures and "rng = rng" in fixtures and "RCW.reset!(env)" in fixtures

@@ -93,6 +93,64 @@ def _report(table):
     return "\n".join(lines)
 
 
+# ---- the seeded case: SingleRoom(; rng = MersenneTwister(1)), two reset!(env) in a 64-step rollout -----------------------
+SEEDED_CFG = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+
+
+class OracleSeeded:
+    def __init__(self, O, directions=None, **sw):
+        self.orc = O.OracleBatch(1, render_top_view=1, **SEEDED_CFG, **sw)
+        if directions is not None:
+            self.orc.set_direction_table(directions)
+
+    def set_state(self, goal, pos, d):
+        self.orc.set_state([goal], [pos], [d])
+
+    def step(self, a):
+        rc = self.orc.step([a])
+        return rc if rc else int(self.orc.status[0])
+
+    def state(self):
+        o = self.orc
+        return o.position[0], o.direction[0], o.reward[0], o.done[0], o.goal[0]
+
+    def camera_view(self):
+        return self.orc.camera_view[0].copy()
+
+    def top_view(self):
+        return self.orc.top_view[0].copy()
+
+
+class HipSeeded:
+    def __init__(self, rcw, directions=None, **sw):
+        self.rcw = rcw
+        self.env = rcw.SingleRoomModule.SingleRoom(batch=1, render_top_view=True, **SEEDED_CFG, **sw)
+        if directions is not None:
+            self.env.set_direction_table(directions)
+
+    def set_state(self, goal, pos, d):
+        self.env.set_state([goal], [pos], [d])
+
+    def step(self, a):
+        self.rcw.act_(self.env, a)
+        try:
+            self.env.sync()
+            return 0
+        except IndexError:
+            self.env.clear_error()
+            return -5
+
+    def state(self):
+        w = self.env.world
+        return w.player_position_wu[0], w.player_direction_au[0], w.reward[0], w.done[0], w.goal_position[0]
+
+    def camera_view(self):
+        return self.env.camera_view_host()[0]
+
+    def top_view(self):
+        return self.env.top_view_host()[0]
+
+
 # ---- the pinning tests proper (need the Julia-made files) ---------------------------------------------------
 @NEED
 def test_reference_pins_the_oracle(oracle):
@@ -108,6 +166,10 @@ def test_reference_pins_the_oracle(oracle):
     theirs = RP.directions_from_bits(refs[0])
     assert np.array_equal(ours.view(np.uint32), theirs.view(np.uint32)), \
         "Julia's cos/sin table differs from the C library's in the last bit: hand it over with rcw_set_direction_table"
+    seeded = RP.read_seeded(REF_DIR)
+    if seeded is not None:                              # (fixtures made since round 4 hold it)
+        bad = RP.replay_seeded(seeded, OracleSeeded(oracle, RP.directions_from_bits(seeded)))
+        assert not bad, f"the seeded rollout with two reset!(env) differs from RayCastWorlds.jl in: {bad}"
 
 
 @NEED
@@ -116,6 +178,10 @@ def test_reference_pins_the_hip_path(rcw):
     refs = RP.read_manifest(REF_DIR)
     table = RP.judge(refs, BY_NAME, hip_run(rcw))
     assert not table[(0, 0, 0)], "HIP path vs RayCastWorlds.jl:\n" + _report(table)
+    seeded = RP.read_seeded(REF_DIR)
+    if seeded is not None:
+        bad = RP.replay_seeded(seeded, HipSeeded(rcw, RP.directions_from_bits(seeded)))
+        assert not bad, f"HIP path: the seeded rollout with two reset!(env) differs from RayCastWorlds.jl in: {bad}"
 
 
 # ---- self-test of the kit (runs everywhere): same file format, written from the oracle under a known setting ----
@@ -159,3 +225,66 @@ def test_kit_identifies_a_known_setting(oracle, tmp_path, truth):
     table = RP.judge(refs, BY_NAME, run)
     matching = [s for s, f in table.items() if not f]
     assert matching == [truth], _report(table)          # the discriminators leave exactly one setting standing
+
+
+def _write_seeded_like_the_julia_script(directory, backend_factory, rcw_draws, rng):
+    """The seeded case's file as julia/make_reference_fixtures.jl::seeded_case writes it, from a backend — with a numpy
+    generator standing in for MersenneTwister(1) (the draws are in the file, so the stream itself is immaterial)."""
+    H, W, N, nd = 8, 8, 64, 128
+    b = backend_factory()
+    j = lambda a: " ".join(str(int(v)) for v in np.asarray(a).reshape(-1))      # noqa: E731
+
+    def reset(construction=False):
+        if construction:
+            rcw_draws(rng, H, W, nd)
+        gi, gj, ti, tj, d = rcw_draws(rng, H, W, nd)
+        pos = np.array([ti - 0.5, tj - 0.5], dtype=np.float32)
+        b.set_state([gi, gj], pos, d)
+        return [gi, gj] + pos.view(np.uint32).tolist() + [d]
+
+    states = [reset(construction=True)]
+    name = RP.SEEDED_NAME
+    b.camera_view().astype("<u4").tofile(os.path.join(directory, name + ".camera_view.u32"))
+    b.top_view().astype("<u4").tofile(os.path.join(directory, name + ".top_view.u32"))
+    actions = RP.lcg_actions(64, seed=7)
+    pos, dirs, rew, done, goals, error_step = [], [], [], [], [], 0
+    for k, a in enumerate(actions, start=1):
+        if k in (20, 45):
+            states.append(reset())
+        if b.step(a) != 0:
+            error_step = k
+            break
+        p, d, r, dn, g = b.state()
+        pos += np.asarray(p, dtype=np.float32).view(np.uint32).tolist()
+        dirs.append(int(d)); rew.append(int(np.float32(r).view(np.uint32))); done.append(int(dn)); goals += [int(g[0]), int(g[1])]
+    with open(os.path.join(directory, name + ".txt"), "w") as f:
+        f.write(f"name {name}\nversions self-test\nrng a numpy generator standing in\nshape {H} {W} {N} {nd} 256 {H * 32} {W * 32}\n")
+        f.write("directions_wu_bits 0\nreset_steps 20 45\n")
+        f.write("reset_states " + j(states) + "\nrollout_actions " + j(actions) + f"\nrollout_error_step {error_step}\n")
+        f.write("rollout_position_bits " + j(pos) + "\nrollout_direction_au " + j(dirs) + "\nrollout_reward_bits " + j(rew) + "\n")
+        f.write("rollout_done " + j(done) + "\nrollout_goal " + j(goals) + "\n")
+    b.camera_view().astype("<u4").tofile(os.path.join(directory, name + ".camera_view_after_rollout.u32"))
+
+
+def test_kit_replays_the_seeded_case(rcw, oracle, tmp_path):
+    """Self-test of the seeded case's reader and replay (the format julia/make_reference_fixtures.jl::seeded_case writes):
+    written from the oracle it replays clean on the oracle; a tampered post-reset state and a dropped reset both show."""
+    draws = rcw.SingleRoomModule.reference_reset_draws
+    _write_seeded_like_the_julia_script(str(tmp_path), lambda: OracleSeeded(oracle), draws, np.random.default_rng(1))
+    ref = RP.read_seeded(str(tmp_path))
+    assert ref is not None and ref["reset_states"].shape == (3, 5) and len(ref["rollout_direction_au"]) + (ref["rollout_error_step"] > 0) >= 1
+    assert RP.replay_seeded(ref, OracleSeeded(oracle)) == []
+    tampered = dict(ref, reset_states=ref["reset_states"].copy())
+    tampered["reset_states"][1, 4] = (tampered["reset_states"][1, 4] + 1) % 128          # the heading after the first reset!
+    assert RP.replay_seeded(tampered, OracleSeeded(oracle)) != []
+    dropped = dict(ref, reset_steps=ref["reset_steps"][:1], reset_states=ref["reset_states"][:2])
+    assert RP.replay_seeded(dropped, OracleSeeded(oracle)) != []
+    assert RP.read_seeded(str(tmp_path / "nowhere")) is None
+
+
+@pytest.mark.gpu
+def test_hip_replays_the_seeded_case(rcw, oracle, tmp_path):
+    """The same file, replayed on the HIP path through the C ABI (rcw_set_state where the reference called reset!)."""
+    draws = rcw.SingleRoomModule.reference_reset_draws
+    _write_seeded_like_the_julia_script(str(tmp_path), lambda: OracleSeeded(oracle), draws, np.random.default_rng(1))
+    assert RP.replay_seeded(RP.read_seeded(str(tmp_path)), HipSeeded(rcw)) == []
