@@ -362,11 +362,12 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     d.top_unit_px = unit ? unit : 256;
     d.top_flat = unit ? 0 : flat;
     d.top_plane_words = d.top_flat ? rcw_top_plane_words(d) : 0;
-    // ... where the batch is big enough to pay for its two extra launches and the side-stream fork / join (≈ 13 µs a step:
-    // with 8×8 tiles of 32 px, 1 / 256 / 1024 / 4096 agents take 51 / 62 / 102 / 340 µs a step against 37 / 49 / 104 / 387 in
-    // the one-kernel form): from 256 MiB of top view a step.
+    // ... at every batch size where a step's camera fill and the drawing go in ONE launch (rcw_fill256_draw_kernel: 8×8 tiles of
+    // 32 px, 1 / 16 / 64 / 256 / 1024 / 4096 agents: 21 / 28 / 30 / 38 / 91 / 330 µs a step against 36 / 38 / 41 / 47 / 103 / 387 in the
+    // one-kernel form); where the drawing needs the side stream (another camera height, planes beyond 64 KiB, runs of agents), only
+    // where the batch is big enough to pay for the fork / join and the extra launch (≈ 13 µs a step: 39 / 51 / 53 / 60 / 102 / 341 µs):
+    // from 256 MiB of top view a step.  (Decided below, when the draw kernel's block and the runs are known.)
     d.top_split = eligible ? 1 : 0;
-    if (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) d.top_split = 0;
     if (want_form == RCW_TOP_VIEW_ONE_KERNEL || want_form == RCW_TOP_VIEW_IN_PLACE) d.top_split = 0;
     if (want_form == RCW_TOP_VIEW_TWO_KERNELS) {
         if (eligible) d.top_split = 1;
@@ -397,6 +398,10 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     // 256-thread draw workgroup): no side stream in the step
     d.top_fused = rcw_fill_draw_fusable(d) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_FUSED")) d.top_fused = d.top_fused && std::atoi(v) ? 1 : 0;
+    if (d.top_split && !d.top_fused && want_form != RCW_TOP_VIEW_TWO_KERNELS &&
+        B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) {
+        d.top_split = 0; d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; d.top_alone_split = 0;
+    }
     if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
     if (d.top_split) {
         hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));

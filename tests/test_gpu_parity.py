@@ -745,18 +745,27 @@ def test_masked_render_right_after_a_change_of_form(rcw, oracle):
 
 
 def test_top_view_form_of_other_geometries(rcw):
-    """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form — and so
-    does a batch too small to pay for two more launches and a stream fork / join (below 256 MiB of top view a step),
-    unless rcw_set_top_view_form asks for it; a form the geometry cannot take is refused and the handle stays usable."""
+    """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form.  Where a step's
+    camera fill and the drawing go in one launch (256-row camera view, planes of a 256-thread draw workgroup) the two-kernel
+    form is taken at EVERY batch size (round 4); where the drawing needs the side stream — here: a 128-row camera view —, only
+    from 256 MiB of top view a step, unless rcw_set_top_view_form asks for it; a form the geometry cannot take is refused and
+    the handle stays usable."""
     from raycastworlds_jl_amd import _capi
 
-    env = rcw.SingleRoomModule.SingleRoom(batch=512, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)     # 128 MiB
+    for batch in (1, 512, 1024):                                            # 0.25 / 128 / 256 MiB: the fused launch at every size
+        env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)
+        assert env.top_view_form() == "two-kernels"
+        env.set_top_view_form("one-kernel"); assert env.top_view_form() == "one-kernel"
+        env.set_top_view_form(None); assert env.top_view_form() == "two-kernels"
+        env.close()
+    env = rcw.SingleRoomModule.SingleRoom(batch=512, seed=1, render_top_view=True, pu_per_tu=32, height_camera_view_pu=128, **CFG2)   # 128 MiB, side stream
     assert env.top_view_form() == "one-kernel"
+    env.set_top_view_form("two-kernels"); assert env.top_view_form() == "two-kernels"
+    rcw.act_(env, 1); env.sync()
+    env.set_top_view_form(None); assert env.top_view_form() == "one-kernel"
     env.close()
-    env = rcw.SingleRoomModule.SingleRoom(batch=1024, seed=1, render_top_view=True, pu_per_tu=32, **CFG2)    # 256 MiB
+    env = rcw.SingleRoomModule.SingleRoom(batch=1024, seed=1, render_top_view=True, pu_per_tu=32, height_camera_view_pu=128, **CFG2)  # 256 MiB
     assert env.top_view_form() == "two-kernels"
-    env.set_top_view_form("one-kernel"); assert env.top_view_form() == "one-kernel"
-    env.set_top_view_form(None); assert env.top_view_form() == "two-kernels"
     env.close()
     for kw, form in ((dict(pu_per_tu=10, **CFG2), "two-kernels"),                     # 10 does not divide 256: the flat store kernel
                      (dict(pu_per_tu=12, height_tile_map_tu=16, width_tile_map_tu=8), "two-kernels"),   # 192 rows of 12-pixel tiles

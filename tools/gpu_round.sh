@@ -16,7 +16,7 @@ if [ "$2" != "notests" ]; then
 fi
 timeout -k 10 300 python bench.py --api rlbase > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; rc=$?; cut -c1-160 gpurun_out/${tag}_bench.json; stop_if_killed $rc bench
 (cd $R && timeout -k 10 300 python bench.py --no-cpu-baseline --top-view --steps 100 --warmup 10 > gpurun_out/${tag}_top_bench.json 2> gpurun_out/${tag}_top_bench.err); rc=$?; stop_if_killed $rc top_bench
-rm -rf gpurun_out/${tag}_top_pmc_fetch gpurun_out/${tag}_top_ring_stats gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_top_stats gpurun_out/${tag}_top_pmc_write gpurun_out/${tag}_cfg5_*
+rm -rf gpurun_out/${tag}_top_pmc_fetch gpurun_out/${tag}_top_side_stats gpurun_out/${tag}_top_ring_stats gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_top_stats gpurun_out/${tag}_top_pmc_write gpurun_out/${tag}_cfg5_*
 cd /tmp
 prof() {  # prof <outdir> <log> <rocprof args...> -- <bench args...>
   local out=$1 log=$2; shift 2
@@ -32,10 +32,12 @@ prof ${tag}_pmc_fetch ${tag}_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --
 prof ${tag}_top_stats ${tag}_top_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
 prof ${tag}_top_pmc_write ${tag}_top_pmc_write.log --pmc WRITE_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
 prof ${tag}_top_pmc_fetch ${tag}_top_pmc_fetch.log --pmc FETCH_SIZE --kernel-trace -- --top-view --steps 20 --warmup 2
+RCW_LIBRARY=$DEVLIB RCW_TOP_FUSED=0 prof ${tag}_top_side_stats ${tag}_top_side_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
+(cd $R && RCW_LIBRARY=$DEVLIB RCW_TOP_FUSED=0 timeout -k 10 300 python bench.py --no-cpu-baseline --top-view --steps 100 --warmup 10 > gpurun_out/${tag}_top_side_bench.json 2> /dev/null)
 RCW_LIBRARY=$DEVLIB RCW_TOP_SPLIT=0 prof ${tag}_top_ring_stats ${tag}_top_ring_stats.log --kernel-trace --stats -- --top-view --steps 60 --warmup 5
 prof ${tag}_top_pmc_sq ${tag}_top_pmc_sq.log --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -- --top-view --steps 20 --warmup 2
 # --- cast kernel at cfg-5 (32x32 map, 1024 columns: 60-step rays), exec-masked march vs ballot-bounded march
-export RCW_LIBRARY=$DEVLIB          # (the measured-and-rejected variants live in the development build only; both marches from it)
+export RCW_LIBRARY=$DEVLIB RCW_CAST_KERNEL=r3   # (the measured-and-rejected variants live in the development build only, in the round-3 kernel: both legs from it)
 for march in exec ballot; do
   export RCW_CAST_MARCH=$march
   prof ${tag}_cfg5_${march}_stats ${tag}_cfg5_${march}_stats.log --kernel-trace --stats -- --workload cfg5 --steps 30 --warmup 3
@@ -48,7 +50,7 @@ for w in cfg2 cfg5; do
   RCW_CAST_TABLE=lds prof ${tag}_${w}_tablelds_stats ${tag}_${w}_tablelds_stats.log --kernel-trace --stats -- --workload $w --steps 30 --warmup 3
   prof ${tag}_${w}_tablel2_stats ${tag}_${w}_tablel2_stats.log --kernel-trace --stats -- --workload $w --steps 30 --warmup 3
 done
-unset RCW_LIBRARY
+unset RCW_LIBRARY RCW_CAST_KERNEL
 cd $R
 # --- the flat kernels (any camera height / any top-view pixel scale): per-kernel times by rocprofv3 on their shapes, bytes written
 export TOPSHAPES_STEPS=60
@@ -69,6 +71,7 @@ python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_fetch FETCH_SIZE | tee gpurun
 python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_write WRITE_SIZE | tee gpurun_out/${tag}_top_write.txt
 python3 tools/pmc_summary.py gpurun_out/${tag}_top_pmc_fetch FETCH_SIZE rcw_top | tee gpurun_out/${tag}_top_fetch.txt
 cp gpurun_out/${tag}_top_ring_stats/*/*_kernel_stats.csv gpurun_out/${tag}_top_ring_kernel_stats.csv
+cp gpurun_out/${tag}_top_side_stats/*/*_kernel_stats.csv gpurun_out/${tag}_top_side_kernel_stats.csv
 cp gpurun_out/${tag}_stats/*/*_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
 cp gpurun_out/${tag}_top_stats/*/*_kernel_stats.csv gpurun_out/${tag}_top_kernel_stats.csv
 for march in exec ballot; do cp gpurun_out/${tag}_cfg5_${march}_stats/*/*_kernel_stats.csv gpurun_out/${tag}_cfg5_${march}_kernel_stats.csv; done

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): step latency at small batches without / with the top view, in its two-kernel and one-kernel forms
-(what the 256 MiB rule in rcw_create is based on)."""
+(what rcw_create's rule for the two-kernel form's smallest batch is based on).  With RCW_LIBRARY = the development build and
+RCW_TOP_FUSED=0 the two-kernel form goes over the side stream again instead of the fused fill + draw launch."""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch
 import raycastworlds_jl_amd as RCW
 CFG2 = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=256)
-for B in (1, 64, 256, 1024):
+for B in (1, 16, 64, 256, 1024):
     for top in (False, True):
         for split in ("1", "0") if top else ("1",):
             env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, render_top_view=top, **CFG2)

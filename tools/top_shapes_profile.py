@@ -7,7 +7,7 @@ import sys
 
 tag = sys.argv[1]
 out = [f"""update_top_view! (SR:446-483) over map / pixel-scale shapes (tools/top_view_shapes.py), 1 MI355X, round {int(tag[1:])}.  ~1 GiB of top view per
-launch (16,384 agents at most).  Two measurements of the same runs:
+launch (65,536 agents at most; round 3 capped the batch at 16,384, i.e. 0.4-0.7 GiB for images of 80-104 px).  Two measurements of the same runs:
   (a) rocprofv3 --kernel-trace --stats per shape (tools/kprof.sh): the kernels' own average / minimum durations over 60 steps,
       and the store kernel's bandwidth on the algorithmic bytes 4*(H*pu)*(W*pu)*B against the 8 TB/s HBM peak;
   (b) HIP events on the handle's stream: the top view's time INSIDE a step (the store kernel incl. the wait for the draw
@@ -24,7 +24,7 @@ for line in open(f"gpurun_out/{tag}_top_shapes_kernels.txt"):
     H, W, pu, N = (int(m.group(k)) for k in range(1, 5))
     name, avg, mn = m.group(5), float(m.group(6)), float(m.group(7))
     px = H * pu * W * pu
-    B = max(64, min(16384, (1 << 30) // (4 * px)))
+    B = max(64, min(65536, (1 << 30) // (4 * px)))
     row = f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d}  {name:46s} avg {avg:7.1f}  min {mn:7.1f}"
     if "store" in name:
         by = 4 * px * B
