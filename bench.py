@@ -95,6 +95,60 @@ def cpu_baseline(kw, batch_hint, target_seconds=10.0):
     }
 
 
+def parse_pmc(directory, counter, kernel_substring):
+    """Mean of `counter` per dispatch of the kernels whose name contains `kernel_substring`, from the *counter_collection.csv of a
+    rocprofv3 --pmc run (rows are per XCD: summed per dispatch first).  None when nothing matches."""
+    import csv
+    import glob
+    from collections import defaultdict
+
+    per = defaultdict(float)
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") == counter and kernel_substring in r.get("Kernel_Name", ""):
+                    per[(f, r["Dispatch_Id"])] += float(r["Counter_Value"])
+    return sum(per.values()) / len(per) if per else None
+
+
+def being_profiled() -> bool:
+    """This process already runs under a profiler (tools/kstats.sh, tools/gpu_round.sh wrap bench.py in rocprofv3): no nested one."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def live_traffic(workload, batch, kernel, seconds=150.0):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: this script again, a few steps, under
+    rocprofv3 — WRITE_SIZE and FETCH_SIZE in separate passes (they do not fit one), `--pmc` with `--kernel-trace` only, as the
+    guide's HBM section prescribes; KiB units; FETCH_SIZE doubled (gfx950 reports half of wide streaming reads: an upper bound
+    for this kernel's narrow descriptor gathers).  Child processes, outside every timed region; None if the profiler is not
+    there or a pass fails — the caller then falls back to the committed figure and says so."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None or being_profiled():
+        return None
+    out = {}
+    for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+        d = tempfile.mkdtemp(prefix="rcw_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--traffic", "off",
+                   "--workload", workload, "--batch", str(batch)]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            env["TMPDIR"] = "/tmp"
+            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=seconds)
+            v = parse_pmc(d, counter, kernel) if res.returncode == 0 else None
+        except Exception:   # noqa: BLE001 — a reported extra: never costs the bench line
+            v = None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        if v is None:
+            return None
+        out[counter] = v * 1024.0                        # KiB -> bytes
+    return {"write_bytes": out["WRITE_SIZE"], "fetch_bytes_raw": out["FETCH_SIZE"], "traffic": out["WRITE_SIZE"] + 2.0 * out["FETCH_SIZE"]}
+
+
 def make_watchdog(rank, emit, headline_ready, pending, seconds, exit_fn=os._exit, err=None):
     """What runs when the optional gather has not finished `seconds` after it began (a rank that died or hangs inside a
     collective leaves the others waiting for ever).  The bench line must still go out — rank 0 writes the headline it
@@ -121,6 +175,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="agents per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", default="live", choices=["live", "committed", "off"],
+                    help="roofline.traffic (HBM bytes per launch of the dominant kernel, PMC counters): live = measured by this run (rank 0 "
+                         "at N = 1: two short rocprofv3 --pmc passes of this script as child processes, after the timed region; falls back to "
+                         "the committed figure if the profiler is not available), committed = profiles/pmc_traffic.json, off = null")
     ap.add_argument("--no-auto-reset", action="store_true")
     ap.add_argument("--top-view", action="store_true",
                     help="also render the reference's top view every step (update_top_view! SR:446-483, opt-in in the "
@@ -305,16 +363,24 @@ def main():
         achieved = bytes_per_launch / fill_s / 1e9
         step_s = kernel_ms / 1e3 / args.steps             # cast + fill, events around the region
         step_achieved = bytes_per_launch / step_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    t = json.load(f)
-                if t.get("workload") == args.workload and t.get("batch") == B:
-                    traffic = t.get("traffic_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = None, None
+        if traffic_live is not None:
+            traffic = traffic_live["traffic"]
+            traffic_source = (f"measured by this run: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes, --kernel-trace only) over 8 steps of "
+                              f"this command; WRITE_SIZE {traffic_live['write_bytes']:.0f} B + 2 x FETCH_SIZE {traffic_live['fetch_bytes_raw']:.0f} B "
+                              f"(gfx950 FETCH correction, an upper bound for narrow gathers) per launch of {fill_kernel}")
+        elif args.traffic != "off":
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    with open(tpath) as f:
+                        t = json.load(f)
+                    if t.get("workload") == args.workload and t.get("batch") == B:
+                        traffic = t.get("traffic_bytes_per_launch")
+                        traffic_source = ("profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE of the fill kernel from separate rocprofv3 --pmc "
+                                          "passes of this command, committed; not re-measured in this run")
+                except Exception:
+                    traffic = None
         out = {
             "metric": "env-steps/sec (whole node) + frames/sec, SingleRoom batch=4096 cols=256",
             "value": world * B * args.steps / dt,
@@ -346,9 +412,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": ("profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE of the fill kernel from separate "
-                                   "rocprofv3 --pmc passes of this command, committed; not re-measured in this run"
-                                   if traffic is not None else None),
+                "traffic_source": traffic_source,
                 "kernel": fill_kernel,
                 "bytes_per_launch": bytes_per_launch,
                 "launch_ms": fill_ms,
@@ -385,6 +449,7 @@ def main():
         return out
 
     gather = None
+    traffic_live = None
     headline_ready = {"line": None}
     pending = {"what": "nothing yet"}
 
@@ -477,6 +542,8 @@ def main():
         pending["what"] = "nothing (the gather is over)"
 
     if rank == 0:
+        if world == 1 and args.traffic == "live" and not args.top_view:
+            traffic_live = live_traffic(args.workload, B, fill_kernel)
         out = build_line(gather)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, B)

@@ -755,11 +755,12 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     // with two a lane, 256 columns 12.3 vs 12.7; 1024 columns take 256 lanes either way), two a lane for small batches, where
     // an agent's own latency is what counts
     { const int lanes = h->B >= 1024 ? (N + 3) / 4 : (N + 1) / 2; d.cast_block = lanes >= 256 ? 256 : ((lanes + 63) / 64) * 64; }
-    d.cast_ballot = 0; d.cast_table_lds = 0; d.cast_r3 = 0; d.top_debug = 0;
+    d.cast_ballot = 0; d.cast_table_lds = 0; d.cast_r3 = 0; d.cast_waves = 0; d.top_debug = 0;
     // development builds (make dev: -DRCW_DEV_SWITCHES -> librcw_hip_dev.so) read tuning knobs and the measured-and-rejected
     // kernel variants from the environment; the shipped library reads nothing but RCW_RCCL_LIBRARY
     if (const char* v = RCW_DEV_ENV("RCW_CAST_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 192 || b == 256) d.cast_block = b; }
     if (const char* v = RCW_DEV_ENV("RCW_CAST_KERNEL")) d.cast_r3 = std::strcmp(v, "r3") == 0 ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_CAST_WAVES")) d.cast_waves = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_CAST_MARCH")) d.cast_ballot = std::strcmp(v, "ballot") == 0 ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_CAST_TABLE"))   // only where tile bytes + 5 N table values fit the default 64 KiB
         d.cast_table_lds = std::strcmp(v, "lds") == 0 && rcw_step_lds_bytes(d) + 2 * (size_t)H + (size_t)RCW_TABLE_ROWS * N * h->real_size + 128 <= 64 * 1024 ? 1 : 0;

@@ -34,6 +34,7 @@ struct RcwDev {
     int32_t cast_block;      // threads per agent in the cast kernel (multiple of 64, <= 256)
     int32_t cast_ballot;     // development only (RCW_CAST_MARCH=ballot): the ballot-bounded march instead of the exec-masked one
     int32_t cast_table_lds;  // development only (RCW_CAST_TABLE=lds): stage the heading's ray-table slice in LDS first
+    int32_t cast_waves;      // development only (RCW_CAST_WAVES=1): the cast kernel with a wavefront per agent, four agents a workgroup — measured, rejected
     int32_t cast_r3;         // development only (RCW_CAST_KERNEL=r3): the round-3 cast kernel (five dependent round trips), for the comparison
     int64_t agent_id_offset;
     uint64_t seed;

@@ -582,7 +582,7 @@ extern "C" __attribute__((visibility("default"))) int rcw_cast_trace_read(unsign
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cast_trace), sizeof(unsigned long long) * 4096 * 10);
 }
 namespace {
-#define RCW_CAST_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) g_cast_trace[blockIdx.x * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RCW_CAST_STAMP(k) do { if (tid == 0 && trace_slot < 4096) g_cast_trace[trace_slot * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RCW_CAST_STAMP(k) do { } while (0)
 #endif
@@ -607,15 +607,23 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
     return r.oob;
 }
 
-template <typename T, bool TIE_LE, bool DIST_PRE>
-__global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
-                                                          const uint8_t* __restrict__ actions,
-                                                          const uint8_t* __restrict__ mask, int first)
+// The lanes of ONE agent wait for each other's LDS writes: a workgroup barrier — or, where the agent is a single wavefront
+// (WAVE), nothing but the wavefront's own LDS counter: its LDS operations execute in order.
+template <bool WAVE>
+__device__ __forceinline__ void agent_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
+
+// WAVE = false: the workgroup is one agent (tid = its thread, nthr = blockDim).  WAVE = true (development build only, measured and
+// rejected): 64 lanes are an agent and the workgroup's wavefronts are DIFFERENT agents (rcw_cast_waves_kernel): the same code with
+// tid = the lane, nthr = 64, the wavefront's own slice of LDS, and no workgroup barrier.
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
+__device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
+                                          const int a, const int tid, const int nthr, uint32_t* const lds, const int trace_slot)
+{
     typedef typename Real<T>::vec2 vec2;
-    const int a = first + (int)blockIdx.x;                  // agents [first, first + gridDim.x)
-    const int tid = threadIdx.x, nthr = (int)blockDim.x;
     const int H = p.H, HW = p.H * p.W, N = p.N;
     RCW_CAST_STAMP(0);
 
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
         const uint32_t b = (tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u;
         tb[t] = (uint8_t)(t == HW - 1 ? (b | 1u) : b);
     }
-    __syncthreads();
+    agent_sync<WAVE>();
     RCW_CAST_STAMP(2);
 
     // ---- phase 0: dynamics, computed redundantly by every lane (no broadcast needed) --------
@@ -693,9 +701,9 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
             const Pose<T> np = reset_agent<T>(p, a, tm_hbm, nullptr);
             s_pose[0] = np.x; s_pose[1] = np.y; s_pose_d = np.d;
         }
-        __syncthreads();
+        agent_sync<WAVE>();
         stage_tile_bytes(tb, tm_hbm, HW, tid, nthr);                        // the goal moved
-        __syncthreads();
+        agent_sync<WAVE>();
         x = s_pose[0]; y = s_pose[1];
         d_new = __builtin_amdgcn_readfirstlane(s_pose_d);
         const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
@@ -753,10 +761,10 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
 #ifdef RCW_TRACE_WAVES
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (the descriptor stores acknowledged)
     RCW_CAST_STAMP(7);
-    if (tid == 0 && blockIdx.x < 4096) {
+    if (tid == 0 && trace_slot < 4096) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
-        g_cast_trace[blockIdx.x * 10 + 8] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+        g_cast_trace[trace_slot * 10 + 8] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
     }
 #endif
     if (N > kCastCols * nthr) {                                             // more than kCastCols columns a lane (N > 1024)
@@ -767,6 +775,34 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
     }
     if (left_the_map) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }   // (Julia: BoundsError in cast_ray)
 }
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
+                                                          const uint8_t* __restrict__ actions,
+                                                          const uint8_t* __restrict__ mask, int first)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // agents [first, first + gridDim.x): one workgroup each
+    cast_body<T, TIE_LE, DIST_PRE, false>(p, actions, mask, first + (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, lds, (int)blockIdx.x);
+}
+
+#ifdef RCW_DEV_SWITCHES
+// Development build only (RCW_CAST_WAVES=1), measured and rejected: the same with a WAVEFRONT per agent, four agents a
+// workgroup — a quarter of the workgroups for the dispatcher to hand out, no s_barrier.  The 4096 workgroups of cfg-2 then enter within
+// 0.9 us instead of 1.6, and the kernel takes 11.5 us instead of 11.2 (cfg-4's shard: 20.2 vs 19.3): the wavefronts live longer by what
+// they no longer wait to be dispatched — the SIMDs' issue slots bound the kernel, not the dispatcher.  agents [first, last).
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_cast_waves_kernel(const RcwDev p,
+                                                                const uint8_t* __restrict__ actions,
+                                                                const uint8_t* __restrict__ mask, int first, int last, int lds_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int a = first + (int)blockIdx.x * (kBlock / 64) + wave;
+    if (a >= last) return;                                                  // (wave-uniform: the batch's last workgroup may be short)
+    cast_body<T, TIE_LE, DIST_PRE, true>(p, actions, mask, a, (int)(threadIdx.x & 63u), 64, lds + (size_t)wave * lds_words, a - first);
+}
+#endif   // RCW_DEV_SWITCHES (rcw_cast_waves_kernel)
 
 // ---- kernel 2 of a step: column descriptors -> pixels -------------------------------------
 // The bandwidth kernel: B·N·H_cam·4 bytes, written once.  HBM on MI355X takes writes fastest
@@ -2781,6 +2817,14 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
 #ifdef RCW_DEV_SWITCHES
     if (p.cast_ballot || p.cast_table_lds || p.cast_r3) {                  // the round-3 kernel and its two rejected variants
         RCW_DISPATCH(rcw_cast_kernel_r3, dim3(count), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev, first);
+        return hipGetLastError();
+    }
+#endif
+#ifdef RCW_DEV_SWITCHES
+    if (p.cast_waves && p.cast_block == 64 && count >= 4 * p.fill_grid) {
+        // a wavefront per agent, four agents a workgroup: batches that fill the chip, at most 256 view columns
+        const size_t per_agent = (rcw_cast_lds_bytes(p) + 15) & ~(size_t)15;
+        RCW_DISPATCH(rcw_cast_waves_kernel, dim3((count + 3) / 4), dim3(kBlock), 4 * per_agent, p, actions_dev, mask_dev, first, first + count, (int)(per_agent / 4));
         return hipGetLastError();
     }
 #endif

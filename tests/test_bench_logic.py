@@ -47,3 +47,23 @@ def test_bench_refuses_to_run_without_a_gpu_or_with_a_wrong_world():
     if not torch.cuda.is_available():
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 3 and "no GPU" in res.stderr and res.stdout.strip() == ""
+
+
+def test_pmc_parser_sums_xcds_and_averages_dispatches(tmp_path):
+    """roofline.traffic is measured live (two rocprofv3 --pmc passes of bench.py as child processes): the parser of their
+    *counter_collection.csv — a row per XCD and dispatch — sums a dispatch's rows and averages over the kernel's dispatches."""
+    bench = _bench()
+    d = tmp_path / "run" / "box"
+    d.mkdir(parents=True)
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    fill = '"void (anonymous namespace)::rcw_fill256_kernel<false>(RcwDev, int const*, unsigned char const*, unsigned int __vector(4)*, long long, unsigned char const*)"'
+    cast = '"void (anonymous namespace)::rcw_cast_kernel<float, false, false>(RcwDev, unsigned char const*, unsigned char const*, int)"'
+    for disp, per_xcd in ((1, 131072.0), (2, 131074.0)):
+        for xcd in range(8):
+            rows.append(f"{disp},{disp},4,1,100,100,65536,7,{fill},256,0,0,24,0,48,WRITE_SIZE,{per_xcd},1,2")
+        rows.append(f"{disp + 10},{disp + 10},4,1,100,100,262144,8,{cast},64,112,0,44,0,84,WRITE_SIZE,5.0,1,2")
+    (d / "123_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    assert bench.parse_pmc(str(tmp_path), "WRITE_SIZE", "rcw_fill256_kernel") == (8 * 131072.0 + 8 * 131074.0) / 2
+    assert bench.parse_pmc(str(tmp_path), "WRITE_SIZE", "rcw_cast") == 5.0
+    assert bench.parse_pmc(str(tmp_path), "FETCH_SIZE", "rcw_fill256_kernel") is None
+    assert bench.parse_pmc(str(tmp_path / "nowhere"), "WRITE_SIZE", "rcw_") is None

@@ -16,6 +16,8 @@ if len(sys.argv) > 1:                                    # one shape: H,W,pu,N
 for H, W, pu, N in SHAPES:
     px = H * pu * W * pu
     B = max(64, min(65536, (1 << 30) // (4 * px)))          # ~1 GiB of top view a launch (round 3 capped the batch at 16,384 agents: 0.4-0.7 GiB for the small images)
+    if os.environ.get("TOPSHAPES_BATCH"):                 # development: another batch than ~1 GiB of top view
+        B = int(os.environ["TOPSHAPES_BATCH"])
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
                                           width_tile_map_tu=W, num_rays=N, pu_per_tu=pu, render_top_view=True)
     if os.environ.get("TOPSHAPES_RUNS"):                  # development: the two-kernel form in this many runs of agents
