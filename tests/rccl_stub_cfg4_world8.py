@@ -11,8 +11,8 @@ everything above it — the engine, its frames, rcw_comm_* / rcw_gather_* — is
 Every rank: a few steps under the reference's BoundsError policy, then rcw_gather_columns of the GLOBAL batch (84 MB)
 against the non-rendering CPU oracle of the unsharded batch; rcw_comm_info == (r, 8).  Rank 0 then assembles the
 global OBSERVATION batch (rcw_gather_observations, descriptor transport: 17 GB of frames) while the others take part in
-the same two all-gathers; every frame is checked against the expansion of its descriptors, a sample against the
-rendering oracle.  Prints one JSON line per process."""
+the same two all-gathers; every frame is checked against the expansion of its descriptors AND, pixel for pixel, against the
+rendering oracle given the unsharded states.  Prints one JSON line per process."""
 import ctypes
 import json
 import os
@@ -104,13 +104,14 @@ def main():
                 for a0 in range(0, GLOBAL_BATCH, 512):
                     want = torch_expand(gh[a0:a0 + 512], gc[a0:a0 + 512]).to(torch.int32)
                     assert torch.equal(frames[a0:a0 + 512].view(torch.int32), want), f"global frames {a0}.. differ from their descriptors"
-                srng = np.random.default_rng(5)
-                sample = np.unique(np.concatenate([[0, 1, 8191, 8192, 16383, 16384, 32767, 32768, 57343, 57344, 65534, 65535],
-                                                   srng.choice(GLOBAL_BATCH, 12, replace=False)]))
-                small = O.OracleBatch(len(sample), seed=0, **CFG4)
-                small.set_state(ref.goal[sample], ref.position[sample], ref.direction[sample])
-                got = np.stack([frames[int(i)].cpu().numpy().view(np.uint32) for i in sample])
-                np.testing.assert_array_equal(got, small.camera_view)
+                # ... and EVERY pixel of the gathered global batch against the oracle's own rendering of the unsharded states
+                O.set_num_threads(8)
+                for a0 in range(0, GLOBAL_BATCH, 4096):
+                    small = O.OracleBatch(4096, seed=0, **CFG4)
+                    small.set_state(ref.goal[a0:a0 + 4096], ref.position[a0:a0 + 4096], ref.direction[a0:a0 + 4096])
+                    got = frames[a0:a0 + 4096].cpu().numpy().view(np.uint32)
+                    assert np.array_equal(got, small.camera_view), f"gathered frames of agents {a0}..{a0 + 4096} differ from the oracle's rendering"
+                    small.close()
                 out["global_frames_bytes"] = int(frames.numel()) * 4
                 del frames
             else:
