@@ -297,7 +297,22 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
             rays_seen += int(per_agent.sum())
         assert rays_seen > batch * pu
 
+    def every_pixel():
+        """... and, where the batch's top views are within 4 GiB, EVERY pixel of both images of EVERY agent against the oracle's
+        rendering of the same states (SimpleDraw's rasterisers restated: 2048 agents at a time)."""
+        px = cfg["height_tile_map_tu"] * cfg["width_tile_map_tu"] * pu * pu
+        if 4 * px * batch > (4 << 30):
+            return
+        for a0 in range(0, batch, 2048):
+            n = min(2048, batch - a0)
+            small = oracle.OracleBatch(n, seed=0, render_top_view=1, pu_per_tu=pu, **cfg)
+            small.set_state(orc.goal[a0:a0 + n], orc.position[a0:a0 + n], orc.direction[a0:a0 + n])
+            assert np.array_equal(env.top_view_host(a0, n), small.top_view), f"top views of agents {a0}..{a0 + n} differ from the oracle's"
+            assert np.array_equal(env.camera_view_host(a0, n), small.camera_view), f"camera views of agents {a0}..{a0 + n} differ from the oracle's"
+            small.close()
+
     verify(1)
+    every_pixel()
     # a MASKED reset next (the draw kernel then runs for the masked agents only, the store kernel writes their pixels only —
     # chunk by chunk, per pixel where an image border or a run's border falls inside a chunk), one more step, and the same again
     mask = (rng.random(batch) < 0.4).astype(np.uint8)
@@ -308,6 +323,7 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
     rcw.act_(env, a)
     assert orc.step(a) == 0
     verify(3)
+    every_pixel()
     env.close()
 
 
