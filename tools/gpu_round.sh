@@ -53,13 +53,13 @@ done
 unset RCW_LIBRARY RCW_CAST_KERNEL
 cd $R
 # --- the flat kernels (any camera height / any top-view pixel scale): per-kernel times by rocprofv3 on their shapes, bytes written
-export TOPSHAPES_STEPS=60
+export TOPSHAPES_STEPS=240
 : > gpurun_out/${tag}_top_shapes_kernels.txt; : > gpurun_out/${tag}_top_shapes_steps.txt
 for shape in 8,8,32,256 8,16,32,512 16,16,32,256 8,8,10,256 8,8,12,256 8,8,13,256 8,8,20,256 8,8,24,256 8,16,24,512 16,16,20,256 9,9,32,256 9,12,32,256 12,12,32,256 8,8,16,256 8,8,64,256 24,24,32,256 32,32,32,1024 32,32,8,256; do
   tools/kprof.sh "top_$shape" tools/top_view_shapes.py $shape >> gpurun_out/${tag}_top_shapes_kernels.txt 2>&1 || echo "shape $shape failed"
   grep -h "^map" gpurun_out/kp_top_$shape.log >> gpurun_out/${tag}_top_shapes_steps.txt
 done
-tools/kprof.sh hcam tools/hcam_bench.py > gpurun_out/${tag}_hcam_kernels.txt 2>&1; grep -h "^H_cam" gpurun_out/kp_hcam.log > gpurun_out/${tag}_hcam_steps.txt
+HCAM_STEPS=200 tools/kprof.sh hcam tools/hcam_bench.py > gpurun_out/${tag}_hcam_kernels.txt 2>&1; grep -h "^H_cam" gpurun_out/kp_hcam.log > gpurun_out/${tag}_hcam_steps.txt
 export TMPDIR=/tmp TOPSHAPES_STEPS=12
 for what in "top_view_shapes.py 8,8,24,256" "top_view_shapes.py 8,8,13,256" "hcam_bench.py 100,10486 250,4194"; do
   n=$(echo $what | tr ' ,.' '___'); rm -rf $R/gpurun_out/${tag}_flat_write_$n

@@ -11,7 +11,7 @@ for hc, B in HEIGHTS:
     a = torch.randint(1, 5, (B,), dtype=torch.uint8, device="cuda")
     for _ in range(5): RCW.act_(env, a)
     env.profile(True)
-    for _ in range(50): RCW.act_(env, a)
+    for _ in range(int(os.environ.get("HCAM_STEPS", "50"))): RCW.act_(env, a)
     c, t, f, n = env.profile_read(); env.profile(False)
     by = 4 * hc * 256 * B
     print(f"H_cam {hc:5d} B {B:6d} {env.fill_kernel_name():24s}: fill {f*1e3:7.1f} us  {by / f / 1e6:7.0f} GB/s  ({by / f / 1e6 / 80:.1f} % of 8 TB/s)", flush=True)

@@ -8,7 +8,8 @@ import sys
 tag = sys.argv[1]
 out = [f"""update_top_view! (SR:446-483) over map / pixel-scale shapes (tools/top_view_shapes.py), 1 MI355X, round {int(tag[1:])}.  ~1 GiB of top view per
 launch (65,536 agents at most; round 3 capped the batch at 16,384, i.e. 0.4-0.7 GiB for images of 80-104 px).  Two measurements of the same runs:
-  (a) rocprofv3 --kernel-trace --stats per shape (tools/kprof.sh): the kernels' own average / minimum durations over 60 steps,
+  (a) rocprofv3 --kernel-trace --stats per shape (tools/kprof.sh): the kernels' own average / minimum / median durations over 240 steps (a run's first ten to twenty
+      launches are 5-15 % slower than the rest — clocks —: the median says what a launch takes once they are up),
       and the store kernel's bandwidth on the algorithmic bytes 4*(H*pu)*(W*pu)*B against the 8 TB/s HBM peak;
   (b) HIP events on the handle's stream: the top view's time INSIDE a step (the store kernel incl. the wait for the draw
       kernel's event — what the draw kernel does not hide behind the camera fill shows up here), the camera fill of the same
@@ -16,21 +17,23 @@ launch (65,536 agents at most; round 3 capped the batch at 16,384, i.e. 0.4-0.7 
 Kernels: rcw_top_store_kernel (whole 256-row chunks: pu in {{8..256}} dividing 256, H*pu % 256 == 0), rcw_top_store_flat_kernel
 <STRADDLE, NARROW, K> (any pu >= 9, H*pu % 4 == 0 — 256-pixel chunks of the flat batch, K columns a chunk), rcw_top_draw_kernel.
 
-== (a) per-kernel, rocprofv3 (us: average, minimum)"""]
+== (a) per-kernel, rocprofv3 (us: average, minimum, median)"""]
 for line in open(f"gpurun_out/{tag}_top_shapes_kernels.txt"):
-    m = re.match(r"top_(\d+),(\d+),(\d+),(\d+)\s+(rcw_\S+(?: \S+)*?)\s+calls\s+\d+ avg\s+([\d.]+) us\s+min\s+([\d.]+)", line)
+    m = re.match(r"top_(\d+),(\d+),(\d+),(\d+)\s+(rcw_\S+(?: \S+)*?)\s+calls\s+\d+ avg\s+([\d.]+) us\s+min\s+([\d.]+)(?:\s+p50\s+([\d.]+))?", line)
     if not m:
         continue
     H, W, pu, N = (int(m.group(k)) for k in range(1, 5))
     name, avg, mn = m.group(5), float(m.group(6)), float(m.group(7))
+    p50 = float(m.group(8)) if m.group(8) else None
     px = H * pu * W * pu
     B = max(64, min(65536, (1 << 30) // (4 * px)))
-    row = f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d}  {name:46s} avg {avg:7.1f}  min {mn:7.1f}"
+    row = f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d}  {name:46s} avg {avg:7.1f}  min {mn:7.1f}" + (f"  p50 {p50:7.1f}" if p50 else "")
     if "store" in name:
         by = 4 * px * B
-        row += f"    {by / avg / 1e6:4.2f} TB/s = {by / avg / 1e6 / 8 * 100:4.1f} % (best launch {by / mn / 1e6 / 8 * 100:4.1f} %)"
+        row += (f"    {by / avg / 1e6:4.2f} TB/s = {by / avg / 1e6 / 8 * 100:4.1f} %" + (f" (median launch {by / p50 / 1e6 / 8 * 100:4.1f} %," if p50 else " (")
+                + f" best launch {by / mn / 1e6 / 8 * 100:4.1f} %)")
     out.append(row)
-out.append("\n== (b) inside a step, HIP events (store kernel + any wait for the draw kernel; 60 steps)")
+out.append("\n== (b) inside a step, HIP events (store kernel + any wait for the draw kernel; 240 steps)")
 out += [l.rstrip("\n") for l in open(f"gpurun_out/{tag}_top_shapes_steps.txt")]
 open(f"profiles/{tag}_top_view_shapes.txt", "w").write("\n".join(out) + "\n")
 print(f"profiles/{tag}_top_view_shapes.txt: {len(out)} lines")
