@@ -92,9 +92,17 @@ class ShardedSingleRoom:
         self.first, self.count = shard_range(self.global_batch, self.world, self.rank)
         if env_factory is None:
             from .single_room import SingleRoom as env_factory
+        # the reference's `rng` keyword (SR:49,265) for a sharded batch: generators are GLOBAL — one per global agent, or one
+        # for all, which every rank advances through all global agents' draws (in the same initial state on every rank) —
+        # so that the states do not depend on the sharding, as with the device generator (agent_id_offset)
+        self.rng = kwargs.pop("rng", None)
         self.env = env_factory(batch=self.count, agent_id_offset=self.first,
                                device=default_device() if device is None else device, **kwargs)
         self._abi_comm = False
+        if self.rng is not None:
+            from .single_room import _reset_from_rng
+
+            _reset_from_rng(self.env, self.rng, None, construction=True, first=self.first, global_batch=self.global_batch)
 
     # ---- stepping: purely local ------------------------------------------------------
     def local_slice(self, global_array):
@@ -106,9 +114,22 @@ class ShardedSingleRoom:
 
         act_(self.env, local_actions)
 
-    def reset_(self, local_mask=None, seed: Optional[int] = None) -> None:
-        from .single_room import reset_
+    def reset_(self, local_mask=None, seed: Optional[int] = None, rng=None, global_mask=None) -> None:
+        """`RCW.reset!` of this rank's agents: on the device (`local_mask`, `seed`), or — `rng`, or a batch constructed with
+        one — from the caller's GLOBAL generator(s), with the GLOBAL mask (`global_mask`: a single generator's draws for the
+        other ranks' unmasked agents have to be made too)."""
+        from .single_room import _reset_from_rng, reset_
 
+        if rng is None and seed is None:
+            rng = self.rng
+        if rng is not None:
+            if local_mask is not None and global_mask is None:
+                if hasattr(rng, "integers") and self.world > 1:
+                    raise ValueError("a masked reset from ONE generator needs the GLOBAL mask (global_mask=...): the other ranks' draws are made too")
+                global_mask = np.ones(self.global_batch, dtype=np.uint8)
+                global_mask[self.first:self.first + self.count] = np.asarray(local_mask, dtype=np.uint8).reshape(self.count)
+            _reset_from_rng(self.env, rng, global_mask, first=self.first, global_batch=self.global_batch)
+            return
         reset_(self.env, local_mask, seed)
 
     # ---- the observation gather over torch.distributed -------------------------------------

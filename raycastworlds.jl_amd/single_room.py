@@ -777,33 +777,38 @@ def reference_reset_draws(rng, H: int, W: int, nd: int, old_goal=None):
     return gi, gj, lin % H + 1, lin // H + 1, d
 
 
-def _reset_from_rng(env: "SingleRoom", rng, mask, construction: bool = False) -> None:
+def _reset_from_rng(env: "SingleRoom", rng, mask, construction: bool = False, first: int = 0, global_batch: Optional[int] = None) -> None:
     """reset!(world) for every (unmasked) agent with the caller's generator(s): agent after agent from ONE generator —
     B reference worlds sharing an rng, reset in order — or agent a from `rng[a]` — each agent the reference world built
     with that rng.  The state goes to the engine with one rcw_set_state (tile_map goal bit, pose, heading, reward 0,
-    done false, rays cast, views rendered: SR:118-134, SR:328-329)."""
+    done false, rays cast, views rendered: SR:118-134, SR:328-329).
+
+    `first` / `global_batch` (ShardedSingleRoom): this engine holds the global agents [first, first + batch) of `global_batch`;
+    `rng` and `mask` are then the GLOBAL ones — one generator is advanced through every unmasked global agent's draws and this
+    shard keeps its own, so that the states do not depend on the sharding (every rank passes generators in the same state)."""
     H, W, nd, B = env.cfg.height_tile_map_tu, env.cfg.width_tile_map_tu, env.cfg.num_directions, env.batch
+    G = B if global_batch is None else int(global_batch)
     per_agent = not hasattr(rng, "integers")
-    if per_agent and len(rng) != B:
-        raise ValueError(f"expected one generator or {B} of them, got {len(rng)}")
-    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(B)
+    if per_agent and len(rng) != G:
+        raise ValueError(f"expected one generator or {G} of them, got {len(rng)}")
+    gm = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(G)
     goal = np.ones((B, 2), dtype=np.int32)
     pos = np.ones((B, 2), dtype=env.T)
     head = np.zeros(B, dtype=np.int32)
-    for a in range(B):
-        if m is not None and not m[a]:
+    for ga in (range(first, first + B) if per_agent else range(G)):          # (one generator: the other shards' draws are made and dropped)
+        if gm is not None and not gm[ga]:
             continue
-        g = rng[a] if per_agent else rng
+        g = rng[ga] if per_agent else rng
         if construction:
             reference_reset_draws(g, H, W, nd)       # SR:62-74: drawn, then overwritten by reset!(world) SR:105
         gi, gj, ti, tj, d = reference_reset_draws(g, H, W, nd)
-        goal[a] = (gi, gj)
-        pos[a] = (env.T(ti - 0.5), env.T(tj - 0.5))  # convert(T, tile - 0.5) SR:125
-        head[a] = d
-    if m is not None:
-        # masked-out agents keep their state: rcw_set_state skips them, the placeholders above are never read
-        pass
-    env.set_state(goal, pos, head, mask=m)
+        a = ga - first
+        if 0 <= a < B:
+            goal[a] = (gi, gj)
+            pos[a] = (env.T(ti - 0.5), env.T(tj - 0.5))  # convert(T, tile - 0.5) SR:125
+            head[a] = d
+    # masked-out agents keep their state: rcw_set_state skips them, the placeholders above are never read
+    env.set_state(goal, pos, head, mask=None if gm is None else gm[first:first + B])
 
 
 def reset_(env: SingleRoom, mask=None, seed: Optional[int] = None, rng=None) -> None:

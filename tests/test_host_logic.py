@@ -502,3 +502,44 @@ def test_reset_from_rng_injects_the_draws(rcw):
     assert not twice.values and captured["goal"].tolist() == [[2, 2]] * 3 and captured["head"].tolist() == [1, 1, 1]
     with pytest.raises(ValueError):
         SR._reset_from_rng(Env(), [one, one], None)
+
+
+def test_sharded_rng_resets_do_not_depend_on_the_sharding(rcw):
+    """The `rng` keyword behind ShardedSingleRoom: generators are global (one for all, or one per global agent); two shards
+    of 3 + 3 agents end up with the states of one engine of 6 — at construction, at a reset, at a masked reset."""
+    from raycastworlds_jl_amd.sharded import ShardedSingleRoom
+
+    class Engine:                                          # an engine double: records what rcw_set_state would get
+        T = np.float32
+
+        class cfg:
+            height_tile_map_tu, width_tile_map_tu, num_directions = 8, 16, 128
+
+        def __init__(self, batch, agent_id_offset, device, **kw):
+            self.batch, self.offset = batch, agent_id_offset
+            self.goal = np.zeros((batch, 2), np.int32); self.pos = np.zeros((batch, 2), np.float32); self.head = np.zeros(batch, np.int32)
+
+        def set_state(self, goal, pos, head, mask=None):
+            m = np.ones(self.batch, bool) if mask is None else np.asarray(mask, bool)
+            self.goal[m], self.pos[m], self.head[m] = goal[m], pos[m], head[m]
+
+    def state(*envs):
+        return (np.concatenate([e.goal for e in envs]), np.concatenate([e.pos for e in envs]), np.concatenate([e.head for e in envs]))
+
+    def same(a, b):
+        return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+    for make_rng in (lambda: np.random.default_rng(5), lambda: [np.random.default_rng(50 + a) for a in range(6)]):
+        whole = ShardedSingleRoom(6, rank=0, world=1, env_factory=Engine, rng=make_rng())
+        parts = [ShardedSingleRoom(6, rank=r, world=2, env_factory=Engine, rng=make_rng()) for r in range(2)]
+        assert same(state(whole.env), state(*(p.env for p in parts))), "construction"
+        whole.reset_(); [p.reset_() for p in parts]
+        assert same(state(whole.env), state(*(p.env for p in parts))), "reset"
+        gmask = np.array([1, 0, 0, 1, 1, 0], np.uint8)
+        whole.reset_(global_mask=gmask); [p.reset_(global_mask=gmask) for p in parts]
+        assert same(state(whole.env), state(*(p.env for p in parts))), "masked reset"
+    one = ShardedSingleRoom(6, rank=1, world=2, env_factory=Engine, rng=np.random.default_rng(1))
+    with pytest.raises(ValueError, match="GLOBAL mask"):
+        one.reset_(local_mask=np.array([1, 0, 1], np.uint8))
+    per = ShardedSingleRoom(6, rank=1, world=2, env_factory=Engine, rng=[np.random.default_rng(a) for a in range(6)])
+    per.reset_(local_mask=np.array([1, 0, 1], np.uint8))          # per-agent generators: a local mask is enough
