@@ -130,19 +130,32 @@ def live_traffic(workload, batch, kernel, seconds=150.0):
         return None
     out = {}
     for counter in ("WRITE_SIZE", "FETCH_SIZE"):
-        d = tempfile.mkdtemp(prefix="rcw_pmc_", dir="/tmp")
+        d = None
         try:
+            d = tempfile.mkdtemp(prefix="rcw_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--traffic", "off",
                    "--workload", workload, "--batch", str(batch)]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
             env["TMPDIR"] = "/tmp"
-            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=seconds)
-            v = parse_pmc(d, counter, kernel) if res.returncode == 0 else None
+            # its own session: on a timeout the WHOLE group goes (rocprofv3 runs the program as its child; killing the
+            # profiler alone would leave that child on the GPU)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=seconds)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, 9)
+                except OSError:
+                    pass
+                proc.wait()
+                rc = -9
+            v = parse_pmc(d, counter, kernel) if rc == 0 else None
         except Exception:   # noqa: BLE001 — a reported extra: never costs the bench line
             v = None
         finally:
-            shutil.rmtree(d, ignore_errors=True)
+            if d:
+                shutil.rmtree(d, ignore_errors=True)
         if v is None:
             return None
         out[counter] = v * 1024.0                        # KiB -> bytes

@@ -1,11 +1,14 @@
 // HIP kernels (gfx950 / CDNA4) for the batched SingleRoom step/render path.
 //
 // A step is two launches on the handle's stream:
-//   rcw_cast_kernel   one workgroup per agent.  The agent's tile_map (2·H·W bits) is staged in
-//            LDS, unpacked to a byte per tile; every lane runs the (wave-uniform) dynamics
+//   rcw_cast_kernel   one workgroup per agent.  Its loads go out in two batches, each awaited once: the agent's
+//            state (scalar loads in one asm statement + the tile-map words), then what depends on the heading
+//            after the action (direction vector, the heading's ray-table entries), issued before the
+//            tile_map (2·H·W bits) is unpacked into LDS, a byte per tile, and hidden behind the dynamics;
+//            every lane runs the (wave-uniform) dynamics
 //            act!(world, a) SR:139-191 redundantly so nothing has to be broadcast — the opt-in
 //            re-sample SR:110-137 runs on lane 0 and goes through LDS; then one lane per
-//            view column: table lookup of the ray (SR:214-221), grid DDA against
+//            view column: the ray's table entries (SR:214-221), grid DDA against
 //            the LDS tile map (RayCaster.cast_ray, SR:223), perpendicular distance and column
 //            height (SR:404-411), colour (SR:417-429) -> a 5-byte column descriptor in HBM,
 //            mirrored to image column k = N - i + 1 (SR:431).
@@ -20,8 +23,9 @@
 // bandwidth, and the frame (4·H_cam·N bytes per agent-step) is written exactly once.
 //
 // (opt-in) the reference's other per-step image, update_top_view! SR:446-483, every pixel written once:
-//   rcw_top_draw_kernel + rcw_top_store_kernel / rcw_top_store_flat_kernel / rcw_top_store_units_kernel   rays -> lines in
-//            an LDS bit plane -> the plane (1/32 of the image) to HBM, on a side stream beside the fill kernel; then the fill
+//   rcw_fill256_draw_kernel / rcw_top_draw_kernel + rcw_top_store_kernel / rcw_top_store_flat_kernel / rcw_top_store_units_kernel   rays -> lines in
+//            an LDS bit plane -> the plane (1/32 of the image) to HBM, in the camera fill's own launch (256-row camera view: the
+//            first workgroups fill, the others draw) or as a kernel of its own on a side stream beside the fill kernel; then the fill
 //            kernel's moving window over the image with the top view's pixel logic (_flat: any pixel scale from 9 pixels a
 //            tile, 256-pixel chunks of the flat batch, descriptor loads one group ahead awaited with vmcnt(63));
 //   rcw_top_view_kernel           the same in one persistent kernel (draw and store groups, a ring of LDS planes);
