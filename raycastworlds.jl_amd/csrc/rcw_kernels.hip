@@ -836,8 +836,8 @@ __device__ __forceinline__ void store16(u32x4* dst, u32x4 v)
     if (PLAIN) *dst = v; else __builtin_nontemporal_store(v, dst);
 }
 
-// (the body is a function of its own — workgroup `block` of `blocks` — because rcw_fill256_draw_kernel below runs it in the
-// first `blocks` workgroups of a larger launch)
+// rcw_fill256_kernel's body as a function — workgroup `block` of `blocks` — for rcw_fill256_draw_kernel, which runs it in the
+// first `blocks` workgroups of a larger launch (the kernel proper follows, with its body verbatim)
 template <bool PLAIN>
 __device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __restrict__ col_h, const uint8_t* __restrict__ col_c,
                                              u32x4* __restrict__ out, long long total_cols, const uint8_t* __restrict__ mask,
@@ -846,6 +846,54 @@ __device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __r
     const int lane = threadIdx.x & 63;
     const long long G = (long long)blocks * (kBlock / 64);
     const long long g = (long long)block * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    const int r0 = lane * 4;
+    for (long long base = g; base < total_cols; base += G * 64) {
+        // lane l holds the descriptor of this wavefront's l-th next chunk
+        const long long mine = base + (long long)lane * G;
+        int pad_l = -1;                       // -1: nothing to write (past the end / masked out)
+        uint32_t colour_l = 0u;
+        if (mine < total_cols && (mask == nullptr || mask[mine / p.N] != 0)) {
+            // THREE DEPENDENT round trips, on purpose: height -> colour id -> colour.  This prefetch is part of the kernel's pace
+            // (DESIGN.md §4.2 / §4.6): every shorter form measured — the two loads issued together, a packed word, the colour by
+            // selects — makes the kernel SLOWER, and the more so the larger the batch.  Round 4 found that out a fourth time: with
+            // this body moved into a function the compiler issued both loads at once, and the fill of an 8 GiB batch took 1420 us
+            // instead of 1250 (1 GiB: 158 instead of 156.5).  The empty asm statements pin the order the round-1 kernel had.
+            const int h = col_h[mine];
+            asm volatile("" :: "v"(h) : "memory");
+            pad_l = column_padding(256, h);
+            const uint32_t cid = col_c[mine];
+            asm volatile("" :: "v"(cid) : "memory");
+            colour_l = p.colour[cid & 3];
+        }
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+            const int pad = __builtin_amdgcn_readlane(pad_l, l);
+            if (pad < 0) continue;            // wave-uniform
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)colour_l, l);
+            u32x4 v;
+            v.x = pixel(r0 + 0, pad, 256, c, ceil_c, floor_c);
+            v.y = pixel(r0 + 1, pad, 256, c, ceil_c, floor_c);
+            v.z = pixel(r0 + 2, pad, 256, c, ceil_c, floor_c);
+            v.w = pixel(r0 + 3, pad, 256, c, ceil_c, floor_c);
+            store16<PLAIN>(out + (base + (long long)l * G) * 64 + lane, v);
+        }
+    }
+}
+
+// (the kernel proper, with the round-1 body verbatim rather than through fill256_body: its generated code — in particular the
+// prefetch's three dependent round trips — is what every measurement of rounds 1-3 was made with; tests/test_build_checks.py
+// checks that shape on the ISA of both)
+template <bool PLAIN>
+__global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
+                                                             const int32_t* __restrict__ col_h,
+                                                             const uint8_t* __restrict__ col_c,
+                                                             u32x4* __restrict__ out, long long total_cols,
+                                                             const uint8_t* __restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const long long G = (long long)gridDim.x * (kBlock / 64);
+    const long long g = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
     const int r0 = lane * 4;
 #ifdef RCW_TRACE_WAVES
@@ -890,16 +938,6 @@ __device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __r
         g_wave_trace[(g * 20 + 18) * 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
     }
 #endif
-}
-
-template <bool PLAIN>
-__global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
-                                                             const int32_t* __restrict__ col_h,
-                                                             const uint8_t* __restrict__ col_c,
-                                                             u32x4* __restrict__ out, long long total_cols,
-                                                             const uint8_t* __restrict__ mask)
-{
-    fill256_body<PLAIN>(p, col_h, col_c, out, total_cols, mask, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of

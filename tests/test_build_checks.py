@@ -56,3 +56,26 @@ def test_the_checker_sees_a_hazard_when_there_is_one(tmp_path):
     assert branch.returncode == 1 and "HAZARD" in branch.stdout, branch.stdout
     in_loop = _check(tmp_path, SYNTHETIC.format(name="loop", between="").replace("global_store_dwordx4 v[8:9], v[10:13]", "global_store_dwordx4 v[4:5], v[10:13]"))
     assert in_loop.returncode == 1 and "HAZARD" in in_loop.stdout and "global_store_dwordx4 v[4:5]" in in_loop.stdout, in_loop.stdout
+
+
+def test_the_fill_kernels_prefetch_keeps_its_three_dependent_round_trips():
+    """rcw_fill256_kernel's descriptor prefetch is part of its pace: height -> colour id -> colour, each
+    load awaited before the next is issued.  Every shorter form measured makes the kernel slower, the more so the larger the
+    batch — round 4 lost 13 % at 8 GiB when a refactoring let the compiler issue the first two loads together.  Checked on the
+    ISA of the kernel proper and of rcw_fill256_draw_kernel (the same body beside the top view's drawing)."""
+    import re
+
+    csrc = os.path.join(ROOT, "raycastworlds.jl_amd", "csrc")
+    res = subprocess.run(["make", "-C", csrc, "asm"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    text = open(os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "asm", "rcw_kernels.s")).read()
+    kernels = re.findall(r"^(_ZN12_GLOBAL__N_1\d+rcw_fill256_(?:draw_)?kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M)
+    assert len(kernels) >= 2 + 8, [k for k, _ in kernels]            # <PLAIN> x 2, the fused kernel x (T, TIE_LE, DIST_PRE)
+    for name, body in kernels:
+        ops = [l.strip() for l in body.splitlines() if re.match(r"\s+(global_load|s_waitcnt vmcnt\(0\))", l)]
+        # the three descriptor loads, in order, with a full wait between each pair
+        i_h = next(i for i, o in enumerate(ops) if o.startswith("global_load_dword") and "off" in o and "s[0:1]" not in o)
+        i_c = next(i for i, o in enumerate(ops) if i > i_h and o.startswith("global_load_ubyte"))
+        i_k = next(i for i, o in enumerate(ops) if i > i_c and o.startswith("global_load_dword") and "s[0:1]" in o)
+        assert any(o.startswith("s_waitcnt vmcnt(0)") for o in ops[i_h + 1:i_c]), f"{name}: height and colour id are requested together"
+        assert any(o.startswith("s_waitcnt vmcnt(0)") for o in ops[i_c + 1:i_k]), f"{name}: colour id and colour are requested together"
