@@ -12,9 +12,12 @@ State, actions and observations are resident in HBM when the timed region starts
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HBM write
-roofline of the step kernel, HIP-event timed on the kernel's own stream) and
+roofline of the step kernel, HIP-event timed on the kernel's own stream; `traffic` = HBM bytes
+per launch from the PMC counters, measured by the run itself at N = 1: two short
+`rocprofv3 --pmc` passes of this script as child processes, after the timed region) and
 `cpu_baseline` (the CPU oracle — a C restatement of the reference, kind "port" — timed on
-this box's host cores on a bounded sample of the same workload).
+this box's host cores on a bounded sample of the same workload).  A default run takes about a
+minute: ~12 s for the GPU part, ~25 s for the two counter passes, ~16 s for the CPU baseline.
 """
 import argparse
 import json
