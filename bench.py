@@ -212,6 +212,8 @@ def main():
                          "device tensors, and its frame gather on the first 256 agents of every rank)")
     ap.add_argument("--watchdog-seconds", type=float, default=120.0,
                     help="how long the optional gather may take before every rank gives up with exit code 3")
+    ap.add_argument("--hang-rank", type=int, default=-1,
+                    help="test only: this rank never enters the gather's first collective (tests/test_gpu_rccl.py drives the watchdog with it)")
     args = ap.parse_args()
 
     # Rank 0 must print ONE JSON line on stdout and nothing else.  Libraries do not know that (RCCL prints a version
@@ -502,6 +504,9 @@ def main():
             return [float(v) for v in t]
 
         try:
+            if args.hang_rank == rank:
+                pending["what"] = "nothing: this rank was told to hang (--hang-rank, test only)"
+                time.sleep(10 ** 6)
             h_loc, c_loc = env.columns_device()
             h_loc, c_loc = h_loc.torch(sync=False), c_loc.torch(sync=False)
             obs_loc = env.camera_view.torch(sync=False).view(torch.int32)[:Bf]
