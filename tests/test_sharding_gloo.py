@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two ranks over gloo.  The host-side sharding logic
+"""N > 1 path on CPU: two and eight ranks over gloo.  The host-side sharding logic
 (raycastworlds.jl_amd/sharded.py) runs for real; the engine underneath is swapped for a test
 double backed by the CPU oracle (injected through `env_factory` — the product default is the
 HIP engine and has no CPU fallback)."""
@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 CFG = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=32)
-GLOBAL_B = 12
+GLOBAL_B = 16
 STEPS = 25
 
 
@@ -87,8 +87,9 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one_unsharded_batch(oracle):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8], ids=["two_ranks", "eight_ranks"])
+def test_sharded_ranks_equal_one_unsharded_batch(oracle, world):
+    """... with two ranks, and with the eight of BASELINE's cfg-4 (a node's GPU count): rank r owns agents [r B / 8, (r + 1) B / 8)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
