@@ -67,6 +67,7 @@ struct rcw_handle {
     int action_slot = 0;
     bool profiling = false;
     int step_pieces = 1;               // development experiment only (RCW_STEP_PIECES)
+    void* d_step_flags = nullptr; void* d_step_hc = nullptr; uint32_t step_epoch = 0;   // development experiment only (RCW_STEP_FUSED)
     int prof_count = 0;
     std::vector<hipEvent_t> prof_ev;   // 4 per recorded step: start | after cast | after top view | after fill
     void* d_rays[4] = {nullptr, nullptr, nullptr, nullptr};   // rcw_rays scratch (grow-only)
@@ -176,6 +177,16 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
         return hipSuccess;
     }
 #endif
+#ifdef RCW_DEV_SWITCHES
+    if (d.step_fused && rcw_step_fusable(d)) {
+        // Development experiment (RCW_STEP_FUSED=1): cast and camera fill in ONE launch
+        if (prof && ((e = hipEventRecord(ev[1], h->stream)) != hipSuccess || (e = hipEventRecord(ev[2], h->stream)) != hipSuccess)) return e;
+        h->dev.step_epoch = ++h->step_epoch;
+        if ((e = rcw_launch_step256(d, actions_dev, mask_dev, h->step_epoch, h->stream)) != hipSuccess) return e;
+        if (prof) { if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e; h->prof_count++; }
+        return hipSuccess;
+    }
+#endif
     if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
     if (prof && (e = hipEventRecord(ev[1], h->stream)) != hipSuccess) return e;
     auto fill = [&]() -> hipError_t {
@@ -217,7 +228,7 @@ void free_all(rcw_handle* h)
     }
     for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
     if (h->top_stream) (void)hipStreamSynchronize(h->top_stream);          // (a draw kernel of a failed step may still run)
-    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_step_flags, &h->d_step_hc}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (h->ev_top_fork) (void)hipEventDestroy(h->ev_top_fork);
     for (hipEvent_t& q : h->ev_top_join) { if (q) (void)hipEventDestroy(q); q = nullptr; }
     if (h->top_stream) (void)hipStreamDestroy(h->top_stream);
@@ -768,6 +779,17 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
+    d.step_fused = 0; d.step_flags = nullptr; d.step_hc = nullptr; d.step_epoch = 0;
+    if (const char* v = RCW_DEV_ENV("RCW_STEP_FUSED")) {
+        if (std::atoi(v)) {
+            hipError_t e = hipMalloc(&h->d_step_flags, B * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(&h->d_step_hc, B * (size_t)N * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemset(h->d_step_flags, 0, B * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemset(h->d_step_hc, 0, B * (size_t)N * sizeof(uint32_t));
+            if (e != hipSuccess) { free_all(h); delete h; return fail(RCW_ERR_OUT_OF_MEMORY, "fused step: %s", hipGetErrorString(e)); }
+            d.step_flags = (uint32_t*)h->d_step_flags; d.step_hc = (uint32_t*)h->d_step_hc; d.step_fused = std::atoi(v) == 2 ? 2 : 1; d.step_epoch = 0;
+        }
+    }
     if (const char* v = RCW_DEV_ENV("RCW_STEP_PIECES")) {
         h->step_pieces = std::atoi(v) == 2 ? 2 : 1;
         if (h->step_pieces == 2) {                                                            // the side stream and its two events

@@ -74,6 +74,10 @@ struct RcwDev {
     uint32_t* top_plane;     // [B][W*pu][H*pu/32] ray-line bit plane of every agent (two-kernel top view)
     int2* top_hdr;           // [B] the player's pixel (ip, jp), 1-based  SR:468
     uint2* top_codes;        // [B][W][H*pu/256] 2-bit fill codes of a chunk's tiles
+    int32_t step_fused;      // development only (RCW_STEP_FUSED=1): cast and camera fill in ONE launch (rcw_step256_kernel), handed off through the two arrays below
+    uint32_t* step_flags;    // ... [B] the epoch of the last step whose descriptors of this agent are complete
+    uint32_t* step_hc;       // ... (N, B) the column's padding (SR:436, 0..256) | colour id << 9 | the step's epoch << 11 by image column
+    uint32_t step_epoch;     // ... this launch's epoch (the handle counts its fused steps)
     int32_t top_debug;       // development only (RCW_TOP_DEBUG): bit 0 skip drawing, bit 1 skip storing — for timing the halves
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
     int32_t* status;         // per-agent sticky status
@@ -110,6 +114,10 @@ size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);    // agents [first, first + count)
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
+#ifdef RCW_DEV_SWITCHES
+bool rcw_step_fusable(const RcwDev& p);       // development experiment (RCW_STEP_FUSED): cast + camera fill in one launch
+hipError_t rcw_launch_step256(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, uint32_t epoch, hipStream_t s);
+#endif
 int rcw_fill_draw_fusable(const RcwDev& p);   // a step's camera fill + top-view drawing in one launch: this geometry takes it
 hipError_t rcw_launch_fill256_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s);   // (fills p.obs from p.col_h / p.col_c, draws every agent)
 hipError_t rcw_prepare_top_view(const RcwDev& p, int device);

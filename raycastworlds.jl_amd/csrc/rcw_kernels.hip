@@ -597,8 +597,9 @@ constexpr int kCastTiles = 4;   // tiles a lane unpacks from words requested in 
 // One view column: march, projection, descriptor.  Returns whether the ray left the map (the caller reports it once per lane:
 // a branch around two stores in every column costs the issue-bound kernel eight instructions a column).  The descriptor arrays
 // are addressed as uniform base (the agent's row) + 32-bit lane offset.
-template <typename T, bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, int32_t* col_h_a, uint8_t* col_c_a, int i, T x, T y, T dx, T dy, T ddx, T ddy, T dot)
+template <typename T, bool TIE_LE, bool DIST_PRE, bool PUBLISH = false>
+__device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, int32_t* col_h_a, uint8_t* col_c_a, int i, T x, T y, T dx, T dy, T ddx, T ddy, T dot,
+                                            uint32_t* hc_a = nullptr)
 {
     const RayHit<T> r = cast_ray_guarded<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
     const int hl = height_line_pu<T>(p, r.dist, dot);
@@ -608,6 +609,10 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
     const uint32_t k = (uint32_t)(p.N - 1 - i);                             // SR:431 (0-based)
     *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(col_h_a) + k * 4u) = h;
     *(col_c_a + k) = (uint8_t)cid;
+#ifdef RCW_DEV_SWITCHES
+    // (rcw_step256_kernel: the two in one word for the fill workgroups of the SAME launch — a write-through store, agent scope)
+    if (PUBLISH) __hip_atomic_store(hc_a + k, (uint32_t)column_padding(256, h) | ((uint32_t)cid << 9) | (p.step_epoch << 11), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     return r.oob;
 }
 
@@ -623,7 +628,7 @@ __device__ __forceinline__ void agent_sync()
 // WAVE = false: the workgroup is one agent (tid = its thread, nthr = blockDim).  WAVE = true (development build only, measured and
 // rejected): 64 lanes are an agent and the workgroup's wavefronts are DIFFERENT agents (rcw_cast_waves_kernel): the same code with
 // tid = the lane, nthr = 64, the wavefront's own slice of LDS, and no workgroup barrier.
-template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE, bool PUBLISH = false>
 __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
                                           const int a, const int tid, const int nthr, uint32_t* const lds, const int trace_slot)
 {
@@ -752,11 +757,12 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
 #endif
     int32_t* const col_h_a = p.col_h + (size_t)a * N;
     uint8_t* const col_c_a = p.col_c + (size_t)a * N;
+    uint32_t* const hc_a = PUBLISH ? p.step_hc + (size_t)a * N : nullptr;
     bool left_the_map = false;
 #pragma unroll
     for (int k = 0; k < kCastCols; ++k) {
         const int i = tid + k * nthr;
-        if (i < N) left_the_map |= cast_column<T, TIE_LE, DIST_PRE>(p, tb, col_h_a, col_c_a, i, x, y, r_dx[k], r_dy[k], r_ddx[k], r_ddy[k], r_dot[k]);
+        if (i < N) left_the_map |= cast_column<T, TIE_LE, DIST_PRE, PUBLISH>(p, tb, col_h_a, col_c_a, i, x, y, r_dx[k], r_dy[k], r_ddx[k], r_ddy[k], r_dot[k], hc_a);
 #ifdef RCW_TRACE_WAVES
         if (k == 0) RCW_CAST_STAMP(5);
 #endif
@@ -775,7 +781,7 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
         const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int i = tid + kCastCols * nthr; i < N; i += nthr)
-            left_the_map |= cast_column<T, TIE_LE, DIST_PRE>(p, tb, col_h_a, col_c_a, i, x, y, tab[i], tab[N + i], tab[2 * N + i], tab[3 * N + i], tab[4 * N + i]);
+            left_the_map |= cast_column<T, TIE_LE, DIST_PRE, PUBLISH>(p, tb, col_h_a, col_c_a, i, x, y, tab[i], tab[N + i], tab[2 * N + i], tab[3 * N + i], tab[4 * N + i], hc_a);
     }
     if (left_the_map) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }   // (Julia: BoundsError in cast_ray)
 }
@@ -939,6 +945,84 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
     }
 #endif
 }
+
+#ifdef RCW_DEV_SWITCHES
+// Development build only (RCW_STEP_FUSED=1): the WHOLE step in one launch.  Workgroups 0 .. fill_blocks - 1 are the camera fill's
+// (dispatched first, onto an empty device, one per CU as in a launch of their own), the others cast four agents each, a wavefront per
+// agent (rcw_cast_waves_kernel).  The hand-off inside the launch (MI355X_MICROARCH.md, "inter-workgroup visibility"): a casting
+// wavefront stores each column's {height, colour id} as ONE word with an agent-scope (write-through, sc1) store into p.step_hc, waits
+// for all its stores (s_waitcnt vmcnt(0)), then its first lane stores the step's epoch into p.step_flags[agent], sc1 too; a fill
+// wavefront's lane polls the flag of the agent its next chunk belongs to with sc1 loads (they bypass the CU's L1, which still holds the
+// previous step's lines) and reads the word with an sc1 load only after the flag has matched.  Casting workgroups never wait, so
+// they drain whatever the dispatcher's order; a fill lane gives up after ~1 s (RCW_ERR_HIP in the handle's error word).
+template <bool PLAIN>
+__device__ __forceinline__ void fill256_wait_body(const RcwDev& p, u32x4* __restrict__ out, long long total_cols, const uint8_t* __restrict__ mask,
+                                                  int block, int blocks, uint32_t epoch)
+{
+    const int lane = threadIdx.x & 63;
+    const long long G = (long long)blocks * (kBlock / 64);
+    const long long g = (long long)block * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    const int r0 = lane * 4;
+    for (long long base = g; base < total_cols; base += G * 64) {
+        const long long mine = base + (long long)lane * G;
+        int pad_l = -1;
+        uint32_t colour_l = 0u;
+        if (mine < total_cols) {
+            const uint32_t a = (uint32_t)mine / (uint32_t)p.N;              // (the launcher takes this form below 2^31 columns only)
+            if (mask == nullptr || mask[a] != 0) {
+                int spins = 0;
+                uint32_t hc;
+                if (p.step_fused == 2) {
+                    // the word carries the step's epoch (its low 21 bits) as a tag: no flag, one round trip when the word is there
+                    while (((hc = __hip_atomic_load(p.step_hc + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 11) != (epoch & 0x1fffffu)) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1 << 20)) { p.err[0] = RCW_ERR_HIP; break; }
+                    }
+                } else {
+                    const uint32_t* const flag = p.step_flags + a;
+                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1 << 20)) { p.err[0] = RCW_ERR_HIP; break; }
+                    }
+                    asm volatile("" ::: "memory");
+                    hc = __hip_atomic_load(p.step_hc + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("" :: "v"(hc) : "memory");
+                pad_l = (int)(hc & 0x1ffu);
+                colour_l = p.colour[(hc >> 9) & 3u];
+            }
+        }
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+            const int pad = __builtin_amdgcn_readlane(pad_l, l);
+            if (pad < 0) continue;            // wave-uniform
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)colour_l, l);
+            u32x4 v;
+            v.x = pixel(r0 + 0, pad, 256, c, ceil_c, floor_c);
+            v.y = pixel(r0 + 1, pad, 256, c, ceil_c, floor_c);
+            v.z = pixel(r0 + 2, pad, 256, c, ceil_c, floor_c);
+            v.w = pixel(r0 + 3, pad, 256, c, ceil_c, floor_c);
+            store16<PLAIN>(out + (base + (long long)l * G) * 64 + lane, v);
+        }
+    }
+}
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__global__ __launch_bounds__(kBlock) void rcw_step256_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
+                                                             u32x4* __restrict__ out, long long total_cols, int fill_blocks, int lds_words,
+                                                             uint32_t epoch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if ((int)blockIdx.x < fill_blocks) { fill256_wait_body<false>(p, out, total_cols, mask, (int)blockIdx.x, fill_blocks, epoch); return; }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int a = ((int)blockIdx.x - fill_blocks) * (kBlock / 64) + wave;
+    if (a >= p.B) return;                                                   // (wave-uniform: the batch's last workgroup may be short)
+    cast_body<T, TIE_LE, DIST_PRE, true, true>(p, actions, mask, a, (int)(threadIdx.x & 63u), 64, lds + (size_t)wave * lds_words, a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every store of this wavefront has been acknowledged
+    if ((threadIdx.x & 63u) == 0) __hip_atomic_store(p.step_flags + a, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif   // RCW_DEV_SWITCHES (rcw_step256_kernel)
 
 // The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of
 // the k row blocks of a column: M = 1) and H_cam = 128 or 64 (a chunk holds M = 2 or 4 whole columns; lane l of a
@@ -2778,6 +2862,9 @@ static FillKernel fill_choice(const RcwDev& p, long long total_cols)
 }
 const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols)
 {
+#ifdef RCW_DEV_SWITCHES
+    if (p.step_fused && total_cols == (long long)p.B * p.N && rcw_step_fusable(p)) return "rcw_step256_kernel";
+#endif
     switch (fill_choice(p, total_cols)) {
     case kFill256: return "rcw_fill256_kernel";
     case kFillWindow1: case kFillWindow2: case kFillWindow4: return "rcw_fill_window_kernel";
@@ -2873,6 +2960,23 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
     RCW_DISPATCH(rcw_cast_kernel, dim3(count), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev, first);
     return hipGetLastError();
 }
+
+#ifdef RCW_DEV_SWITCHES
+// the whole step in one launch (rcw_step256_kernel): whether this handle can take it, and the launch
+bool rcw_step_fusable(const RcwDev& p)
+{
+    return p.step_flags != nullptr && p.step_hc != nullptr && p.top_view == nullptr && p.cast_block == 64 && (long long)p.B * p.N < (1ll << 31)
+        && fill_choice(p, (long long)p.B * p.N) == kFill256 && !p.fill_plain;
+}
+hipError_t rcw_launch_step256(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, uint32_t epoch, hipStream_t s)
+{
+    const size_t per_agent = (rcw_cast_lds_bytes(p) + 15) & ~(size_t)15;
+    const int cast_blocks = (p.B + 3) / 4;
+    RCW_DISPATCH(rcw_step256_kernel, dim3(p.fill_grid + cast_blocks), dim3(kBlock), 4 * per_agent, p, actions_dev, mask_dev,
+                 reinterpret_cast<u32x4*>(p.obs), (long long)p.B * p.N, p.fill_grid, (int)(per_agent / 4), epoch);
+    return hipGetLastError();
+}
+#endif
 
 size_t rcw_top_view_lds_bytes(const RcwDev& p)
 {

@@ -89,12 +89,13 @@ def test_shipped_library_reads_no_development_switch(rcw):
     assert env_names(_capi.LIB_PATH) == ["RCW_RCCL_LIBRARY"]
     # ... nor does it carry the development-only kernels (the round-3 cast kernel and its variants, the wavefront-per-agent form)
     shipped = open(_capi.LIB_PATH, "rb").read()
-    assert b"rcw_cast_kernel_r3" not in shipped and b"rcw_cast_waves_kernel" not in shipped
+    assert b"rcw_cast_kernel_r3" not in shipped and b"rcw_cast_waves_kernel" not in shipped and b"rcw_step256_kernel" not in shipped
     assert b"rcw_cast_kernel" in shipped and b"rcw_fill256_draw_kernel" in shipped
     if os.path.exists(_capi.DEV_LIB_PATH):
         dev = env_names(_capi.DEV_LIB_PATH)
         assert "RCW_CAST_MARCH" in dev and "RCW_TOP_DEBUG" in dev and "RCW_RCCL_LIBRARY" in dev
-        assert "RCW_CAST_KERNEL" in dev and "RCW_TOP_FUSED" in dev and b"rcw_cast_kernel_r3" in open(_capi.DEV_LIB_PATH, "rb").read()
+        assert "RCW_CAST_KERNEL" in dev and "RCW_TOP_FUSED" in dev and "RCW_STEP_FUSED" in dev
+        assert b"rcw_cast_kernel_r3" in open(_capi.DEV_LIB_PATH, "rb").read() and b"rcw_step256_kernel" in open(_capi.DEV_LIB_PATH, "rb").read()
         # the development build exports the same ABI
         lib = C.CDLL(_capi.DEV_LIB_PATH)
         assert not [n for n in _declared() if not hasattr(lib, n)]

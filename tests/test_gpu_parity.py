@@ -879,6 +879,30 @@ def test_lds_staged_ray_table_gives_the_same_rays(rcw, oracle, monkeypatch):
         env.close()
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_whole_step_in_one_launch_gives_the_same_frames(rcw, oracle, monkeypatch, form):
+    """Development switch RCW_STEP_FUSED of the development build (measured and rejected): cast and camera fill
+    in ONE launch, the column descriptors handed from the casting wavefronts to the fill workgroups inside it — through a
+    per-agent flag (1) or through words that carry the step's epoch (2).  Same frames, same state, with masked resets and
+    auto-reset; also in Float64 and with a batch that is not a multiple of a workgroup's four agents."""
+    monkeypatch.setenv("RCW_STEP_FUSED", form)
+    rng = np.random.default_rng(21)
+    for batch, kw in ((203, dict(num_rays=100, height_tile_map_tu=9, width_tile_map_tu=7)), (64, dict(T="Float64", **CFG1)),
+                      (1030, dict(num_rays=256, height_tile_map_tu=8, width_tile_map_tu=8))):
+        env, orc = _make(rcw, oracle, batch, seed=6, auto_reset=True, out_of_bounds=1, library="dev", **kw)
+        assert env.fill_kernel_name() == "rcw_step256_kernel"
+        for s in range(12):
+            if s % 5 == 2:
+                mask = (rng.random(batch) < 0.4).astype(np.uint8)
+                rcw.reset_(env, mask=mask, seed=40 + s); orc.reset(mask=mask, seed=40 + s)
+            a = rng.integers(1, 5, batch).astype(np.uint8)
+            rcw.act_(env, a)
+            assert orc.step(a) == 0
+            if s % 4 == 3 or s == 11:
+                assert_state_equal(env, orc, frames=True, where=f"fused form {form}, {kw}, step {s}")
+        env.close()
+
+
 def test_create_destroy_cycles_leave_device_memory_unchanged(rcw):
     """Handles with every optional buffer (top view, Float64 tables, typed rewards, rays scratch, a bound observation
     buffer, the gather scratch is covered by the RCCL test) are created, used and destroyed 25 times: free device
@@ -898,7 +922,15 @@ def test_create_destroy_cycles_leave_device_memory_unchanged(rcw):
         env.sync()
         env.close()
 
-    cycle(0)                                        # first use loads code objects etc.
+    for k in range(4):                              # first use of each type combination loads its kernels' code objects etc.
+        cycle(k)
+    # an environment runs on a torch.cuda.Stream() when torch is loaded: torch hands those out of a pool of 32 per device that it
+    # fills on demand (a new HIP stream, ~1 MiB of device memory, for each of the first 32 requests — tools/_build/memdrift.py
+    # measured +1 MiB per environment up to the 32nd and nothing after it): fill the pool before measuring
+    # (a HIP stream gets its queue with its first command: run something on each)
+    for _ in range(32):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            torch.zeros(8, device="cuda").add_(1)
     gc.collect()                                    # (what earlier tests dropped without close() goes now, not during the cycles)
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()

@@ -16,7 +16,7 @@ for t in glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"):
         per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for r in csv.reader(open(f)):
     m = re.search(r"rcw_[a-z0-9_]+(<[^>]*>)?", r[0])
-    if m and ("store" in r[0] or "fill" in r[0] or "draw" in r[0] or "top_view" in r[0] or "cast" in r[0]):
+    if m and ("store" in r[0] or "fill" in r[0] or "draw" in r[0] or "top_view" in r[0] or "cast" in r[0] or "step" in r[0]):
         d = sorted(per.get(r[0], []))
         p50 = f"  p50 {d[len(d) // 2]:8.1f}" if d else ""
         print(f"{sys.argv[2]:28s} {m.group(0)[:44]:44s} calls {r[1]:>4s} avg {float(r[3]) / 1e3:8.1f} us  min {float(r[5]) / 1e3:8.1f}{p50}")
