@@ -1,0 +1,39 @@
+"""The examples and the README's snippet run as a user would run them (GPU box): each in a process of its own."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, **kw):
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=300, **kw)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_random_policy_example(tmp_path):
+    out = _run(["examples/random_policy.py", "96", "40"])
+    assert "('MOVE_FORWARD', 'MOVE_BACKWARD', 'TURN_LEFT', 'TURN_RIGHT')" in out or "MOVE_FORWARD" in out
+    assert re.search(r"96 agents x 40 random steps on .*gfx950|96 agents x 40 random steps", out), out
+    assert os.path.getsize("/tmp/agent0.ppm") > 256 * 512 * 3          # (reference defaults: 512 columns x 256 rows, binary PPM)
+
+
+def test_torch_loop_example():
+    out = _run(["examples/torch_loop.py", "512", "30"])
+    assert re.search(r"512 agents x 30 steps, policy \+ engine on one stream: [\d.]+ M env-steps/s", out), out
+
+
+def test_readme_snippet(tmp_path):
+    """The python block of README.md, with `actions` defined, runs as printed."""
+    text = open(os.path.join(ROOT, "README.md")).read()
+    block = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    script = tmp_path / "readme_snippet.py"
+    script.write_text("import sys, numpy as np\nsys.path.insert(0, %r)\nactions = np.random.default_rng(0).integers(1, 5, 4096).astype(np.uint8)\n" % ROOT
+                      + block + "\nprint('state', obs.shape, RCW.RLBase.reward(rl).shape, RCW.RLBase.is_terminated(rl).shape)\nenv.close()\n")
+    out = _run([str(script)])
+    assert "state (4096, 256, 256) (4096,) (4096,)" in out, out

@@ -55,7 +55,7 @@ GEOMETRIES = (
     dict(height_tile_map_tu=32, width_tile_map_tu=32, num_rays=64, height_camera_view_pu=128),
 )
 counts = {}
-OPS = ["act_host", "act_host", "act_device", "act_device", "act_scalar", "reset_mask", "reset_all", "set_state", "bad_action", "stream",
+OPS = ["act_host", "act_host", "act_device", "act_device", "act_scalar", "reset_mask", "reset_all", "reset_rng", "set_state", "bad_action", "stream",
        "bind_obs", "form", "rerender", "rays", "expand", "profile"] + (["gather_columns", "gather_columns_abi", "gather_obs", "gather_obs_abi"] * 2 if SHARDED else [])
 
 
@@ -117,6 +117,27 @@ class Ctx:
             s = int(rng.integers(0, 1 << 30))
             RCW.reset_(env, mask=mask, seed=s)
             orc.reset(mask=mask, seed=s)
+        elif op == "reset_rng":
+            # the reference's `rng` keyword (SR:49): draws from the caller's generator(s) on the host, in the reference's order;
+            # the oracle gets the same draws made here from generators in the same state
+            from raycastworlds_jl_amd.single_room import reference_reset_draws
+            mask = (rng.random(B) < 0.5).astype(np.uint8) if rng.integers(0, 2) else None
+            s = int(rng.integers(0, 1 << 30))
+            per_agent = bool(rng.integers(0, 2))
+            mine = [np.random.default_rng([s, a]) for a in range(B)] if per_agent else np.random.default_rng(s)
+            theirs = [np.random.default_rng([s, a]) for a in range(B)] if per_agent else np.random.default_rng(s)
+            nd = kw.get("num_directions", 128)
+            goal, pos, d = np.ones((B, 2), np.int32), np.ones((B, 2), np.float64 if kw.get("T") == "Float64" else np.float32), np.zeros(B, np.int32)
+            for a in range(B):
+                if mask is None or mask[a]:
+                    gi, gj, ti, tj, da = reference_reset_draws(theirs[a] if per_agent else theirs, H, W, nd)
+                    goal[a], pos[a], d[a] = (gi, gj), (ti - 0.5, tj - 0.5), da
+            self.last = dict(op=op, per_agent=per_agent, mask=None if mask is None else mask.tolist())
+            if self.sh is not None:
+                self.sh.reset_(local_mask=mask, rng=mine)
+            else:
+                RCW.reset_(env, mask=mask, rng=mine)
+            orc.set_state(goal, pos, d, mask=mask)
         elif op == "set_state":
             if H < 4:
                 return                                       # (no second free interior row to move the player to)
