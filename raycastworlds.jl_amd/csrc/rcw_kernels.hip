@@ -844,7 +844,7 @@ __device__ __forceinline__ void store16(u32x4* dst, u32x4 v)
 
 // rcw_fill256_kernel's body as a function — workgroup `block` of `blocks` — for rcw_fill256_draw_kernel, which runs it in the
 // first `blocks` workgroups of a larger launch (the kernel proper follows, with its body verbatim)
-template <bool PLAIN>
+template <bool PLAIN, int EXTRA = 0>
 __device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __restrict__ col_h, const uint8_t* __restrict__ col_c,
                                              u32x4* __restrict__ out, long long total_cols, const uint8_t* __restrict__ mask,
                                              int block, int blocks)
@@ -865,8 +865,19 @@ __device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __r
             // selects — makes the kernel SLOWER, and the more so the larger the batch.  Round 4 found that out a fourth time: with
             // this body moved into a function the compiler issued both loads at once, and the fill of an 8 GiB batch took 1420 us
             // instead of 1250 (1 GiB: 158 instead of 156.5).  The empty asm statements pin the order the round-1 kernel had.
-            const int h = col_h[mine];
+            int h = col_h[mine];
             asm volatile("" :: "v"(h) : "memory");
+#ifdef RCW_DEV_SWITCHES
+            // (development experiment RCW_FILL_TRIPS: EXTRA more dependent round trips in front — the same word again, at an
+            // address the compiler cannot tell from the first one's)
+#pragma unroll
+            for (int e = 0; e < EXTRA; ++e) {
+                int z = h & 0x40000000;                                     // 0: a height is below 2^30
+                asm volatile("" : "+v"(z));
+                h = col_h[mine + z];
+                asm volatile("" :: "v"(h) : "memory");
+            }
+#endif
             pad_l = column_padding(256, h);
             const uint32_t cid = col_c[mine];
             asm volatile("" :: "v"(cid) : "memory");
@@ -946,6 +957,16 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_kernel(const RcwDev p,
 #endif
 }
 
+#ifdef RCW_DEV_SWITCHES
+// Development build only (RCW_FILL_TRIPS=1..3): rcw_fill256_kernel's body with that many MORE dependent round trips in each group's
+// prefetch (five measurements say a shorter prefetch makes this store stream slower: is a longer one faster?)
+template <int EXTRA>
+__global__ __launch_bounds__(kBlock) void rcw_fill256_trips_kernel(const RcwDev p, const int32_t* __restrict__ col_h, const uint8_t* __restrict__ col_c,
+                                                                   u32x4* __restrict__ out, long long total_cols, const uint8_t* __restrict__ mask)
+{
+    fill256_body<false, EXTRA>(p, col_h, col_c, out, total_cols, mask, (int)blockIdx.x, (int)gridDim.x);
+}
+#endif
 #ifdef RCW_DEV_SWITCHES
 // Development build only (RCW_STEP_FUSED=1): the WHOLE step in one launch.  Workgroups 0 .. fill_blocks - 1 are the camera fill's
 // (dispatched first, onto an empty device, one per CU as in a launch of their own), the others cast four agents each, a wavefront per
@@ -2882,6 +2903,17 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     u32x4* const frames4 = reinterpret_cast<u32x4*>(frames);
     switch (fill_choice(p, total_cols)) {
     case kFill256:
+#ifdef RCW_DEV_SWITCHES
+        if (p.fill_trips >= 0 && !p.fill_plain) {
+            switch (p.fill_trips) {
+            case 0: hipLaunchKernelGGL(rcw_fill256_trips_kernel<0>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev); break;
+            case 1: hipLaunchKernelGGL(rcw_fill256_trips_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev); break;
+            case 2: hipLaunchKernelGGL(rcw_fill256_trips_kernel<2>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev); break;
+            default: hipLaunchKernelGGL(rcw_fill256_trips_kernel<4>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev); break;
+            }
+            break;
+        }
+#endif
         if (p.fill_plain) hipLaunchKernelGGL(rcw_fill256_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
         else              hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
         break;
