@@ -18,8 +18,11 @@ for H, W, pu, N in SHAPES:
     B = max(64, min(65536, (1 << 30) // (4 * px)))          # ~1 GiB of top view a launch (round 3 capped the batch at 16,384 agents: 0.4-0.7 GiB for the small images)
     if os.environ.get("TOPSHAPES_BATCH"):                 # development: another batch than ~1 GiB of top view
         B = int(os.environ["TOPSHAPES_BATCH"])
+    extra = {}
+    if os.environ.get("TOPSHAPES_RADIUS"):                # development: another player radius (the circle drawn into the top view, SR:480)
+        extra["player_radius_wu"] = float(os.environ["TOPSHAPES_RADIUS"])
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
-                                          width_tile_map_tu=W, num_rays=N, pu_per_tu=pu, render_top_view=True)
+                                          width_tile_map_tu=W, num_rays=N, pu_per_tu=pu, render_top_view=True, **extra)
     if os.environ.get("TOPSHAPES_RUNS"):                  # development: the two-kernel form in this many runs of agents
         env.set_top_view_form("two-kernels", runs=int(os.environ["TOPSHAPES_RUNS"]))
     st = torch.cuda.Stream(); env.set_stream(st.cuda_stream); torch.cuda.set_stream(st)
