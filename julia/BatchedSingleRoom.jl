@@ -31,6 +31,7 @@
 module BatchedSingleRoomModule
 
 import ..RayCastWorlds as RCW
+import MiniFB as MFB
 import ReinforcementLearningBase as RLBase
 
 const librcw = get(ENV, "LIBRCW_HIP", "librcw_hip.so")
@@ -217,7 +218,8 @@ function act_device!(env::BatchedSingleRoom, actions_device::Ptr{UInt8})
     return nothing
 end
 
-RCW.get_action_names(env::BatchedSingleRoom) = (:MOVE_FORWARD, :MOVE_BACKWARD, :TURN_LEFT, :TURN_RIGHT)
+RCW.get_action_keys(env::BatchedSingleRoom) = (MFB.KB_KEY_W, MFB.KB_KEY_S, MFB.KB_KEY_A, MFB.KB_KEY_D)   # single_room.jl:485
+RCW.get_action_names(env::BatchedSingleRoom) = (:MOVE_FORWARD, :MOVE_BACKWARD, :TURN_LEFT, :TURN_RIGHT)   # single_room.jl:486
 
 # RCW.cast_rays!(world) single_room.jl:195-231, RCW.update_camera_view!(env) :374-444, RCW.update_top_view!(env) :446-483
 function RCW.cast_rays!(env::BatchedSingleRoom)

@@ -20,7 +20,7 @@ from . import single_room as SingleRoomModule
 from .rlbase import RLBaseEnv
 from .sharded import ShardedSingleRoom, make_unique_id, shard_range
 from .viewer import frame_buffer_of, frame_to_rgb, play_keys, save_agent_ppm, save_ppm
-from .single_room import (act_, cast_rays_, get_action_names, reset_, update_camera_view_, update_top_view_)
+from .single_room import (act_, cast_rays_, get_action_keys, get_action_names, pu_to_tu, reset_, update_camera_view_, update_top_view_, wu_to_pu, wu_to_tu)
 
 __all__ = ["SingleRoomModule", "RLBase", "RLBaseEnv", "ShardedSingleRoom", "shard_range", "make_unique_id", "frame_to_rgb", "save_ppm", "save_agent_ppm", "play_keys", "frame_buffer_of", "reset_", "act_", "cast_rays_",
-           "update_camera_view_", "update_top_view_", "get_action_names"]
+           "update_camera_view_", "update_top_view_", "get_action_names", "get_action_keys", "wu_to_tu", "wu_to_pu", "pu_to_tu"]

@@ -917,6 +917,27 @@ def update_top_view_(env: SingleRoom) -> None:
     env._check(env._lib.rcw_update_top_view(env._h))
 
 
+def get_action_keys(env: SingleRoom):
+    """`RCW.get_action_keys(env)` SR:485: the keys of actions 1..4 — MiniFB's KB_KEY_W / S / A / D there, their letters here
+    (what `viewer.play_keys` takes)."""
+    return ("w", "s", "a", "d")
+
+
 def get_action_names(env: SingleRoom):
     """`RCW.get_action_names(env)` SR:486."""
     return ("MOVE_FORWARD", "MOVE_BACKWARD", "TURN_LEFT", "TURN_RIGHT")
+
+
+def wu_to_tu(x_wu) -> int:
+    """utils.jl:5: the (1-based) tile of a world-unit coordinate."""
+    return int(np.floor(x_wu)) + 1
+
+
+def wu_to_pu(x_wu, pu_per_wu) -> int:
+    """utils.jl:6: the (1-based) pixel of a world-unit coordinate; the product is formed in x_wu's own type, as Julia does."""
+    return int(np.floor(x_wu * pu_per_wu)) + 1
+
+
+def pu_to_tu(i_pu: int, pu_per_tu: int) -> int:
+    """utils.jl:7: the (1-based) tile of a (1-based) pixel."""
+    return (int(i_pu) - 1) // int(pu_per_tu) + 1

@@ -543,3 +543,17 @@ def test_sharded_rng_resets_do_not_depend_on_the_sharding(rcw):
         one.reset_(local_mask=np.array([1, 0, 1], np.uint8))
     per = ShardedSingleRoom(6, rank=1, world=2, env_factory=Engine, rng=[np.random.default_rng(a) for a in range(6)])
     per.reset_(local_mask=np.array([1, 0, 1], np.uint8))          # per-agent generators: a local mask is enough
+
+
+def test_action_keys_names_and_unit_helpers():
+    """`RCW.get_action_keys` / `get_action_names` (SR:485-486) and utils.jl:5-7 as the mirror spells them."""
+    import raycastworlds_jl_amd as RCW
+    from raycastworlds_jl_amd import viewer
+
+    assert RCW.get_action_keys(None) == viewer.ACTION_KEYS == ("w", "s", "a", "d")
+    assert RCW.get_action_names(None) == ("MOVE_FORWARD", "MOVE_BACKWARD", "TURN_LEFT", "TURN_RIGHT")
+    assert [RCW.wu_to_tu(x) for x in (0.0, 0.999, 1.0, 7.5)] == [1, 1, 2, 8]                       # floor(Int, x) + 1
+    assert RCW.wu_to_pu(np.float32(0.125), 32) == 5 and RCW.wu_to_pu(np.float32(3.5), 32) == 113    # floor(Int, x * pu) + 1
+    assert RCW.wu_to_pu(np.float32(0.1), 10) == 2                                                   # Float32: 0.1f0 * 10 == 1.0f0 exactly
+    assert RCW.wu_to_pu(0.1 * 3, 10) == int(np.floor(0.1 * 3 * 10)) + 1
+    assert [RCW.pu_to_tu(i, 32) for i in (1, 32, 33, 256)] == [1, 1, 2, 8]                          # (i - 1) ÷ pu + 1
