@@ -16,6 +16,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "librcw_oracle.so")
 _LIB64_PATH = os.path.join(_HERE, "_build", "librcw_oracle64.so")   # the same source with T = Float64
+if os.environ.get("RCW_ORACLE_SANITIZED"):                           # tests/test_oracle_sanitizers.py: the ASan + UBSan build (make san)
+    _LIB_PATH = os.path.join(_HERE, "_build", "san", "librcw_oracle.so")
+    _LIB64_PATH = os.path.join(_HERE, "_build", "san", "librcw_oracle64.so")
 
 
 class RcwConfig(C.Structure):
@@ -100,7 +103,7 @@ def build(force: bool = False) -> str:
     newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
     stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in (_LIB_PATH, _LIB64_PATH))
     if stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"] + (["san"] if os.environ.get("RCW_ORACLE_SANITIZED") else []), check=True,
                        stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
