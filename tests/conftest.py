@@ -32,3 +32,20 @@ def oracle():
 
     O.build()
     return O
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _abi_call_census(request, tmp_path_factory):
+    """GPU runs: count the calls that reach each export of the library through the binding — in this process and, through
+    RCW_ABI_CALL_LOG, in the rank scripts the suite starts (tests/abi_census.py; tests/test_zz_abi_call_coverage.py reads it)."""
+    markexpr = request.config.option.markexpr or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr:
+        yield None
+        return
+    import abi_census
+
+    log = str(tmp_path_factory.mktemp("abi") / "calls.jsonl")
+    os.environ["RCW_ABI_CALL_LOG"] = log
+    abi_census.install()
+    yield log
+    os.environ.pop("RCW_ABI_CALL_LOG", None)

@@ -28,6 +28,11 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import abi_census
+
+abi_census.install_if_asked()
+
 WORLD, GLOBAL_BATCH, STEPS = 8, 65536, 5
 CFG4 = dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=256)
 COLOURS = [0x808080, 0xC0C0C0, 0x800000, 0xC00000]

@@ -25,6 +25,11 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import abi_census
+
+abi_census.install_if_asked()
+
 
 def main():
     ap = argparse.ArgumentParser()

@@ -339,6 +339,63 @@ def test_custom_direction_table(rcw, oracle):
     env.close()
 
 
+def test_tables_config_profile_and_timer_entry_points(rcw, oracle):
+    """The exports tests/test_zz_abi_call_coverage.py found no GPU test calling (round 4): the Float32 tables
+    (rcw_direction_table, rcw_ray_table: SR:65-69 and the fan of SR:214-221 per heading, against the oracle's), the caller's
+    table in Float64 (rcw_set_direction_table64), rcw_batch / rcw_get_config (what the handle was made with, defaults filled in),
+    and the two timing aids (rcw_profile / rcw_profile_read: HIP events around each kernel of a step; rcw_timer_start / _stop)."""
+    import ctypes as C
+
+    from raycastworlds_jl_amd import _capi
+
+    env, orc = _make(rcw, oracle, 24, seed=17, auto_reset=True, out_of_bounds=1, num_directions=96, **CFG2)
+    lib = env._lib
+    # Float32 tables
+    np.testing.assert_array_equal(env.world.directions_wu, orc.directions)
+    tab = env.ray_table()                                                    # (nd, 5, N): dx | dy | |1/dx| | |1/dy| | dir . ray
+    assert tab.dtype == np.float32 and tab.shape == (96, 5, 256)
+    np.testing.assert_array_equal(tab[:, 0, :], orc.ray_table[:, :, 0])
+    np.testing.assert_array_equal(tab[:, 1, :], orc.ray_table[:, :, 1])
+    with np.errstate(divide="ignore"):
+        np.testing.assert_array_equal(tab[:, 2, :], np.abs(np.float32(1) / tab[:, 0, :]))
+        np.testing.assert_array_equal(tab[:, 3, :], np.abs(np.float32(1) / tab[:, 1, :]))
+    d = env.world.directions_wu
+    np.testing.assert_array_equal(tab[:, 4, :], d[:, None, 0] * tab[:, 0, :] + d[:, None, 1] * tab[:, 1, :])   # SR:404, one rounding per operation
+    # what the handle was made with
+    n = C.c_int32()
+    env._check(lib.rcw_batch(env._h, C.byref(n)))
+    assert n.value == 24
+    cfg = _capi.RcwConfig()
+    env._check(lib.rcw_get_config(env._h, C.byref(cfg)))
+    assert (cfg.abi_version, cfg.height_tile_map_tu, cfg.width_tile_map_tu, cfg.num_rays, cfg.num_directions) == (lib.rcw_abi_version(), 8, 8, 256, 96)
+    assert (cfg.height_camera_view_pu, cfg.pu_per_tu, cfg.auto_reset) == (256, 32, 1) and cfg.player_radius_wu == np.float32(1 / 8)
+    # profiling: events around the cast and the fill kernel of each step
+    env.profile(True)
+    a = np.random.default_rng(0).integers(1, 5, 24).astype(np.uint8)
+    for _ in range(5):
+        rcw.act_(env, a); assert orc.step(a) == 0
+    cast_ms, top_ms, fill_ms, steps = env.profile_read()
+    env.profile(False)
+    assert steps == 5 and 0 < cast_ms < 5 and 0 < fill_ms < 5 and top_ms == 0
+    env.timer_start()                                                        # (stream time between two events: nothing of the host in between)
+    for _ in range(3):
+        rcw.act_(env, a)
+    assert 0 < env.timer_stop() < 50
+    for _ in range(3):
+        assert orc.step(a) == 0
+    assert_state_equal(env, orc, where="after profiled and timed steps")
+    env.close()
+    # the caller's direction table in Float64
+    env, orc = _make(rcw, oracle, 6, seed=4, T="Float64", **CFG1)
+    th = (np.arange(128) * 2 * np.pi / 128) - 0.003
+    dirs = np.stack([np.cos(th), np.sin(th)], axis=1)
+    env.set_direction_table(dirs); orc.set_direction_table(dirs)
+    np.testing.assert_array_equal(env.world.directions_wu, dirs)
+    assert_state_equal(env, orc, rays=True, where="custom Float64 table")
+    _rollout(rcw, env, orc, 20, np.random.default_rng(1), check_every=10, rays_every=10)
+    env.close()
+
+
 def test_top_view_matches_oracle(rcw, oracle):
     """update_top_view! SR:446-483 (opt-in): tiles + grid, one line per ray, the player circle."""
     rng = np.random.default_rng(13)
