@@ -2914,8 +2914,10 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
             break;
         }
 #endif
-        if (p.fill_plain) hipLaunchKernelGGL(rcw_fill256_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
-        else              hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
+#ifdef RCW_DEV_SWITCHES
+        if (p.fill_plain) { hipLaunchKernelGGL(rcw_fill256_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev); break; }
+#endif
+        hipLaunchKernelGGL(rcw_fill256_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, total_cols, mask_dev);
         break;
     case kFillWindow1:
         hipLaunchKernelGGL(rcw_fill_window_kernel<1>, dim3(grid), dim3(kBlock), 0, s, p, col_h, col_c, frames4, chunks, mask_dev);
@@ -2933,7 +2935,8 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
 #define RCW_FILL_FLAT(AL, KK) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev)
 #define RCW_FILL_FLAT_K(KK) case KK: if ((p.Hc & 3) == 0) RCW_FILL_FLAT(true, KK); else RCW_FILL_FLAT(false, KK); break
         switch (K) { RCW_FILL_FLAT_K(2); RCW_FILL_FLAT_K(3); RCW_FILL_FLAT_K(4); RCW_FILL_FLAT_K(5); RCW_FILL_FLAT_K(6); RCW_FILL_FLAT_K(7); RCW_FILL_FLAT_K(8);
-                     RCW_FILL_FLAT_K(9); RCW_FILL_FLAT_K(10); RCW_FILL_FLAT_K(11); RCW_FILL_FLAT_K(12);
+                     RCW_FILL_FLAT_K(9); RCW_FILL_FLAT_K(11); RCW_FILL_FLAT_K(12);
+                     case 10: if ((p.Hc & 3) == 0) return hipErrorInvalidValue; RCW_FILL_FLAT(false, 10); break;   // (29, 30, 31 rows: none a multiple of 4)
                      default: return hipErrorInvalidValue; }
 #undef RCW_FILL_FLAT_K
 #undef RCW_FILL_FLAT
@@ -3035,7 +3038,9 @@ int rcw_top_split_unit(const RcwDev& p)
     if (p.pu < 8 || 2 * p.top_rp > 31) return 0;
     int unit = 0;
     if (256 % p.pu == 0 && Ht % 256 == 0) unit = 256;
-    else if (128 % p.pu == 0 && Ht % 128 == 0 && 128 / p.pu <= 14) unit = 128;
+#ifdef RCW_DEV_SWITCHES
+    else if (128 % p.pu == 0 && Ht % 128 == 0 && 128 / p.pu <= 14) unit = 128;   // (every such geometry takes the flat kernel: RCW_TOP_FLAT=0 only)
+#endif
     else if (64 % p.pu == 0 && Ht % 64 == 0) unit = 64;
     else if (32 % p.pu == 0 && Ht % 32 == 0) unit = 32;
     if (!unit) return 0;
@@ -3111,29 +3116,39 @@ hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int fi
 #define RCW_FLAT(ST, NA, KK) hipLaunchKernelGGL((rcw_top_store_flat_kernel<ST, NA, KK>), grid, block, lds, s, p, mask_dev, c0, c1, first, first + count)
 #define RCW_FLAT_K(KK) case KK: if (straddle) { if (narrow) RCW_FLAT(true, true, KK); else RCW_FLAT(true, false, KK); } \
                                 else          { if (narrow) RCW_FLAT(false, true, KK); else RCW_FLAT(false, false, KK); } break
-        switch (p.top_flat) { RCW_FLAT_K(2); RCW_FLAT_K(3); RCW_FLAT_K(4); RCW_FLAT_K(5); RCW_FLAT_K(6); RCW_FLAT_K(7); default: return hipErrorInvalidValue; }
+        // (7 columns a chunk are images of 44 or 48 rows: at 19 pixels a tile and more that would be a map of two rows — there is no such instantiation;
+        // and 6 columns a chunk — 52, 56 or 60 rows — at such a scale are three tile rows of 20 pixels: a multiple of 4, no straddling)
+        switch (p.top_flat) { RCW_FLAT_K(2); RCW_FLAT_K(3); RCW_FLAT_K(4); RCW_FLAT_K(5);
+                              case 6: if (straddle && narrow) return hipErrorInvalidValue;
+                                      if (straddle) RCW_FLAT(true, false, 6); else if (narrow) RCW_FLAT(false, true, 6); else RCW_FLAT(false, false, 6); break;
+                              case 7: if (narrow) return hipErrorInvalidValue; if (straddle) RCW_FLAT(true, false, 7); else RCW_FLAT(false, false, 7); break;
+                              default: return hipErrorInvalidValue; }
 #undef RCW_FLAT_K
 #undef RCW_FLAT
         return hipGetLastError();
     }
     const uint32_t per_agent = (uint32_t)(((long long)p.H * p.pu * p.W * p.pu) >> 8);
     const uint32_t c0 = (uint32_t)first * per_agent, c1 = (uint32_t)(first + count) * per_agent;
+    // (plain instead of non-temporal stores — p.top_store_plain — and units of 128 rows, which the flat kernel has taken over, are
+    // choices of the development build only: the shipped library carries no instantiation it cannot reach)
+#ifdef RCW_DEV_SWITCHES
+#define RCW_STORE(KERNEL, ...) do { if (p.top_store_plain) hipLaunchKernelGGL((KERNEL<true, __VA_ARGS__>), grid, block, 0, s, p, mask_dev, c0, c1); \
+                                    else hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__>), grid, block, 0, s, p, mask_dev, c0, c1); } while (0)
+#else
+#define RCW_STORE(KERNEL, ...) hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__>), grid, block, 0, s, p, mask_dev, c0, c1)
+#endif
     if (p.top_unit_px == 128) {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 2>), grid, block, 0, s, p, mask_dev, c0, c1);
-        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 2>), grid, block, 0, s, p, mask_dev, c0, c1);
-    } else if (p.top_unit_px == 64) {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 4>), grid, block, 0, s, p, mask_dev, c0, c1);
-        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 4>), grid, block, 0, s, p, mask_dev, c0, c1);
-    } else if (p.top_unit_px == 32) {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_units_kernel<true, 8>), grid, block, 0, s, p, mask_dev, c0, c1);
-        else                   hipLaunchKernelGGL((rcw_top_store_units_kernel<false, 8>), grid, block, 0, s, p, mask_dev, c0, c1);
-    } else if (p.pu < 16) {                                                  // 32 tiles in a chunk
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, true>), grid, block, 0, s, p, mask_dev, c0, c1);
-        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, true>), grid, block, 0, s, p, mask_dev, c0, c1);
-    } else {
-        if (p.top_store_plain) hipLaunchKernelGGL((rcw_top_store_kernel<true, false>), grid, block, 0, s, p, mask_dev, c0, c1);
-        else                   hipLaunchKernelGGL((rcw_top_store_kernel<false, false>), grid, block, 0, s, p, mask_dev, c0, c1);
+#ifdef RCW_DEV_SWITCHES
+        RCW_STORE(rcw_top_store_units_kernel, 2);
+#else
+        return hipErrorInvalidValue;
+#endif
     }
+    else if (p.top_unit_px == 64) RCW_STORE(rcw_top_store_units_kernel, 4);
+    else if (p.top_unit_px == 32) RCW_STORE(rcw_top_store_units_kernel, 8);
+    else if (p.pu < 16) RCW_STORE(rcw_top_store_kernel, true);               // 32 tiles in a chunk
+    else RCW_STORE(rcw_top_store_kernel, false);
+#undef RCW_STORE
     return hipGetLastError();
 }
 

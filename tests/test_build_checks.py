@@ -70,7 +70,7 @@ def test_the_fill_kernels_prefetch_keeps_its_three_dependent_round_trips():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     text = open(os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "asm", "rcw_kernels.s")).read()
     kernels = re.findall(r"^(_ZN12_GLOBAL__N_1\d+rcw_fill256_(?:draw_)?kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M)
-    assert len(kernels) >= 2 + 8, [k for k, _ in kernels]            # <PLAIN> x 2, the fused kernel x (T, TIE_LE, DIST_PRE)
+    assert len(kernels) == 1 + 8, [k for k, _ in kernels]            # the kernel proper (non-temporal stores; <PLAIN> is the development build's), the fused kernel x (T, TIE_LE, DIST_PRE)
     for name, body in kernels:
         ops = [l.strip() for l in body.splitlines() if re.match(r"\s+(global_load|s_waitcnt vmcnt\(0\))", l)]
         # the three descriptor loads, in order, with a full wait between each pair

@@ -85,3 +85,7 @@ done
 for w in cfg2 cfg5; do for v in tablelds tablel2; do echo "$w $v calls,total_ns,avg_ns,pct,min_ns,max_ns,stddev: $(grep -h rcw_cast_kernel gpurun_out/${tag}_${w}_${v}_stats/*/*_kernel_stats.csv | sed 's/.*)",//' | tail -1)"; done; done | tee gpurun_out/${tag}_cast_table.txt
 grep -h "rcw_" gpurun_out/${tag}_cfg5_*_kernel_stats.csv | cut -c1-200 | head -8
 echo "round script done"
+# --- which kernel instantiations of the shipped build the GPU suite launches (tests/kernel_census.sh -> gpurun_out/census/summary.txt)
+make -s -C raycastworlds.jl_amd/csrc asm > /dev/null 2>&1
+tests/kernel_census.sh > gpurun_out/${tag}_kernel_census.log 2>&1; head -3 gpurun_out/census/summary.txt
+echo "round script done (census)"
