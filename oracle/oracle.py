@@ -19,6 +19,9 @@ _LIB64_PATH = os.path.join(_HERE, "_build", "librcw_oracle64.so")   # the same s
 if os.environ.get("RCW_ORACLE_SANITIZED"):                           # tests/test_oracle_sanitizers.py: the ASan + UBSan build (make san)
     _LIB_PATH = os.path.join(_HERE, "_build", "san", "librcw_oracle.so")
     _LIB64_PATH = os.path.join(_HERE, "_build", "san", "librcw_oracle64.so")
+if os.environ.get("RCW_ORACLE_COVERAGE"):                            # make cov: gcov-instrumented (which lines of the checker do its tests run?)
+    _LIB_PATH = os.path.join(_HERE, "_build", "cov", "librcw_oracle.so")
+    _LIB64_PATH = os.path.join(_HERE, "_build", "cov", "librcw_oracle64.so")
 
 
 class RcwConfig(C.Structure):
@@ -103,7 +106,7 @@ def build(force: bool = False) -> str:
     newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
     stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in (_LIB_PATH, _LIB64_PATH))
     if stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"] + (["san"] if os.environ.get("RCW_ORACLE_SANITIZED") else []), check=True,
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"] + (["san"] if os.environ.get("RCW_ORACLE_SANITIZED") else ["cov"] if os.environ.get("RCW_ORACLE_COVERAGE") else []), check=True,
                        stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

@@ -35,6 +35,60 @@ def test_oracle_random_policy_invariants(oracle):
     assert terminated > 0
 
 
+def test_oracle_auto_reset_and_lenient_step_invariants(oracle):
+    """The checker's own two batch conventions, by what must hold whatever the generator draws (CPU; `make -C oracle cov` showed
+    no CPU test running these lines — the GPU parity tests compare the HIP path WITH them): with auto_reset an agent that was
+    terminated is reset by the next step INSTEAD of acting — a new episode, reward 0, not terminated, the player at the centre
+    of an empty interior tile, the goal inside the wall ring (SR:110-137) — and the others act as without it; the lenient step
+    (rcw_step_device's convention) skips an agent with an invalid action, flags it, and steps the rest."""
+    B, H, W = 48, 8, 8
+    kw = dict(height_tile_map_tu=H, width_tile_map_tu=W, num_rays=16, render=False, out_of_bounds=1)
+    auto, plain = oracle.OracleBatch(B, seed=9, auto_reset=1, **kw), oracle.OracleBatch(B, seed=9, auto_reset=0, **kw)
+    rng = np.random.default_rng(2)
+    restarts = 0
+    for s in range(1500):
+        was_done = auto.done.copy() != 0
+        before = (auto.position.copy(), auto.direction.copy(), auto.goal.copy(), auto.episode.copy())
+        # keep the twin without auto-reset in the same state, so that "the others act as without it" can be checked
+        plain.set_state(before[2], before[0], before[1])
+        a = rng.integers(1, 5, B).astype(np.uint8)
+        assert auto.step(a) == 0 and plain.step(a) == 0
+        ep = auto.episode
+        assert (ep[was_done] == before[3][was_done] + 1).all() and (ep[~was_done] == before[3][~was_done]).all()
+        assert (auto.reward[was_done] == 0).all() and not auto.done[was_done].any()          # SR:131-132
+        pos, goal = auto.position[was_done], auto.goal[was_done]
+        tile = np.floor(pos).astype(int) + 1                                                  # wu_to_tu  UT:5
+        assert (pos == tile - 0.5).all()                                                      # the centre of a tile  SR:125
+        assert ((tile >= 2) & (tile <= [H - 1, W - 1])).all() and ((goal >= 2) & (goal <= [H - 1, W - 1])).all()
+        assert not (tile == goal).all(axis=1).any()                                           # an EMPTY tile  UT:27
+        assert ((auto.direction[was_done] >= 0) & (auto.direction[was_done] < 128)).all()     # SR:128
+        keep = ~was_done
+        np.testing.assert_array_equal(auto.position[keep], plain.position[keep])
+        np.testing.assert_array_equal(auto.direction[keep], plain.direction[keep])
+        np.testing.assert_array_equal(auto.done[keep], plain.done[keep])
+        np.testing.assert_array_equal(auto.col_height[keep], plain.col_height[keep])
+        restarts += int(was_done.sum())
+    assert restarts >= 8, restarts
+    # the lenient step
+    len_, ref = oracle.OracleBatch(B, seed=11, **kw), oracle.OracleBatch(B, seed=11, **kw)
+    for s in range(40):
+        a = rng.integers(1, 5, B).astype(np.uint8)
+        bad = rng.random(B) < 0.2
+        a_bad = np.where(bad, rng.choice([0, 5, 200], B), a).astype(np.uint8)
+        before = (len_.position.copy(), len_.direction.copy(), len_.goal.copy())
+        ref.set_state(before[2], before[0], before[1])
+        len_.clear_status()
+        assert len_.step_lenient(a_bad) == 0 and ref.step(a) == 0
+        assert (len_.status[bad] == -2).all() and (len_.status[~bad] == 0).all()              # RCW_ERR_INVALID_ACTION on the skipped ones only
+        np.testing.assert_array_equal(len_.position[bad], before[0][bad])
+        np.testing.assert_array_equal(len_.direction[bad], before[1][bad])
+        np.testing.assert_array_equal(len_.position[~bad], ref.position[~bad])
+        np.testing.assert_array_equal(len_.direction[~bad], ref.direction[~bad])
+        np.testing.assert_array_equal(len_.col_height[~bad], ref.col_height[~bad])
+        assert ref.step(a_bad) == -2                                                          # the strict step rejects the batch (SR:140's @assert)
+        ref.clear_status()
+
+
 @pytest.mark.gpu
 def test_rlbase_random_policy_invariants(rcw):
     RLBase = rcw.RLBase
