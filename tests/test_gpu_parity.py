@@ -487,6 +487,50 @@ def test_error_paths_fail_loudly(rcw):
     env.close()
 
 
+def test_live_handle_hostile_arguments(rcw, oracle):
+    """Every entry point, called on a LIVE handle with each of its pointer arguments NULL and its integers at 0, -1 and
+    2^31 - 1: an error code (or, where NULL / 0 has a meaning — no mask, own stream, own buffer, automatic form — success),
+    never a fault, never a kernel launched on a NULL pointer (read off rcw_api.hip: each pointer is checked before use);
+    afterwards the handle still steps bit-exactly."""
+    import ctypes as C
+
+    from raycastworlds_jl_amd import _capi
+
+    env, orc = _make(rcw, oracle, 12, seed=8, out_of_bounds=1, render_top_view=True, pu_per_tu=16, **CFG1)
+    lib, h = env._lib, env._h
+    calls = 0
+    for name, sig in _capi.SIGNATURES.items():
+        if not sig or sig[0] is not C.c_void_p or name in ("rcw_destroy", "rcw_comm_unique_id"):
+            continue
+        for ints in (0, -1, 2**31 - 1):
+            args = [h]
+            for t in sig[1:]:
+                if t in (C.c_float, C.c_double):
+                    args.append(0.0)
+                elif t is C.c_void_p or t is C.c_char_p or hasattr(t, "contents"):
+                    args.append(None)
+                elif t is C.c_uint64:
+                    args.append(t(ints & 0xFFFFFFFF))
+                else:
+                    args.append(t(ints))
+            rc = getattr(lib, name)(*args)
+            assert isinstance(rc, int) and -8 <= rc <= 0, (name, ints, rc)
+            if rc < 0:
+                assert _capi.last_error(lib), name
+            calls += 1
+            if len(sig) == 1 or not any(t not in (C.c_void_p, C.c_char_p) and not hasattr(t, "contents") and t not in (C.c_float, C.c_double) for t in sig[1:]):
+                break                                                        # (no integer argument to vary)
+    assert calls >= 70
+    # the handle is as usable as before: same stream rule, own buffer, automatic form; bring both sides to one state and step
+    env.clear_error()
+    env.set_top_view_form(None)
+    rcw.reset_(env, seed=77)                                                 # (the all-NULL rcw_reset calls above were resets too: the oracle takes the state over)
+    orc.set_state(env.world.goal_position, env.world.player_position_wu, env.world.player_direction_au)
+    _rollout(rcw, env, orc, 12, np.random.default_rng(4), check_every=4)
+    np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+    env.close()
+
+
 def test_float64_world_units(rcw, oracle):
     """T = Float64 (SingleRoom(; T = Float64) SR:259): every operation of the path in Float64, compared
     with the oracle compiled for T = Float64 (positions, distances, tables as doubles)."""
