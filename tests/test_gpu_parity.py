@@ -487,6 +487,54 @@ def test_error_paths_fail_loudly(rcw):
     env.close()
 
 
+def test_handles_on_concurrent_host_threads(rcw, oracle):
+    """Six host threads, a handle each (different geometries, world-unit types, top-view forms — among them the first handle of
+    the process that needs more than 64 KiB of LDS for its top view, i.e. the once-per-device kernel attribute), created, stepped
+    and read concurrently (ctypes releases the interpreter lock inside the library): what is per process in the library — the
+    error text (thread-local), the kernel attributes (a mutex) — holds, every thread's rollout equals its oracle's, and an
+    error raised in one thread (an invalid action) shows in that thread only."""
+    import threading
+
+    cases = [dict(CFG1), dict(CFG2, T="Float64"), dict(CFG1, render_top_view=True, pu_per_tu=32),
+             dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=64, render_top_view=True, pu_per_tu=32),     # 768 x 768 px: 72 KiB bit plane
+             dict(CFG1, height_camera_view_pu=100), dict(height_tile_map_tu=9, width_tile_map_tu=7, num_rays=33, render_top_view=True, pu_per_tu=13)]
+    failures, barrier = [], threading.Barrier(len(cases))
+
+    def worker(k, kw):
+        try:
+            rng = np.random.default_rng(100 + k)
+            barrier.wait()
+            env, orc = _make(rcw, oracle, 20 + k, seed=40 + k, auto_reset=True, out_of_bounds=1, **kw)
+            for s in range(30):
+                a = rng.integers(1, 5, env.batch).astype(np.uint8)
+                if k == 0 and s == 10:                                       # this thread's error, and its text, stay in this thread
+                    bad = a.copy(); bad[3] = 9
+                    with pytest.raises(AssertionError, match="Invalid action: 9"):
+                        rcw.act_(env, bad)
+                    assert orc.step(bad) == -2
+                rcw.act_(env, a)
+                assert orc.step(a) == 0
+                if s % 10 == 9:
+                    assert_state_equal(env, orc, where=f"thread {k} step {s}")
+                    if kw.get("render_top_view"):
+                        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+            env.close()
+        except BaseException as e:                                           # noqa: BLE001 (reported by the main thread)
+            failures.append((k, repr(e)[:600]))
+            try:
+                barrier.abort()
+            except Exception:                                                # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=worker, args=(k, kw)) for k, kw in enumerate(cases)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not failures, failures
+    assert not any(t.is_alive() for t in threads)
+
+
 def test_live_handle_hostile_arguments(rcw, oracle):
     """Every entry point, called on a LIVE handle with each of its pointer arguments NULL and its integers at 0, -1 and
     2^31 - 1: an error code (or, where NULL / 0 has a meaning — no mask, own stream, own buffer, automatic form — success),
