@@ -487,6 +487,68 @@ def test_error_paths_fail_loudly(rcw):
     env.close()
 
 
+def test_small_conveniences_of_the_mirror(rcw, oracle):
+    """What a line census of the Python mirror (round 4) found no test executing: DeviceArray's array-like protocol (nbytes, all,
+    sum, indexing, repr), the world's bool tile map (SR:22, unpacked from the BitArray chunks) and scalar properties, the
+    environment as a context manager, device_name, RLBaseEnv's repr, the refusals of malformed descriptor / action / form
+    arguments, host torch actions, and the 16-deep ring of held references on a stream torch does not own."""
+    torch = pytest.importorskip("torch")
+    SR = rcw.SingleRoomModule.SingleRoom
+    with SR(batch=40, seed=5, auto_reset=True, out_of_bounds=1, **CFG1) as env:
+        orc = oracle.OracleBatch(40, seed=5, auto_reset=1, out_of_bounds=1, **CFG1)
+        rl = rcw.RLBaseEnv(env)
+        assert "batch=40" in repr(rl) and "8x8" in repr(rl) and "gfx950" in env.device_name()
+        w = env.world
+        assert (w.num_rays, w.num_directions) == (64, 128) and w.player_radius_wu == np.float32(1 / 8)
+        assert w.position_increment_wu == np.float32(1 / 8) and w.semi_field_of_view_wu == np.float32(2 / 3)
+        # tile_map[b, o, i, j]: the wall ring, one goal tile where goal_position says (SR:54-63)
+        tm = w.tile_map
+        assert tm.shape == (40, 2, 8, 8) and tm.dtype == bool
+        ring = np.ones((8, 8), bool); ring[1:-1, 1:-1] = False
+        assert (tm[:, 0] == ring).all() and (tm[:, 1].sum(axis=(1, 2)) == 1).all()
+        g = w.goal_position
+        assert all(tm[b, 1, g[b, 0] - 1, g[b, 1] - 1] for b in range(40))
+        # DeviceArray: a device-resident array that behaves like its host copy
+        a = np.random.default_rng(0).integers(1, 5, 40).astype(np.uint8)
+        rcw.act_(env, a); assert orc.step(a) == 0
+        cam = env.camera_view
+        assert cam.nbytes == 40 * 64 * 256 * 4 and "DeviceArray(ptr=0x" in repr(cam) and len(cam) == 40
+        np.testing.assert_array_equal(cam[3], orc.camera_view[3])
+        np.testing.assert_array_equal(cam[5:7, ::8], orc.camera_view[5:7, ::8])
+        rew = env.reward_device()
+        assert rew.sum() == orc.reward.sum() and rew.all() == orc.reward.all() and not env.done_device().any()
+        # actions as a HOST torch tensor, and malformed device ones
+        acts = torch.from_numpy(a).cuda()
+        rcw.act_(env, torch.from_numpy(a)); assert orc.step(a) == 0
+        with pytest.raises(ValueError, match="contiguous uint8"):
+            rcw.act_(env, acts.to(torch.int32))
+        with pytest.raises(ValueError, match="contiguous uint8"):
+            rcw.act_(env, acts[:17])
+        h, c = env.columns_device()
+        with pytest.raises(ValueError, match="shape"):
+            env.expand_columns(h.torch()[:, :10], c.torch()[:, :10])
+        with pytest.raises(ValueError, match="int32 / uint8"):
+            env.expand_columns(h.torch().float(), c.torch())
+        with pytest.raises(ValueError, match="unknown top view form"):
+            env.set_top_view_form("sideways")
+        assert_state_equal(env, orc, where="after the refusals")
+        # a raw stream (not torch's to keep alive): references to device actions are held in a ring of 16 events
+        raw = torch.cuda.Stream()
+        env.set_stream(raw.cuda_stream)
+        rng = np.random.default_rng(1)
+        for _ in range(60):                                                  # (more launches than the ring is deep; temporaries dropped at once)
+            a = rng.integers(1, 5, 40).astype(np.uint8)
+            rcw.act_(env, (torch.from_numpy(a).cuda() + 0).to(torch.uint8))
+            assert orc.step(a) == 0
+        assert 1 <= len(env._held) <= 16
+        assert_state_equal(env, orc, where="60 steps on a raw stream")
+        env.sync()
+    assert env._handle is None or not env._handle.h                          # (the context manager closed it)
+    from raycastworlds_jl_amd import viewer
+    with pytest.raises(ValueError):
+        viewer.frame_to_rgb(np.zeros((2, 3, 4), np.uint32))
+
+
 def test_handles_on_concurrent_host_threads(rcw, oracle):
     """Six host threads, a handle each (different geometries, world-unit types, top-view forms — among them the first handle of
     the process that needs more than 64 KiB of LDS for its top view, i.e. the once-per-device kernel attribute), created, stepped
