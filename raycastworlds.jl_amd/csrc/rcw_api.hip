@@ -30,6 +30,18 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+#ifdef RCW_DEV_SWITCHES
+// Development build only: which error returns of this file has the process taken?  Every `fail(...)` below leaves its source
+// line in a table that rcw_dev_fail_sites hands out (tests: which refusals does the suite provoke, which never).
+unsigned char g_fail_hit[4096];
+template <typename... A>
+int fail_at(int line, int code, const char* fmt, A... args)
+{
+    if (line >= 0 && line < (int)sizeof g_fail_hit) g_fail_hit[line] = 1;
+    return fail(code, fmt, args...);
+}
+#define fail(...) fail_at(__LINE__, __VA_ARGS__)
+#endif
 
 #define RCW_HIP(expr)                                                                   \
     do {                                                                                \
@@ -40,6 +52,15 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 }  // namespace
+#ifdef RCW_DEV_SWITCHES
+extern "C" __attribute__((visibility("default"))) int rcw_dev_fail_sites(unsigned char* out, int cap)
+{
+    if (!out || cap < 1) return -1;
+    const int n = cap < (int)sizeof g_fail_hit ? cap : (int)sizeof g_fail_hit;
+    std::memcpy(out, g_fail_hit, (size_t)n);
+    return n;
+}
+#endif
 
 struct rcw_handle {
     rcw_config cfg{};

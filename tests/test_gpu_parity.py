@@ -597,6 +597,92 @@ def test_handles_on_concurrent_host_threads(rcw, oracle):
     assert not any(t.is_alive() for t in threads)
 
 
+def test_c_level_validation(rcw):
+    """The refusals of the C ABI itself — what a C or Julia caller meets; the Python mirror checks most of these on its own
+    side first, so its tests never reached them (a census of the error returns taken, round 4): every rule of
+    rcw_config / rcw_create, an action outside 1..4 in rcw_step, misaligned buffers, the wrong world-unit entry point, the
+    top view on a handle made without it, a second communicator — each with its code and a message, none disturbing the handle."""
+    import ctypes as C
+
+    from raycastworlds_jl_amd import _capi
+
+    lib = _capi.load()
+    INV, UNS, ACT = _capi.RCW_ERR_INVALID_ARGUMENT, _capi.RCW_ERR_UNSUPPORTED, _capi.RCW_ERR_INVALID_ACTION
+
+    def create(batch=4, device=0, **kw):
+        cfg = _capi.RcwConfig()
+        assert lib.rcw_config_default(C.byref(cfg)) == 0
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.rcw_create(C.byref(cfg), batch, device, 1, C.byref(h))
+        if rc == 0:
+            return h
+        assert not h.value and _capi.last_error(lib), kw
+        return rc
+
+    assert lib.rcw_config_default(None) == INV
+    assert lib.rcw_create(None, 4, 0, 1, None) == INV
+    nan, inf = float("nan"), float("inf")
+    for want, kw in ((INV, dict(abi_version=3)), (INV, dict(height_tile_map_tu=2)), (INV, dict(width_tile_map_tu=2)),
+                     (UNS, dict(height_tile_map_tu=300, width_tile_map_tu=300)), (INV, dict(num_directions=0)), (INV, dict(num_rays=0)),
+                     (INV, dict(height_camera_view_pu=0)), (INV, dict(num_rays=(1 << 24) + 1, num_directions=1)),
+                     (UNS, dict(num_directions=4096, num_rays=8192)), (UNS, dict(height_camera_view_pu=(1 << 20) + 1)),
+                     (INV, dict(reward_type=7)), (INV, dict(goal_reward=nan)), (INV, dict(goal_reward_f64=inf)),
+                     (INV, dict(reward_type=_capi.RCW_REWARD_INT32, goal_reward_f64=0.5)), (INV, dict(world_unit_bits=16)),
+                     (INV, dict(world_unit_bits=64, player_radius_wu_f64=0.5)), (INV, dict(world_unit_bits=64, position_increment_wu_f64=nan)),
+                     (INV, dict(player_radius_wu=0.5)), (INV, dict(player_radius_wu=0.0)), (INV, dict(position_increment_wu=-1.0)),
+                     (INV, dict(semi_field_of_view_wu=inf)), (INV, dict(render_top_view=1, pu_per_tu=0)), (INV, dict(render_top_view=1, pu_per_tu=5000)),
+                     (INV, dict(camera_height_tile_wu=0.0)), (INV, dict(dda_tie_break=2)), (INV, dict(dda_distance=-1)),
+                     (INV, dict(normalize_mode=2)), (INV, dict(out_of_bounds=2))):
+        assert create(**kw) == want, (kw, _capi.last_error(lib))
+    assert create(batch=0) == INV and create(device=99) == _capi.RCW_ERR_NO_DEVICE and create(device=-1) == _capi.RCW_ERR_NO_DEVICE
+    # a live Float32 handle without the top view
+    h = create(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    assert not isinstance(h, int)
+    acts = (C.c_uint8 * 4)(1, 2, 9, 4)
+    assert lib.rcw_step(h, acts) == ACT and "Invalid action: 9 (agent 2)" in _capi.last_error(lib)   # @assert SR:140
+    assert lib.rcw_step(h, None) == INV
+    buf = C.c_void_p()
+    assert lib.rcw_device_malloc(h, 4 * 64 * 256 * 4 + 64, C.byref(buf)) == 0
+    assert lib.rcw_bind_obs(h, C.c_void_p(buf.value + 4)) == INV and "16-byte aligned" in _capi.last_error(lib)
+    hh, cc = C.c_void_p(), C.c_void_p()
+    assert lib.rcw_columns_device_ptr(h, C.byref(hh), C.byref(cc)) == 0
+    assert lib.rcw_expand_columns(h, hh, cc, 4, C.c_void_p(buf.value + 8)) == INV and "16-byte aligned" in _capi.last_error(lib)
+    assert lib.rcw_expand_columns(h, hh, cc, 0, buf) == INV
+    out = (C.c_double * 8)()
+    assert lib.rcw_position64(h, out) == UNS and "Float32" in _capi.last_error(lib)                      # the wrong world-unit entry point
+    assert lib.rcw_set_state64(h, None, None, None, None) == UNS and lib.rcw_rays64(h, 0, 1, None, None, None, None) == UNS
+    form = C.c_int32(-1)
+    assert lib.rcw_top_view_form(h, C.byref(form)) == 0 and form.value == 0                             # "none"
+    assert lib.rcw_set_top_view_form(h, _capi.RCW_TOP_VIEW_TWO_KERNELS, 0) == UNS and "render_top_view = 0" in _capi.last_error(lib)
+    img = (C.c_uint32 * 16)()
+    assert lib.rcw_top_view_copy(h, img, 0, 1) == UNS and lib.rcw_update_top_view(h) == UNS
+    tv = C.c_void_p()
+    assert lib.rcw_top_view_device_ptr(h, C.byref(tv)) == UNS
+    assert lib.rcw_gather_columns(h, buf, buf) == INV and "rcw_comm_init first" in _capi.last_error(lib)
+    assert lib.rcw_gather_observations(h, 0, buf) == INV
+    assert lib.rcw_comm_init(h, None, 0, 1) == INV and lib.rcw_comm_init(h, buf, 1, 1) == INV and lib.rcw_comm_init(h, buf, 0, 0) == INV
+    assert lib.rcw_comm_unique_id(None) == INV
+    # none of it disturbed the handle
+    acts = (C.c_uint8 * 4)(1, 3, 2, 4)
+    assert lib.rcw_step(h, acts) == 0 and lib.rcw_sync(h) == 0
+    assert lib.rcw_device_free(h, buf) == 0 and lib.rcw_destroy(h) == 0
+    # a handle with the top view: the form's own argument checks
+    h = create(render_top_view=1, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    assert not isinstance(h, int)
+    assert lib.rcw_set_top_view_form(h, 9, 0) == INV and lib.rcw_set_top_view_form(h, 0, 9) == INV and lib.rcw_set_top_view_form(h, 0, -1) == INV
+    assert lib.rcw_set_top_view_form(h, _capi.RCW_TOP_VIEW_ONE_KERNEL, 0) == 0 and lib.rcw_update_top_view(h) == 0 and lib.rcw_sync(h) == 0
+    assert lib.rcw_destroy(h) == 0
+    # a Float64 handle refuses the Float32 entry points
+    h = create(world_unit_bits=64, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+    assert not isinstance(h, int)
+    out32 = (C.c_float * 8)()
+    assert lib.rcw_position(h, out32) == UNS and "Float64" in _capi.last_error(lib)
+    assert lib.rcw_set_direction_table(h, out32) == UNS and lib.rcw_rays(h, 0, 1, None, None, None, None) == UNS
+    assert lib.rcw_destroy(h) == 0
+
+
 def test_live_handle_hostile_arguments(rcw, oracle):
     """Every entry point, called on a LIVE handle with each of its pointer arguments NULL and its integers at 0, -1 and
     2^31 - 1: an error code (or, where NULL / 0 has a meaning — no mask, own stream, own buffer, automatic form — success),
