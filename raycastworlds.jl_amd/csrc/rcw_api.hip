@@ -581,12 +581,17 @@ int load_rccl()
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.lib) return RCW_OK;
-    const char* names[] = {std::getenv("RCW_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // RCW_RCCL_LIBRARY, where set, is THE library: one that cannot be loaded is an error, not a reason to fall back to another copy
+    const char* const chosen = std::getenv("RCW_RCCL_LIBRARY");
     void* lib = nullptr;
-    for (const char* n : names) {
-        if (!n || !*n) continue;
-        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (lib) break;
+    if (chosen && *chosen) {
+        lib = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return fail(RCW_ERR_UNSUPPORTED, "RCW_RCCL_LIBRARY=%s could not be loaded (%s)", chosen, dlerror());
+    } else {
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
     }
     if (!lib) return fail(RCW_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded (%s); set RCW_RCCL_LIBRARY", dlerror());
     RcclApi api;

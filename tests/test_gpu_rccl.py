@@ -160,3 +160,61 @@ def test_a_hung_gather_looks_hung(rcw):
     assert "did not finish within 20 s" in out["gather"]["error"] and "all_gather_into_tensor of height_line_pu" in out["gather"]["error"]
     assert "rank 0" in res.stderr and "rank 1" in res.stderr and "exiting with code 3" in res.stderr
     assert "told to hang" in res.stderr                                               # rank 1 says where it was, too
+
+
+def test_communicator_argument_checks_and_a_library_that_cannot_be_loaded(rcw):
+    """The refusals around the communicator that no other test provoked (a census of the error returns taken, round 4), in child
+    processes because RCCL is loaded once per process: RCW_RCCL_LIBRARY naming a file that does not exist, or a library without
+    the RCCL symbols, is an error (never a silent fall back to another copy); with the real library and a world of one: a second
+    rcw_comm_init, NULL / misaligned gather buffers, an unknown gather mode."""
+
+    prog = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd())
+import raycastworlds_jl_amd as RCW
+from raycastworlds_jl_amd import _capi
+mode = sys.argv[1]
+env = RCW.SingleRoomModule.SingleRoom(batch=8, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
+lib, h = env._lib, env._h
+uid = (C.c_uint8 * _capi.RCW_UNIQUE_ID_BYTES)()
+if mode in ("missing", "not-rccl"):
+    rc = lib.rcw_comm_unique_id(uid)
+    print("RC", rc, _capi.last_error(lib))
+    rc = lib.rcw_comm_init(h, uid, 0, 1)
+    print("RC", rc, _capi.last_error(lib))
+else:
+    _capi.preload_rccl()
+    assert lib.rcw_comm_unique_id(uid) == 0
+    assert lib.rcw_comm_init(h, uid, 0, 1) == 0
+    print("RC", lib.rcw_comm_init(h, uid, 0, 1), _capi.last_error(lib))
+    buf = C.c_void_p()
+    assert lib.rcw_device_malloc(h, 8 * 64 * 256 * 4 + 64, C.byref(buf)) == 0
+    print("RC", lib.rcw_gather_columns(h, None, buf), _capi.last_error(lib))
+    print("RC", lib.rcw_gather_observations(h, 0, None), _capi.last_error(lib))
+    print("RC", lib.rcw_gather_observations(h, 0, C.c_void_p(buf.value + 4)), _capi.last_error(lib))
+    print("RC", lib.rcw_gather_observations(h, 7, buf), _capi.last_error(lib))
+    assert lib.rcw_gather_observations(h, 0, buf) == 0 and lib.rcw_sync(h) == 0
+    assert lib.rcw_comm_destroy(h) == 0 and lib.rcw_device_free(h, buf) == 0
+env.close()
+print("DONE")
+"""
+
+    def child(mode, **extra_env):
+        env = {k: v for k, v in os.environ.items() if k != "RCW_RCCL_LIBRARY"}
+        env.update(extra_env)
+        res = subprocess.run([sys.executable, "-c", prog, mode], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "DONE" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+        return [l for l in res.stdout.splitlines() if l.startswith("RC ")]
+
+    out = child("missing", RCW_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    assert len(out) == 2 and all(l.startswith("RC -7 RCW_RCCL_LIBRARY=/nonexistent/librccl.so.1 could not be loaded") for l in out), out
+    import ctypes.util
+
+    libm = ctypes.util.find_library("m")
+    out = child("not-rccl", RCW_RCCL_LIBRARY=libm)
+    assert len(out) == 2 and all(l.startswith("RC -7 librccl lacks ncclGetUniqueId") for l in out), out
+    out = child("real")
+    assert len(out) == 5, out
+    assert out[0].startswith("RC -1 the handle already has a communicator")
+    assert out[1].startswith("RC -1 NULL argument") and out[2].startswith("RC -1 NULL argument")
+    assert out[3].startswith("RC -1 frames must be 16-byte aligned") and out[4].startswith("RC -1 unknown gather mode 7")
