@@ -1117,14 +1117,30 @@ def test_two_top_view_handles_with_large_planes_alive_together(rcw, oracle):
     e1.close(); e2.close()
 
 
-def test_captured_step_with_top_view_replays(rcw, oracle):
-    """A step is capturable into a HIP graph (torch.cuda.CUDAGraph on the stream the engine shares), including the
-    two-kernel top view's fork to the handle's side stream and the join back: eight replays with the same device
-    actions equal eight oracle steps, both images."""
+@pytest.mark.parametrize("shape", ["fused", "side-stream", "one-kernel", "camera-only", "auto-reset"])
+def test_captured_step_with_top_view_replays(rcw, oracle, shape):
+    """A step is capturable into a HIP graph (torch.cuda.CUDAGraph on the stream the engine shares) in each of its launch
+    shapes: the camera fill and the top view's drawing in one launch (the default), the drawing on the handle's side stream
+    (a camera height the fused launch does not take: a fork and a join inside the capture), the one-kernel top view, the
+    camera view alone, and with auto-reset on (episodes restart inside the replays, their generator keyed by the device-side
+    episode counters): eight replays with the same device actions equal eight oracle steps, both images."""
     torch = pytest.importorskip("torch")
-    env, orc = _make(rcw, oracle, 48, seed=31, render_top_view=1, pu_per_tu=32, out_of_bounds=1, **CFG2)
-    env.set_top_view_form("two-kernels")                                     # (48 agents would take the one-kernel form)
-    assert env.top_view_form() == "two-kernels"
+    kw = dict(render_top_view=1, pu_per_tu=32, out_of_bounds=1, **CFG2)
+    if shape == "side-stream":
+        kw["height_camera_view_pu"] = 128
+    if shape in ("camera-only", "auto-reset"):
+        kw = dict(out_of_bounds=1, **CFG2)
+    if shape == "auto-reset":
+        kw["auto_reset"] = True
+    env, orc = _make(rcw, oracle, 48, seed=31, **kw)
+    if shape in ("fused", "side-stream"):
+        env.set_top_view_form("two-kernels")
+        assert env.top_view_form() == "two-kernels"
+    elif shape == "one-kernel":
+        env.set_top_view_form("one-kernel")
+    if shape == "auto-reset":                                                # every agent four forward steps from its goal: episodes end during the replays
+        g = np.tile(np.array([[4, 6]], np.int32), (48, 1)); p = np.tile(np.array([[3.5, 4.5]], np.float32), (48, 1)); d = np.full(48, 32, np.int32)
+        env.set_state(g, p, d); orc.set_state(g, p, d)
     stream = torch.cuda.Stream()
     env.set_stream(stream.cuda_stream)
     a_host = np.random.default_rng(2).integers(1, 5, env.batch).astype(np.uint8)
@@ -1141,8 +1157,12 @@ def test_captured_step_with_top_view_replays(rcw, oracle):
         for _ in range(7):
             g.replay(); orc.step(a_host)
         stream.synchronize()
-    assert_state_equal(env, orc, where="after 8 graph replays")
-    np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+    assert_state_equal(env, orc, where=f"after 8 graph replays ({shape})")
+    if kw.get("render_top_view"):
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+    if shape == "auto-reset":
+        np.testing.assert_array_equal(env.world.episode, orc.episode)
+        assert (orc.episode > 0).any(), "no episode restarted inside the replays"
     env.close()
 
 
