@@ -37,3 +37,23 @@ def test_readme_snippet(tmp_path):
                       + block + "\nprint('state', obs.shape, RCW.RLBase.reward(rl).shape, RCW.RLBase.is_terminated(rl).shape)\nenv.close()\n")
     out = _run([str(script)])
     assert "state (4096, 256, 256) (4096,) (4096,)" in out, out
+
+
+@pytest.mark.parametrize("flags", [["--workload", "cfg2"], ["--workload", "cfg3"], ["--workload", "cfg4"], ["--workload", "cfg5"], ["--top-view"],
+                                   ["--api", "rlbase"], ["--batch", "1000"], ["--no-auto-reset"], ["--gather"]])
+def test_bench_modes(flags):
+    """Every mode of bench.py the documents quote runs and prints ONE JSON line with the contract's keys (a few steps each; the
+    default invocation is what the round-end driver runs)."""
+    import json
+
+    out = _run(["bench.py", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--traffic", "off"] + flags)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, (k, flags)
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "env-steps/s" and d["dtype"] == "f32"
+    assert 0.3 < d["roofline"]["frac"] < 1.0, d["roofline"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    if flags == ["--gather"]:
+        assert "gather" in d and "error" not in d["gather"], d.get("gather")
