@@ -805,6 +805,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
+    d.top_rotate = 33;                                                       // (measured: rcw_kernels.hip, rcw_top_store_flat_kernel)
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_ROTATE")) { const int r = std::atoi(v); if (r >= 0 && r < 65536) d.top_rotate = r; }
     d.fill_trips = -1;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_TRIPS")) d.fill_trips = std::atoi(v);
     d.step_fused = 0; d.step_flags = nullptr; d.step_hc = nullptr; d.step_epoch = 0;

@@ -74,6 +74,7 @@ struct RcwDev {
     uint32_t* top_plane;     // [B][W*pu][H*pu/32] ray-line bit plane of every agent (two-kernel top view)
     int2* top_hdr;           // [B] the player's pixel (ip, jp), 1-based  SR:468
     uint2* top_codes;        // [B][W][H*pu/256] 2-bit fill codes of a chunk's tiles
+    int32_t top_rotate;      // rcw_top_store_flat_kernel's wavefront -> chunk assignment turns by this many slots from group to group (33; development: RCW_TOP_ROTATE)
     int32_t fill_trips;      // development only (RCW_FILL_TRIPS=0..3): rcw_fill256_kernel's body with that many more dependent round trips a prefetch; -1: the kernel proper
     int32_t step_fused;      // development only (RCW_STEP_FUSED=1): cast and camera fill in ONE launch (rcw_step256_kernel), handed off through the two arrays below
     uint32_t* step_flags;    // ... [B] the epoch of the last step whose descriptors of this agent are complete

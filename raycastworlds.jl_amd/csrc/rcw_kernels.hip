@@ -2642,8 +2642,17 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     const uint32_t lane16 = (uint32_t)lane * 16u;                            // the store's address: uniform chunk base + this
     // this lane's chunk of the first group as (image column of the flat batch, row in it); every group moves all lanes alike
     const unsigned long long id0 = (unsigned long long)chunk_begin + g + (unsigned long long)lane * G;
-    const unsigned long long step_px = (unsigned long long)G * 64 * 256;
+    // The wavefront -> chunk assignment TURNS by R slots from group to group: wavefront g takes slot (g + k R) mod G of group k — every
+    // group is still one compact window, every chunk is written once.  Without it (R = 0), where an image is a whole number of chunks
+    // that divides G (128 x 128 px = 64 chunks, 128 x 256 = 128), a wavefront meets the SAME image columns of every agent for the whole
+    // launch, and the kernel takes 10-14 % longer (round 4: 190 -> 172 us / GiB at 8x8 tiles of 16 px, 203 -> 179 at 4x4 of 32; a turn
+    // of 64 slots — the same columns again — changes nothing; images that are no such number of chunks are not affected: DESIGN.md §4.4).
+    const uint32_t R = (uint32_t)p.top_rotate % G;                           // (33 slots; the development build reads RCW_TOP_ROTATE)
+    const unsigned long long step_px = ((unsigned long long)G * 64 + R) * 256;        // a lane's step from group to group ...
+    const unsigned long long step_px_w = step_px - (unsigned long long)G * 256;       // ... and where its slot wraps past G
     const uint32_t dq = (uint32_t)(step_px / (unsigned)Ht), dr = (uint32_t)(step_px - (unsigned long long)dq * (unsigned)Ht);
+    const uint32_t dq_w = (uint32_t)(step_px_w / (unsigned)Ht), dr_w = (uint32_t)(step_px_w - (unsigned long long)dq_w * (unsigned)Ht);
+    uint32_t slot_i = g;                                                               // the slot of the group `issue` is asked for next
     uint32_t col = (uint32_t)((id0 * 256) / (unsigned)Ht);
     uint32_t rem = (uint32_t)(id0 * 256 - (unsigned long long)col * (unsigned)Ht);
     u32x4* const out4 = reinterpret_cast<u32x4*>(p.top_view);
@@ -2658,6 +2667,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     // tile_map words of a column are one 12-byte load, a chunk's plane words two 16-byte loads by the chunk's own lane.
     uint32_t a_cur = col / (unsigned)Wt, j_cur = col - a_cur * (unsigned)Wt;      // (agent, image column) of this lane's next chunk
     const uint32_t dqa = dq / (unsigned)Wt, dqj = dq - dqa * (unsigned)Wt;        // ... move by this much a group (+ 1 column on a row wrap)
+    const uint32_t dqa_w = dq_w / (unsigned)Wt, dqj_w = dq_w - dqa_w * (unsigned)Wt;
     const uint32_t chunks_agent_lo = (uint32_t)(px_agent >> 8);                   // (floor of an image's chunks; the exact first chunk: 64-bit product)
     auto issue = [&](uint32_t base, TopFlatPre<K>& P) {
         const uint32_t id = base + (uint32_t)lane * G;
@@ -2695,10 +2705,12 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
         flat_load_b128(P.pa[0], pwa); flat_load_b128(P.pa[1], pwa + 4);
         flat_load_b128(P.pb[0], pwb); flat_load_b128(P.pb[1], pwb + 4);
         // this lane's chunk of the next group
-        col += dq; rem += dr;
-        uint32_t jn = j_cur + dqj;
+        const bool wrap = slot_i + R >= G;                                   // (wave-uniform)
+        slot_i = wrap ? slot_i + R - G : slot_i + R;
+        col += wrap ? dq_w : dq; rem += wrap ? dr_w : dr;
+        uint32_t jn = j_cur + (wrap ? dqj_w : dqj);
         if (rem >= (unsigned)Ht) { rem -= (unsigned)Ht; col += 1; jn += 1; }
-        a_cur += dqa;
+        a_cur += wrap ? dqa_w : dqa;
         if (jn >= (unsigned)Wt) { jn -= (unsigned)Wt; a_cur += 1; }
         j_cur = jn;
     };
@@ -2812,11 +2824,13 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     int grp = 0;
     unsigned long long t_pause = __builtin_amdgcn_s_memrealtime();           // (a group's "pause": from the end of the previous group's stores to its own first)
 #endif
-    while (base + G * 64 < chunk_end) {                                      // (wave-uniform) there is a next group:
+    uint32_t slot = g;                                                       // the slot of the group at `base`
+    auto delta = [&](uint32_t sl) -> uint32_t { return G * 64 + R - (sl + R >= G ? G : 0u); };
+    while (base + delta(slot) < chunk_end) {                                 // (wave-uniform) there is a next group:
         // its loads go out now, ahead of this group's stores, and are awaited behind them — in one straight line, every
         // iteration, so that no register copy can come between a load and its wait (tools/check_async_loads.py)
         __builtin_amdgcn_wave_barrier();
-        issue(base + G * 64, P);
+        issue(base + delta(slot), P);
 #ifdef RCW_TRACE_WAVES
         {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -2832,7 +2846,8 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
         if (!stored_64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (fewer than 64 stores behind the loads: wait for everything; names no register)
         flat_wait_loads<63, K>(P);
         finish(P, state_l, rem_l);                                           // ... while this group's stores drain
-        base += G * 64;
+        base += delta(slot);
+        slot = slot + R >= G ? slot + R - G : slot + R;
     }
     __builtin_amdgcn_wave_barrier();
     store_group(base, state_l, rem_l);
