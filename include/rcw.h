@@ -345,7 +345,8 @@ RCW_API int rcw_timer_stop(rcw_handle* h, float* elapsed_ms);
  * cfg.render_top_view) and the fill kernel of each step (at most 256 steps are recorded).
  * rcw_profile_read returns their mean durations over the recorded steps (top_view_ms = 0 without it).
  * With the two-kernel top view (RCW_TOP_VIEW_TWO_KERNELS below) top_view_ms is its store kernel — the one that
- * writes the image; its draw kernel runs on a side stream beside the camera fill, inside fill_ms. */
+ * writes the image; its drawing runs inside the camera fill's launch (or, at camera heights other than 256 rows, on a
+ * side stream beside it): inside fill_ms. */
 RCW_API int rcw_profile(rcw_handle* h, int32_t enable);
 RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* fill_ms, int32_t* steps);
 
@@ -353,14 +354,16 @@ RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, 
  *   RCW_TOP_VIEW_NONE         cfg.render_top_view = 0
  *   RCW_TOP_VIEW_IN_PLACE     tiles, then lines and circle drawn over them in HBM (images beyond the LDS bit planes)
  *   RCW_TOP_VIEW_ONE_KERNEL   write-once: bit planes in LDS, draw and store groups of one persistent kernel
- *   RCW_TOP_VIEW_TWO_KERNELS  write-once, inside rcw_step / rcw_reset / rcw_set_state: draw kernel (bit planes -> HBM,
- *                             beside the camera fill), then the moving-window store kernel; rcw_update_top_view
- *                             alone takes the one-kernel form (except at pixel scales that are not a multiple of 4).
- *                             Geometries: H*pu a multiple of 256, 128 or 64 rows with pu_per_tu >= 8 dividing that
- *                             number and a player circle of <= 32 rows (rcw_top_store_kernel / _units_kernel), or any
- *                             pu_per_tu >= 9 with H*pu a multiple of 4 and >= 42 rows (rcw_top_store_flat_kernel);
- *                             batches of at least 256 MiB of top view a step (smaller ones: the one-kernel form is
- *                             faster) unless rcw_set_top_view_form asks for it */
+ *   RCW_TOP_VIEW_TWO_KERNELS  write-once, inside rcw_step / rcw_reset / rcw_set_state: the drawing (bit planes -> HBM) in the
+ *                             camera fill's own launch, then the moving-window store kernel; rcw_update_top_view alone
+ *                             takes the one-kernel form (except at pixel scales that are not a multiple of 4).
+ *                             Geometries: H*pu a multiple of 256 rows with pu_per_tu in {8, 16, ..., 256} and a player
+ *                             circle of <= 32 rows (rcw_top_store_kernel), any pu_per_tu >= 9 with H*pu a multiple of 4
+ *                             and >= 42 rows (rcw_top_store_flat_kernel), 8-pixel tiles with H*pu a multiple of 64 or 32
+ *                             (rcw_top_store_units_kernel).  Taken at every batch size where the camera view is 256
+ *                             rows high (one launch for fill + drawing); at other camera heights the drawing needs the
+ *                             handle's side stream, and the form is taken from 256 MiB of top view a step (below that
+ *                             the one-kernel form is faster) unless rcw_set_top_view_form asks for it */
 enum { RCW_TOP_VIEW_NONE = 0, RCW_TOP_VIEW_IN_PLACE = 1, RCW_TOP_VIEW_ONE_KERNEL = 2, RCW_TOP_VIEW_TWO_KERNELS = 3 };
 RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
 /* Choose the form instead of the rule above (all forms write the same pixels; this is a performance choice, e.g. the
