@@ -31,6 +31,13 @@ def oracle():
     from oracle import oracle as O
 
     O.build()
+    # OpenMP would start a thread per hardware thread of the HOST (hundreds on a GPU box) inside a CPU share of 16: a step of
+    # three agents then takes 100-200 ms in its barriers (measured, round 4) — most of the suite's time.  Sixteen at most.
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    O.set_num_threads(max(1, min(16, cpus)))
     return O
 
 

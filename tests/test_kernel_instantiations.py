@@ -146,3 +146,39 @@ def test_top_view_forms_under_every_unpinned_switch(rcw, oracle, T):
                 rcw.update_top_view_(env)
                 np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
                 env.close()
+
+
+@pytest.mark.gpu
+def test_top_view_planner_sweep(rcw, oracle):
+    """Every pixel scale from 8 to 40 on maps of 3, 4, 5, 7, 8 and 10 tile rows (198 geometries; whatever form the library's rule picks for each —
+    in-place, one kernel, units, flat, 256-row chunks — and the fused or side-stream drawing): two steps and a stand-alone redraw
+    against the oracle.  A systematic walk along the rule's boundaries, where the random fuzzers only sample."""
+    rng = np.random.default_rng(9)
+    forms = {}
+    for H in (3, 4, 5, 7, 8, 10):
+        for pu in range(8, 41):
+            env, orc = _make(rcw, oracle, 3, 15, out_of_bounds=1, render_top_view=True, pu_per_tu=pu, height_tile_map_tu=H, width_tile_map_tu=4, num_rays=24)
+            forms[env.top_view_form()] = forms.get(env.top_view_form(), 0) + 1
+            _steps(rcw, env, orc, rng, 2, True)
+            rcw.update_top_view_(env)
+            np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"H {H} pu {pu}")
+            env.close()
+    assert forms.get("two-kernels", 0) >= 80 and forms.get("one-kernel", 0) >= 80 and sum(forms.values()) == 198, forms
+
+
+@pytest.mark.gpu
+def test_camera_height_sweep(rcw, oracle):
+    """Every camera height from 1 to 72 rows and around the window kernels' heights (126-130, 254-258, 510-514): whatever kernel
+    the rule picks (frame per workgroup below 24 rows, the flat kernel with up to twelve columns a chunk, the moving window), two
+    steps and a masked reset against the oracle, at a column count (25) that leaves the batch's last chunk short."""
+    rng = np.random.default_rng(10)
+    names = {}
+    for hc in list(range(1, 73)) + [126, 127, 128, 129, 130, 254, 255, 256, 257, 258, 510, 511, 512, 513, 514]:
+        env, orc = _make(rcw, oracle, 3, 16, out_of_bounds=1, height_camera_view_pu=hc, height_tile_map_tu=6, width_tile_map_tu=7, num_rays=25)
+        names[env.fill_kernel_name()] = names.get(env.fill_kernel_name(), 0) + 1
+        _steps(rcw, env, orc, rng, 2, False)
+        mask = np.array([1, 0, 1], dtype=np.uint8)
+        rcw.reset_(env, mask=mask, seed=6); orc.reset(mask=mask, seed=6)
+        _steps(rcw, env, orc, rng, 1, False)
+        env.close()
+    assert set(names) == {"rcw_fill_frame_kernel", "rcw_fill_flat_kernel", "rcw_fill_window_kernel", "rcw_fill256_kernel"}, names
