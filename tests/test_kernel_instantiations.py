@@ -76,7 +76,7 @@ def _steps(rcw, env, orc, rng, n, top):
 
 def _make(rcw, oracle, batch, seed, **kw):
     env = rcw.SingleRoomModule.SingleRoom(batch=batch, seed=seed, **kw)
-    okw = {k: v for k, v in kw.items() if k not in ("T", "auto_reset")}
+    okw = {k: v for k, v in kw.items() if k not in ("T", "auto_reset", "library")}
     okw["auto_reset"] = 1 if kw.get("auto_reset") else 0
     if kw.get("T") == "Float64":
         okw["world_unit_bits"] = 64
@@ -182,3 +182,24 @@ def test_camera_height_sweep(rcw, oracle):
         _steps(rcw, env, orc, rng, 1, False)
         env.close()
     assert set(names) == {"rcw_fill_frame_kernel", "rcw_fill_flat_kernel", "rcw_fill_window_kernel", "rcw_fill256_kernel"}, names
+
+
+@pytest.mark.gpu
+def test_turning_assignment_under_any_grid(rcw, oracle, monkeypatch):
+    """rcw_top_store_flat_kernel's wavefront -> chunk assignment turns by 33 slots a group (DESIGN.md §4.4); the walk through a group's
+    slots wraps at the number of wavefronts, which follows the device's CU count: other grids (development build: RCW_TOP_STORE_GRID,
+    1 .. 257 workgroups, i.e. turns of 33 mod 4 .. 33 mod 1028) and other turns (RCW_TOP_ROTATE 0 / 5) write the same pixels."""
+    rng = np.random.default_rng(11)
+    for grid in ("1", "3", "33", "257"):
+        monkeypatch.setenv("RCW_TOP_STORE_GRID", grid)
+        for rot in ("33", "5", "0"):
+            monkeypatch.setenv("RCW_TOP_ROTATE", rot)
+            for (H, W, pu), batch in (((8, 8, 16), 300), ((8, 8, 13), 40), ((5, 4, 20), 700)):
+                env, orc = _make(rcw, oracle, batch, 17, auto_reset=True, out_of_bounds=1, render_top_view=True, pu_per_tu=pu,
+                                 height_tile_map_tu=H, width_tile_map_tu=W, num_rays=40, library="dev")
+                env.set_top_view_form("two-kernels")
+                _steps(rcw, env, orc, rng, 2, True)
+                mask = (rng.random(batch) < 0.5).astype(np.uint8)
+                rcw.reset_(env, mask=mask, seed=7); orc.reset(mask=mask, seed=7)
+                np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"grid {grid} turn {rot} {(H, W, pu)}")
+                env.close()
