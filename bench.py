@@ -16,8 +16,15 @@ roofline of the step kernel, HIP-event timed on the kernel's own stream; `traffi
 per launch from the PMC counters, measured by the run itself at N = 1: two short
 `rocprofv3 --pmc` passes of this script as child processes, after the timed region) and
 `cpu_baseline` (the CPU oracle — a C restatement of the reference, kind "port" — timed on
-this box's host cores on a bounded sample of the same workload).  A default run takes about a
-minute: ~12 s for the GPU part, ~25 s for the two counter passes, ~16 s for the CPU baseline.
+this box's host cores on a bounded sample of the same workload).  A default run takes 20-40 s:
+a few seconds for the GPU part, ~6-12 s each for the two counter passes (bounded at 60 s each; a pass
+that fails or runs out of time says so on stderr and the committed figure is used, labelled), ~15 s for
+the CPU baseline.
+
+N > 1: every rank stops its own clock after its own synchronisation — no collective inside the timed
+region —; the per-rank times are gathered afterwards, `value` uses the slowest rank (MAX), and the line
+carries `ms_per_step_min` / `ms_per_step_max` over ranks and `roofline.per_rank` (every rank's fill-kernel
+launch time), so that a straggling GPU shows.
 """
 import argparse
 import json
@@ -119,7 +126,29 @@ def being_profiled() -> bool:
     return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
-def live_traffic(workload, batch, kernel, seconds=150.0):
+def reduce_rank_times(rows, steps):
+    """rows[r] = (dt seconds, kernel_ms, cast_ms, fill_ms, top_ms) as rank r measured them with its OWN clock (stopped after
+    its own synchronisation).  The job's figures are the slowest rank's (MAX, what whole-job throughput is bound by); the
+    spread and every rank's fill-kernel launch time go into the line so that one slow GPU is visible."""
+    rows = [[float(v) for v in r] for r in rows]
+    mx = [max(r[k] for r in rows) for k in range(5)]
+    return {
+        "dt": mx[0], "kernel_ms": mx[1], "cast_ms": mx[2], "fill_ms": mx[3], "top_ms": mx[4],
+        "ms_per_step_min": min(r[0] for r in rows) * 1e3 / steps,
+        "ms_per_step_max": mx[0] * 1e3 / steps,
+        "per_rank": [{"rank": i, "ms_per_step": r[0] * 1e3 / steps, "launch_ms": r[3], "cast_ms": r[2],
+                      "step_kernels_ms": r[1] / steps} for i, r in enumerate(rows)],
+    }
+
+
+def top_view_scratch_bytes(H, W, pu, B):
+    """What the top view's drawing leaves in HBM for the store kernel, per launch: the ray-line bit plane (one bit a
+    pixel), the player's pixel (8 B an agent) and the 2-bit tile codes (8 B per tile column and 256-row run)."""
+    Ht, Wt = H * pu, W * pu
+    return B * (Ht * Wt // 8 + 8 + 8 * W * ((Ht + 255) // 256))
+
+
+def live_traffic(workload, batch, kernel, seconds=60.0, extra_args=()):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: this script again, a few steps, under
     rocprofv3 — WRITE_SIZE and FETCH_SIZE in separate passes (they do not fit one), `--pmc` with `--kernel-trace` only, as the
     guide's HBM section prescribes; KiB units; FETCH_SIZE doubled (gfx950 reports half of wide streaming reads: an upper bound
@@ -129,8 +158,11 @@ def live_traffic(workload, batch, kernel, seconds=150.0):
     import subprocess
     import tempfile
 
-    if shutil.which("rocprofv3") is None or being_profiled():
+    if shutil.which("rocprofv3") is None:
+        print("bench.py: roofline.traffic: no rocprofv3 on PATH; the committed figure (if any) is used", file=sys.stderr)
         return None
+    if being_profiled():
+        return None                                      # (a profiler's own run of this script: it measures what it came for)
     out = {}
     for counter in ("WRITE_SIZE", "FETCH_SIZE"):
         d = None
@@ -138,7 +170,7 @@ def live_traffic(workload, batch, kernel, seconds=150.0):
             d = tempfile.mkdtemp(prefix="rcw_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--traffic", "off",
-                   "--workload", workload, "--batch", str(batch)]
+                   "--workload", workload, "--batch", str(batch)] + list(extra_args)
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
             env["TMPDIR"] = "/tmp"
             # its own session: on a timeout the WHOLE group goes (rocprofv3 runs the program as its child; killing the
@@ -154,7 +186,14 @@ def live_traffic(workload, batch, kernel, seconds=150.0):
                 proc.wait()
                 rc = -9
             v = parse_pmc(d, counter, kernel) if rc == 0 else None
-        except Exception:   # noqa: BLE001 — a reported extra: never costs the bench line
+            if v is None:
+                why = (f"ran out of its {seconds:.0f} s" if rc == -9 else f"ended with exit code {rc}" if rc != 0
+                       else f"recorded no dispatch of {kernel}")
+                print(f"bench.py: roofline.traffic: the live rocprofv3 --pmc {counter} pass {why}; "
+                      f"the committed figure (if any) is used and labelled in traffic_source", file=sys.stderr)
+        except Exception as e:   # noqa: BLE001 — a reported extra: never costs the bench line
+            print(f"bench.py: roofline.traffic: the live rocprofv3 --pmc {counter} pass failed ({type(e).__name__}: {e}); "
+                  f"the committed figure (if any) is used and labelled in traffic_source", file=sys.stderr)
             v = None
         finally:
             if d:
@@ -296,9 +335,22 @@ def main():
             env.clear_error()
             return n
 
+    cpu_coll = args.rehearse_on_one_gpu              # gloo moves host tensors only
+
+    def gather_rows(values):
+        """Every rank's row of figures on every rank, [world][len(values)] (one all-gather, OUTSIDE every timed region)."""
+        if dist is None:
+            return [[float(v) for v in values]]
+        t = torch.tensor(values, dtype=torch.float64, device="cpu" if cpu_coll else "cuda")
+        allt = torch.empty((world, len(values)), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allt, t)
+        return allt.cpu().tolist()
+
     for s in range(args.warmup):
         RCW.act_(env, actions[s])
     sync_counting_bounds_errors()
+    torch.cuda.synchronize()
+    gather_rows([0.0])                               # one warm-up collective: the communicator is up before the clock starts
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -308,8 +360,8 @@ def main():
     kernel_ms = env.timer_stop()   # HIP events on the stream the kernels run on
     bounds_errors = sync_counting_bounds_errors()
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0  # this rank's own clock, stopped behind its own synchronisation: NO collective inside dt
     barrier()
-    dt = time.perf_counter() - t0
     # Outside the timed region: the same steps again with HIP events around each kernel, to
     # read the dominant (fill) kernel's own launch duration for the roofline block.
     nprof = min(args.steps, 200)
@@ -319,11 +371,9 @@ def main():
     cast_ms, top_ms, fill_ms, nrec = env.profile_read()
     env.profile(False)
     sync_counting_bounds_errors()
-    if dist is not None:
-        t = torch.tensor([dt, kernel_ms, cast_ms, fill_ms, top_ms], dtype=torch.float64,
-                         device="cpu" if args.rehearse_on_one_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms, cast_ms, fill_ms, top_ms = (float(v) for v in t)
+    # the ranks' own figures, gathered; the job's are the slowest rank's (MAX), the spread goes into the line
+    ranks = reduce_rank_times(gather_rows([dt, kernel_ms, cast_ms, fill_ms, top_ms]), args.steps)
+    dt, kernel_ms, cast_ms, fill_ms, top_ms = (ranks[k] for k in ("dt", "kernel_ms", "cast_ms", "fill_ms", "top_ms"))
     # Outside the timed region too (--api rlbase): the same steps through the verbs the reference's test drives
     # (test/runtests.jl:26-33), with a GPU-resident consumer: state(env) -> env(action) -> reward(env) -> is_terminated(env)
     # every step.  reward / is_terminated return the engine's own device arrays (refreshed in stream order), so the loop
@@ -356,12 +406,9 @@ def main():
         syncs = env.host_syncs - syncs0                               # (before the closing synchronisation below)
         bounds_api = sync_counting_bounds_errors()
         torch.cuda.synchronize()
+        dta = time.perf_counter() - t0a                               # (this rank's own clock, as above)
         barrier()
-        dta = time.perf_counter() - t0a
-        if dist is not None:
-            ta = torch.tensor([dta], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
-            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
-            dta = float(ta[0])
+        dta = max(r[0] for r in gather_rows([dta]))
         api_loop = {"loop": "RLBase.state -> env(action) -> RLBase.reward -> RLBase.is_terminated per step (test/runtests.jl:26-33), "
                             "reward / done consumed on the device (returns += reward; episodes += done)",
                     "value": world * B * args.steps / dta, "unit": "env-steps/s", "ms_per_step": dta * 1e3 / args.steps,
@@ -377,6 +424,15 @@ def main():
     def build_line(gather):
         frame_bytes = 4 * Hc * N                          # bytes per env-step
         bytes_per_launch = frame_bytes * B                # one fill launch = B agents
+        launch_note = None
+        if fill_kernel == "rcw_fill256_draw_kernel":
+            # --top-view, fused launch: the kernel between the two events is the camera fill AND the top view's drawing; what it
+            # writes is the frames plus the drawing's scratch for the store kernel
+            bytes_per_launch += top_view_scratch_bytes(kw["height_tile_map_tu"], kw["width_tile_map_tu"], top_pu, B)
+            launch_note = ("one launch = the camera fill (workgroups 0..255) + the top view's drawing (one workgroup per agent): bytes_per_launch = "
+                           "frames + bit planes + player pixels + tile codes; launch_ms covers both")
+        elif args.top_view and top_form == "two-kernels":
+            launch_note = "the top view's draw kernel runs on a side stream beside this launch and inside its launch_ms"
         fill_s = fill_ms / 1e3                            # dominant kernel, HIP events around it
         achieved = bytes_per_launch / fill_s / 1e9
         step_s = kernel_ms / 1e3 / args.steps             # cast + fill, events around the region
@@ -387,7 +443,7 @@ def main():
             traffic_source = (f"measured by this run: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes, --kernel-trace only) over 8 steps of "
                               f"this command; WRITE_SIZE {traffic_live['write_bytes']:.0f} B + 2 x FETCH_SIZE {traffic_live['fetch_bytes_raw']:.0f} B "
                               f"(gfx950 FETCH correction, an upper bound for narrow gathers) per launch of {fill_kernel}")
-        elif args.traffic != "off":
+        elif args.traffic != "off" and not args.top_view:      # (the committed figure is the plain camera fill's: never another kernel's)
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
@@ -407,6 +463,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps,
+            "ms_per_step_min": ranks["ms_per_step_min"],
+            "ms_per_step_max": ranks["ms_per_step_max"],
+            "timing": "per rank: barrier | clock | K steps | stream + device synchronised | clock; MAX over ranks afterwards (no collective inside the timed region)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -435,6 +494,7 @@ def main():
                 "bytes_per_launch": bytes_per_launch,
                 "launch_ms": fill_ms,
                 "launches_timed": nrec,
+                "per_rank": ranks["per_rank"],
                 "whole_step": {
                     "kernels": "rcw_cast_kernel + fill kernel",
                     "launch_ms": step_s * 1e3,
@@ -444,6 +504,8 @@ def main():
                 },
             },
         }
+        if launch_note:
+            out["roofline"]["launch_note"] = launch_note
         if gather is not None:
             out["gather"] = gather
         if args.top_view:
@@ -458,9 +520,11 @@ def main():
                 "bound": "hbm", "bytes_per_launch": top_bytes, "launch_ms": top_ms,
                 "achieved": top_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top_gbs / HBM_PEAK_GBS,
                 "note": "update_top_view! SR:446-483, 4*(H*pu)*(W*pu) bytes per agent written once; opt-in, not in `value` of the headline run"
-                        + ("; two-kernel form: launch_ms is the store kernel (the one that writes the image), the draw kernel "
-                           "(rcw_top_draw_kernel, VALU/LDS work, planes of 1/32 of the image) runs on a side stream beside the "
-                           "camera fill and is inside the fill's launch_ms — see profiles/ for its own duration" if form == "two-kernels" else ""),
+                        + ("; two-kernel form: launch_ms is the store kernel (the one that writes the image); the drawing (VALU/LDS work, "
+                           "planes of 1/32 of the image) " + ("rides in the camera fill's launch (rcw_fill256_draw_kernel, roofline.kernel)"
+                                                              if fill_kernel == "rcw_fill256_draw_kernel" else
+                                                              "is rcw_top_draw_kernel on a side stream beside the camera fill")
+                           + " and is inside roofline.launch_ms — see profiles/ for its own duration" if form == "two-kernels" else ""),
             }
         if api_loop is not None:
             out["api_loop"] = api_loop
@@ -563,8 +627,8 @@ def main():
         pending["what"] = "nothing (the gather is over)"
 
     if rank == 0:
-        if world == 1 and args.traffic == "live" and not args.top_view:
-            traffic_live = live_traffic(args.workload, B, fill_kernel)
+        if world == 1 and args.traffic == "live":
+            traffic_live = live_traffic(args.workload, B, fill_kernel, extra_args=["--top-view"] if args.top_view else [])
         out = build_line(gather)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, B)

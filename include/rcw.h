@@ -54,6 +54,11 @@ extern "C" {
                                         collision_detection.jl:35 or inside cast_ray)      */
 #define RCW_ERR_HIP              -6  /* any other HIP error; text in rcw_last_error()      */
 #define RCW_ERR_UNSUPPORTED      -7
+/* A per-agent status WARNING (rcw_status), not an error: no call fails on it and the handle's error word stays clear.
+ * sample_empty_position (utils.jl:23-37) gave up after max_tries = 1024*H*W occupied draws and reset!(world) placed the player
+ * on the last — occupied — tile drawn; the reference @warns there (utils.jl:34) and goes on.  Only a map without an empty tile
+ * (3x3: the one interior tile is the goal) gets here. */
+#define RCW_WARN_SAMPLER_GAVE_UP  1
 
 /* ---- objects, actions (SR:16-19) --------------------------------------------------- */
 #define RCW_NUM_OBJECTS 2
@@ -272,8 +277,9 @@ RCW_API int rcw_position(rcw_handle* h, float* out_host /* (2, B) */);
 RCW_API int rcw_direction(rcw_handle* h, int32_t* out_host /* (B) */);
 RCW_API int rcw_goal(rcw_handle* h, int32_t* out_host /* (2, B), 1-based */);
 RCW_API int rcw_episode(rcw_handle* h, uint32_t* out_host /* (B): resets seen by each agent */);
-/* Per-agent sticky status: 0, RCW_ERR_OUT_OF_BOUNDS (see RCW_OOB_ERROR) or
- * RCW_ERR_INVALID_ACTION (rcw_step_device).  Does not fail on a set error word, so it can
+/* Per-agent sticky status: 0, RCW_ERR_OUT_OF_BOUNDS (see RCW_OOB_ERROR),
+ * RCW_ERR_INVALID_ACTION (rcw_step_device) or — a warning, where no error is recorded —
+ * RCW_WARN_SAMPLER_GAVE_UP (utils.jl:34).  Does not fail on a set error word, so it can
  * be used to find the faulting agents. */
 RCW_API int rcw_status(rcw_handle* h, int32_t* out_host /* (B) */);
 /* world.tile_map SR:22 as BitArray{3}(2, H, W).chunks per agent: UInt64 (nchunks, B),
@@ -374,8 +380,10 @@ RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
  * scratch in HBM.  The library reads no environment variable other than RCW_RCCL_LIBRARY: what used to be development
  * switches (RCW_TOP_SPLIT, RCW_TOP_RUNS, ...) exists only in the development build (make dev -> librcw_hip_dev.so). */
 RCW_API int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs);
-/* The kernel update_camera_view! (SR:374-444) takes for this handle's camera height and batch (what bench.py labels its
- * roofline block with): "rcw_fill256_kernel", "rcw_fill_window_kernel", "rcw_fill_flat_kernel", ... */
+/* The kernel update_camera_view! (SR:374-444) runs in INSIDE A STEP of this handle (what bench.py labels its roofline block
+ * with): "rcw_fill256_kernel", "rcw_fill_window_kernel", "rcw_fill_flat_kernel", ... by camera height and batch — and
+ * "rcw_fill256_draw_kernel" where the handle also renders the top view and the camera fill and the top view's drawing go in
+ * one launch (rcw_update_camera_view alone always takes the plain fill kernel). */
 RCW_API int rcw_fill_kernel_name(rcw_handle* h, char* buf, int32_t buflen);
 
 /* Introspection */

@@ -313,7 +313,8 @@ function episode(env::BatchedSingleRoom)
     out = Vector{UInt32}(undef, env.batch)
     check(ccall((:rcw_episode, librcw), Cint, (Ptr{Cvoid}, Ptr{UInt32}), env.handle, out)); out
 end
-# per-agent sticky status: 0, -5 where the reference would have raised BoundsError, -2 for an invalid device action
+# per-agent sticky status: 0, -5 where the reference would have raised BoundsError, -2 for an invalid device action,
+# 1 (a warning) where sample_empty_position gave up after max_tries and returned an occupied tile (utils.jl:34 @warns there)
 function status(env::BatchedSingleRoom)
     out = Vector{Int32}(undef, env.batch)
     check(ccall((:rcw_status, librcw), Cint, (Ptr{Cvoid}, Ptr{Int32}), env.handle, out)); out

@@ -457,10 +457,13 @@ static void orc_reset_agent(orc_batch* b, int32_t a, uint64_t seed)
     /* sample_empty_position(rng, tile_map)  UT:52-58 -> UT:23-37 */
     const uint64_t max_tries = (uint64_t)1024 * H * W;
     uint64_t lin = orc_below(orc_draw(key, n++), (uint64_t)HW);      /* UT:24 */
+    int gave_up = 1;
     for (uint64_t t = 0; t < max_tries; ++t) {                       /* UT:26 */
         if (wm[lin] | gm[lin]) lin = orc_below(orc_draw(key, n++), (uint64_t)HW); /* UT:27-28 */
-        else break;
+        else { gave_up = 0; break; }
     }
+    /* UT:34 "@warn Could not sample an empty position in max_tries ... Returning non-empty position": the reference goes on */
+    if (gave_up && b->status[a] == 0) b->status[a] = RCW_WARN_SAMPLER_GAVE_UP;
     const int32_t pi = (int32_t)(lin % (uint64_t)H) + 1, pj = (int32_t)(lin / (uint64_t)H) + 1;
     b->pos[2 * a] = (real)((double)pi - 0.5);                       /* SR:125 */
     b->pos[2 * a + 1] = (real)((double)pj - 0.5);

@@ -20,6 +20,7 @@ RCW_ERR_OUT_OF_MEMORY = -4
 RCW_ERR_OUT_OF_BOUNDS = -5
 RCW_ERR_HIP = -6
 RCW_ERR_UNSUPPORTED = -7
+RCW_WARN_SAMPLER_GAVE_UP = 1      # a per-agent status WARNING (utils.jl:34), not an error
 RCW_ABI_VERSION = 4
 
 # R of SingleRoom(; R = ...) SR:266 (include/rcw.h RCW_REWARD_*)

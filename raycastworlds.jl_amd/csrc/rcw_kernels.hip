@@ -191,11 +191,15 @@ __device__ __forceinline__ Pose<T> reset_agent(const RcwDev& p, int a, uint32_t*
     const uint64_t HW = (uint64_t)H * (uint64_t)W;
     const uint64_t max_tries = 1024ull * HW;
     uint64_t lin = rcw_below(rcw_draw(key, n++), HW);                          // UT:24
+    bool gave_up = true;
     for (uint64_t t = 0; t < max_tries; ++t) {                                 // UT:26
         const int ti = (int)(lin % (uint64_t)H) + 1, tj = (int)(lin / (uint64_t)H) + 1;
         if (tile_bits(tm_a, H, ti, tj)) lin = rcw_below(rcw_draw(key, n++), HW);   // UT:27-28
-        else break;
+        else { gave_up = false; break; }
     }
+    // UT:34: "@warn Could not sample an empty position in max_tries ... Returning non-empty position" — the reference goes on
+    // with the occupied tile; so does the engine, and says so in the agent's status word (a warning: no error word, no call fails)
+    if (gave_up && p.status[a] == 0) p.status[a] = RCW_WARN_SAMPLER_GAVE_UP;
     const int pi = (int)(lin % (uint64_t)H) + 1, pj = (int)(lin / (uint64_t)H) + 1;
     Pose<T> o;
     o.x = (T)((double)pi - 0.5);                                              // SR:125
@@ -2901,6 +2905,8 @@ const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols)
 #ifdef RCW_DEV_SWITCHES
     if (p.step_fused && total_cols == (long long)p.B * p.N && rcw_step_fusable(p)) return "rcw_step256_kernel";
 #endif
+    // a step that also renders the top view in the fused form: the camera fill of the whole batch and the drawing are ONE launch
+    if (p.top_view && p.top_split && p.top_fused && total_cols == (long long)p.B * p.N) return "rcw_fill256_draw_kernel";
     switch (fill_choice(p, total_cols)) {
     case kFill256: return "rcw_fill256_kernel";
     case kFillWindow1: case kFillWindow2: case kFillWindow4: return "rcw_fill_window_kernel";

@@ -76,17 +76,18 @@ class ShardedSingleRoom:
     def __init__(self, global_batch: int, *, rank: Optional[int] = None, world: Optional[int] = None,
                  group=None, device: Optional[int] = None, env_factory: Optional[Callable] = None,
                  collective: str = "auto", **kwargs):
-        import torch.distributed as dist
-
         if collective not in ("auto", "always"):
             raise ValueError(f"collective must be 'auto' or 'always', not {collective!r}")
-        self._dist = dist
         self.group = group
         self.collective = collective
-        if world is None:
-            world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if rank is None:
-            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # torch.distributed is asked only for what the caller did not say: with `rank` and `world` given (and the library
+        # transport's unique id brought by the caller, comm_init_abi) a host without torch shards and gathers all the same
+        if world is None or rank is None:
+            dist = self._dist
+            if world is None:
+                world = dist.get_world_size(group) if dist.is_initialized() else 1
+            if rank is None:
+                rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world, self.rank = int(world), int(rank)
         self.global_batch = int(global_batch)
         self.first, self.count = shard_range(self.global_batch, self.world, self.rank)
@@ -103,6 +104,12 @@ class ShardedSingleRoom:
             from .single_room import _reset_from_rng
 
             _reset_from_rng(self.env, self.rng, None, construction=True, first=self.first, global_batch=self.global_batch)
+
+    @property
+    def _dist(self):
+        import torch.distributed as dist                  # (on first use: the torch transport, or a rank / world left to it)
+
+        return dist
 
     # ---- stepping: purely local ------------------------------------------------------
     def local_slice(self, global_array):
@@ -210,9 +217,7 @@ class ShardedSingleRoom:
 
         `unique_id`: the 128 bytes of `make_unique_id()` brought here by the CALLER's own transport (MPI, a file, a socket:
         what a host without torch.distributed does — and how several ranks can live in one process, one engine each,
-        where torch.distributed's ranks are processes)."""
-        import torch
-
+        where torch.distributed's ranks are processes).  That path imports no torch."""
         from . import _capi
 
         if self._abi_comm:
@@ -230,6 +235,8 @@ class ShardedSingleRoom:
         if self.rank == 0:
             self.env._check(lib.rcw_comm_unique_id(uid))
         if self.world > 1:
+            import torch                                  # (only the torch.distributed hand-over needs it)
+
             t = torch.tensor(list(uid), dtype=torch.uint8)
             backend = self._dist.get_backend(self.group)
             if backend == "nccl":

@@ -275,7 +275,8 @@ class SingleRoomWorld:
 
     @property
     def status(self) -> np.ndarray:
-        """Per-agent sticky status: 0, or -5 where the reference would have raised BoundsError."""
+        """Per-agent sticky status: 0, -5 where the reference would have raised BoundsError, -2 for an invalid device action, or the
+        warning 1 (`RCW_WARN_SAMPLER_GAVE_UP`) where `sample_empty_position` found no empty tile and gave up (utils.jl:34)."""
         return self._get(self._env._lib.rcw_status, np.int32, (self._env.batch,))
 
     @property
@@ -773,6 +774,11 @@ def reference_reset_draws(rng, H: int, W: int, nd: int, old_goal=None):
             lin = int(rng.integers(0, H * W))        # UT:28
         else:
             break
+    else:                                            # UT:34 (@warn, then the occupied tile is returned)
+        import warnings
+
+        warnings.warn(f"Could not sample an empty position in max_tries = {1024 * H * W}. "
+                      f"Returning non-empty position: ({lin % H + 1}, {lin // H + 1})", RuntimeWarning, stacklevel=2)
     d = int(rng.integers(0, nd))                     # 0 : nd - 1
     return gi, gj, lin % H + 1, lin // H + 1, d
 
@@ -939,5 +945,9 @@ def wu_to_pu(x_wu, pu_per_wu) -> int:
 
 
 def pu_to_tu(i_pu: int, pu_per_tu: int) -> int:
-    """utils.jl:7: the (1-based) tile of a (1-based) pixel."""
-    return (int(i_pu) - 1) // int(pu_per_tu) + 1
+    """utils.jl:7: the (1-based) tile of a (1-based) pixel, `(i_pu - 1) ÷ pu_per_tu + 1`.  Julia's `÷` truncates toward zero
+    (Python's `//` floors): for a pixel off the image's low edge, i_pu <= 0, the two differ — pixel 0 at 32 pixels a tile is
+    tile 1 in the reference, not tile 0."""
+    n, d = int(i_pu) - 1, int(pu_per_tu)
+    q = abs(n) // abs(d)
+    return (q if (n < 0) == (d < 0) else -q) + 1

@@ -67,3 +67,42 @@ def test_pmc_parser_sums_xcds_and_averages_dispatches(tmp_path):
     assert bench.parse_pmc(str(tmp_path), "WRITE_SIZE", "rcw_cast") == 5.0
     assert bench.parse_pmc(str(tmp_path), "FETCH_SIZE", "rcw_fill256_kernel") is None
     assert bench.parse_pmc(str(tmp_path / "nowhere"), "WRITE_SIZE", "rcw_") is None
+
+
+def test_rank_times_are_reduced_after_the_clock_and_keep_the_spread():
+    """with N > 1 every rank stops its own clock behind its own synchronisation; the job's time is the
+    slowest rank's (MAX) and the line keeps the spread and every rank's fill-kernel launch time, so a straggling GPU shows."""
+    bench = _bench()
+    rows = [(3.4e-3, 3.30, 0.011, 0.156, 0.0), (3.9e-3, 3.80, 0.012, 0.181, 0.0), (3.5e-3, 3.35, 0.011, 0.157, 0.0)]
+    r = bench.reduce_rank_times(rows, steps=20)
+    assert r["dt"] == 3.9e-3 and r["kernel_ms"] == 3.80 and r["fill_ms"] == 0.181 and r["cast_ms"] == 0.012
+    assert abs(r["ms_per_step_min"] - 0.17) < 1e-12 and abs(r["ms_per_step_max"] - 0.195) < 1e-12
+    assert [p["rank"] for p in r["per_rank"]] == [0, 1, 2]
+    assert [p["launch_ms"] for p in r["per_rank"]] == [0.156, 0.181, 0.157]            # rank 1 is the slow GPU, and it shows
+    json.dumps(r)
+    one = bench.reduce_rank_times([(1.0, 2.0, 3.0, 4.0, 5.0)], steps=10)
+    assert one["ms_per_step_min"] == one["ms_per_step_max"] == 100.0 and len(one["per_rank"]) == 1
+
+
+def test_no_collective_inside_the_timed_regions():
+    """The source of bench.py between a clock's start and its stop holds no barrier, all-reduce or all-gather (the closing
+    barrier comes AFTER the clock has stopped; one warm-up collective comes before it starts)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for start, stop in (("t0 = time.perf_counter()", "dt = time.perf_counter() - t0  # this rank's own clock"), ("t0a = time.perf_counter()", "dta = time.perf_counter() - t0a")):
+        b = src.index(stop)
+        a = src.rindex(start, 0, b)
+        region = src[a:b]
+        for word in ("barrier(", "all_reduce", "all_gather", "gather_rows", "dist."):
+            assert word not in region, (word, start)
+        assert "torch.cuda.synchronize()" in region                  # the rank's own synchronisation is inside
+        assert "barrier()" in src[b:b + 400]                          # ... and the barrier right behind the stop
+    warm = src.index("gather_rows([0.0])")
+    assert warm < src.index("t0 = time.perf_counter()", warm) < src.index("dt = time.perf_counter() - t0  # this rank's own clock")
+
+
+def test_top_view_scratch_bytes_of_the_fused_launch():
+    """bench.py --top-view: the fused launch writes the frames AND the drawing's scratch; 8x8 tiles of 32 px, 4096 agents: 8 KiB of
+    plane + 8 B + 8 tile columns x 8 B an agent."""
+    bench = _bench()
+    assert bench.top_view_scratch_bytes(8, 8, 32, 4096) == 4096 * (8192 + 8 + 64)
+    assert bench.top_view_scratch_bytes(8, 16, 32, 1) == 256 * 512 // 8 + 8 + 8 * 16

@@ -55,5 +55,16 @@ def test_bench_modes(flags):
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "env-steps/s" and d["dtype"] == "f32"
     assert 0.3 < d["roofline"]["frac"] < 1.0, d["roofline"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["ms_per_step_min"] == d["ms_per_step_max"] == d["ms_per_step"] and len(d["roofline"]["per_rank"]) == 1   # one rank: no spread
+    if flags == ["--top-view"]:
+        # the block names the kernel that RAN between the two events (camera fill + drawing in one launch),
+        # with that launch's bytes (frames + the drawing's scratch) — never the plain fill's label or its committed traffic figure
+        r = d["roofline"]
+        assert r["kernel"] == "rcw_fill256_draw_kernel" and "launch_note" in r
+        assert r["bytes_per_launch"] == 4 * 256 * 256 * 4096 + 4096 * (8192 + 8 + 64)
+        assert r["traffic"] is None and r["traffic_source"] is None          # (--traffic off here; live it is this kernel's own)
+        assert d["top_view"]["form"] == "two-kernels" and 0.3 < d["top_view"]["frac"] < 1.0
+    else:
+        assert d["roofline"]["kernel"] != "rcw_fill256_draw_kernel" and "launch_note" not in d["roofline"]
     if flags == ["--gather"]:
         assert "gather" in d and "error" not in d["gather"], d.get("gather")

@@ -291,6 +291,31 @@ def test_reference_bounds_error_quirk(rcw, oracle):
     env.close()
 
 
+def test_sampler_give_up_status_bit(rcw, oracle):
+    """utils.jl:34: on a map without an empty tile (3 x 3: the one interior tile is the goal) `sample_empty_position` exhausts its
+    1024 H W tries, @warns and returns the occupied tile; the engine's reset does the same 9,216 draws, goes on, and records the
+    warning RCW_WARN_SAMPLER_GAVE_UP in the agent's status word — no error word, no call fails.  State, status words and frames
+    against the oracle at construction, after a masked reset and through steps (a start inside an obstacle: every ray ends at once)."""
+    _capi = rcw.SingleRoomModule._capi
+    env, orc = _make(rcw, oracle, 6, seed=4, height_tile_map_tu=3, width_tile_map_tu=3, num_rays=16, out_of_bounds=1)
+    env.sync()                                                           # a warning is no error
+    np.testing.assert_array_equal(env.world.status, orc.status)
+    assert (env.world.status == _capi.RCW_WARN_SAMPLER_GAVE_UP).all()
+    assert_state_equal(env, orc, rays=True, where="3x3 create")
+    env.clear_error(); orc.clear_status()
+    mask = np.array([1, 0, 1, 0, 0, 1], np.uint8)
+    rcw.reset_(env, mask, seed=9); orc.reset(mask=mask, seed=9)
+    env.sync()
+    np.testing.assert_array_equal(env.world.status, orc.status)
+    assert list(env.world.status) == [1, 0, 1, 0, 0, 1]
+    _rollout(rcw, env, orc, 6, np.random.default_rng(2), rays_every=2)
+    np.testing.assert_array_equal(env.world.status, orc.status)
+    env.close()
+    env, orc = _make(rcw, oracle, 6, seed=4, height_tile_map_tu=4, width_tile_map_tu=3, num_rays=16)   # two interior tiles: one stays empty
+    assert (env.world.status == 0).all() and (orc.status == 0).all()
+    env.close()
+
+
 def test_non_default_parameters(rcw, oracle):
     """Odd sizes and non-default kwargs of SingleRoom(; ...) SR:258-272: non-square map, N not a
     multiple of 64, other num_directions / fov / radius / increment / camera height."""

@@ -136,6 +136,13 @@ def test_bench_rehearsal_with_four_ranks(rcw, tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 4 * 4096 and out["steps"] == 5 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out          # rank 0 at N = 1 only
+    # every rank's own clock, reduced afterwards: the slowest rank is the job's time, the spread and every rank's fill-kernel
+    # launch time are in the line
+    assert out["ms_per_step"] == out["ms_per_step_max"] >= out["ms_per_step_min"] > 0 and "no collective inside the timed region" in out["timing"]
+    per = out["roofline"]["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1, 2, 3] and all(p["launch_ms"] > 0 and p["ms_per_step"] > 0 for p in per)
+    assert max(p["ms_per_step"] for p in per) == out["ms_per_step_max"] and min(p["ms_per_step"] for p in per) == out["ms_per_step_min"]
+    assert out["roofline"]["launch_ms"] == max(p["launch_ms"] for p in per)
     g = out["gather"]
     assert "error" not in g and g["ranks"] == 4 and g["columns_us"] > 0 and g["frames_us"] > 0 and "rehearsal" in g
 

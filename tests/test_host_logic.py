@@ -557,3 +557,111 @@ def test_action_keys_names_and_unit_helpers():
     assert RCW.wu_to_pu(np.float32(0.1), 10) == 2                                                   # Float32: 0.1f0 * 10 == 1.0f0 exactly
     assert RCW.wu_to_pu(0.1 * 3, 10) == int(np.floor(0.1 * 3 * 10)) + 1
     assert [RCW.pu_to_tu(i, 32) for i in (1, 32, 33, 256)] == [1, 1, 2, 8]                          # (i - 1) ÷ pu + 1
+    # Julia's ÷ truncates toward zero (Python's // floors): pixels off the image's low edge — e.g. the player circle near the border
+    assert [RCW.pu_to_tu(i, 32) for i in (0, -1, -30, -31, -32, -63, -64)] == [1, 1, 1, 0, 0, -1, -1]
+    assert [RCW.pu_to_tu(i, 10) for i in (0, -8, -9, -10)] == [1, 1, 0, 0]
+
+
+def test_comm_init_with_a_callers_unique_id_imports_no_torch():
+    """`comm_init_abi(unique_id=...)` is the path of hosts WITHOUT torch.distributed (and of several ranks in one
+    process); it must not import torch.  Checked in a child interpreter in which importing torch fails, against an engine double."""
+    import os
+    import subprocess
+    import sys
+
+    prog = r'''
+import sys, types
+class _Block:
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" or name.startswith("torch."):
+            raise ImportError("torch is not installed on this host")
+sys.meta_path.insert(0, _Block())
+sys.path.insert(0, %r)
+import raycastworlds_jl_amd as RCW
+from raycastworlds_jl_amd import _capi, sharded
+calls = []
+class Lib:
+    def rcw_comm_init(self, h, uid, rank, world):
+        calls.append((bytes(uid), rank, world)); return 0
+class Env:
+    def __init__(self, *a, **k): self._lib, self._h = Lib(), None
+    def _check(self, rc): assert rc == 0
+_capi.preload_rccl = lambda: None
+s = sharded.ShardedSingleRoom(8, rank=1, world=2, env_factory=Env)
+s.comm_init_abi(unique_id=bytes(range(128)))
+assert calls == [(bytes(range(128)), 1, 2)], calls
+assert "torch" not in sys.modules
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip() == "ok", res.stdout + res.stderr
+
+
+def test_turning_chunk_assignment_replayed_against_plain_division():
+    """ADVICE round 4: rcw_top_store_flat_kernel's wavefront -> chunk assignment TURNS from group to group (slot (g + k R) mod G of
+    group k) and carries every lane's (agent, image column, row) from group to group with two step sets — (dq, dr) and, where the
+    slot wraps past G, (dq_w, dr_w) — instead of dividing.  Replayed here statement by statement (rcw_kernels.hip, `issue` and the
+    main loop) for random grids, turns, image shapes and chunk ranges, including a short last group and turns >= G: every carried
+    value equals the plain division of the chunk's first pixel, every chunk of the range is taken exactly once, and everything
+    stays inside 32 bits."""
+    rng = np.random.default_rng(5)
+    cases = [(1024, 33, 128, 128, 0, 16384 * 64), (1024, 33, 80, 80, 0, 5000), (8, 3, 44, 52, 7, 999), (4, 4, 100, 60, 0, 700), (12, 64, 48, 48, 3, 2000)]
+    for _ in range(60):
+        G = int(rng.integers(1, 65)) * int(rng.choice([1, 4]))
+        Ht = 4 * int(rng.integers(11, 200)); Wt = int(rng.integers(40, 300))
+        c0 = int(rng.integers(0, 300)); c1 = c0 + int(rng.integers(1, 64 * G * 6))
+        cases.append((G, int(rng.integers(0, 3 * G + 2)), Ht, Wt, c0, c1))
+    for G, rotate, Ht, Wt, chunk_begin, chunk_end in cases:
+        R = rotate % G
+        step_px = (G * 64 + R) * 256
+        step_px_w = step_px - G * 256
+        dq, dr = divmod(step_px, Ht)
+        dq_w, dr_w = divmod(step_px_w, Ht)
+        dqa, dqj = divmod(dq, Wt)
+        dqa_w, dqj_w = divmod(dq_w, Wt)
+        if G > 64 and chunk_end > 100000:
+            waves, lanes = [0, 1, G // 2, G - 1], [0, 1, 31, 63]          # (the full-size case: a sample; coverage is checked on the small ones)
+        else:
+            waves, lanes = range(G), range(64)
+        seen = {}
+        for g in waves:
+            for lane in lanes:
+                id0 = chunk_begin + g + lane * G
+                col, rem = divmod(id0 * 256, Ht)
+                a_cur, j_cur = divmod(col, Wt)
+                slot_i = g
+                state = dict(col=col, rem=rem, a=a_cur, j=j_cur, slot=slot_i)
+
+                def issue(base, st=state, lane=lane):
+                    ident = base + lane * G
+                    want_col, want_rem = divmod(ident * 256, Ht)
+                    assert (st["col"], st["rem"]) == (want_col, want_rem), (G, R, Ht, Wt, g, lane, base)
+                    assert (st["a"], st["j"]) == divmod(want_col, Wt)
+                    assert max(st["col"], ident, st["a"]) < 2 ** 32 and st["rem"] % 4 == 0
+                    if ident < chunk_end:
+                        seen[ident] = seen.get(ident, 0) + 1
+                    wrap = st["slot"] + R >= G
+                    st["slot"] = st["slot"] + R - G if wrap else st["slot"] + R
+                    st["col"] += dq_w if wrap else dq
+                    st["rem"] += dr_w if wrap else dr
+                    jn = st["j"] + (dqj_w if wrap else dqj)
+                    if st["rem"] >= Ht:
+                        st["rem"] -= Ht; st["col"] += 1; jn += 1
+                    st["a"] += dqa_w if wrap else dqa
+                    if jn >= Wt:
+                        jn -= Wt; st["a"] += 1
+                    assert jn < Wt
+                    st["j"] = jn
+
+                base, slot = chunk_begin + g, g
+                if base >= chunk_end:
+                    continue
+                issue(base)
+                delta = lambda sl: G * 64 + R - (G if sl + R >= G else 0)          # noqa: E731
+                while base + delta(slot) < chunk_end:
+                    issue(base + delta(slot))
+                    base += delta(slot)
+                    slot = slot + R - G if slot + R >= G else slot + R
+                    assert (base - chunk_begin) % (G * 64) == slot                 # group k's slot, in the compact window of group k
+        if waves.__class__ is range:
+            assert sorted(seen) == list(range(chunk_begin, chunk_end)) and set(seen.values()) == {1}, (G, R, Ht, Wt, chunk_begin, chunk_end)

@@ -117,3 +117,29 @@ def test_rlbase_random_policy_invariants(rcw):
                 break
     assert terminated > 0, "no agent out of 256 reached the goal in 5 x 800 random steps"
     env.env.close()
+
+
+def test_sampler_gives_up_on_a_map_without_an_empty_tile(oracle):
+    """utils.jl:23-37: after max_tries = 1024 H W occupied draws `sample_empty_position` @warns (utils.jl:34) and returns the occupied
+    tile; reset! goes on with it.  Only a map with no empty tile gets there — 3 x 3: the one interior tile is the goal.  The oracle
+    (and the engine: test_gpu_parity.py::test_sampler_give_up_status_bit) records it as the WARNING 1 in the agent's status word; the
+    mirror's host draws (`rng` keyword) warn like the reference.  A 4 x 4 map has empty tiles: no warning."""
+    import warnings
+
+    import raycastworlds_jl_amd as RCW
+    from raycastworlds_jl_amd import _capi
+
+    orc = oracle.OracleBatch(4, seed=1, height_tile_map_tu=3, width_tile_map_tu=3, num_rays=8)
+    assert (orc.status == _capi.RCW_WARN_SAMPLER_GAVE_UP).all() and (orc.goal == 2).all()
+    frac = orc.position - np.floor(orc.position)
+    assert (frac == 0.5).all()                                            # placed on a tile centre all the same (SR:125)
+    orc.close()
+    orc = oracle.OracleBatch(4, seed=1, height_tile_map_tu=4, width_tile_map_tu=4, num_rays=8)
+    assert (orc.status == 0).all()
+    orc.close()
+    with pytest.warns(RuntimeWarning, match="Could not sample an empty position in max_tries = 9216"):
+        gi, gj, ti, tj, d = RCW.SingleRoomModule.reference_reset_draws(np.random.default_rng(0), 3, 3, 128)
+    assert (gi, gj) == (2, 2) and 1 <= ti <= 3 and 1 <= tj <= 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        RCW.SingleRoomModule.reference_reset_draws(np.random.default_rng(0), 4, 4, 128)
