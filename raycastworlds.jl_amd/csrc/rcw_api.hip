@@ -415,7 +415,7 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top
     // view in a step with 256 / 512 / 1024 threads: 512² px, 256 rays 180 / 182 / 200; 768² px 212 / 200 / 203; 1024² px, 1024 rays 357 / 265 / 216)
     if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > 64 * 1024) { const int b = ((N + 255) / 256) * 256; d.top_draw_block = b < 512 ? 512 : (b > 1024 ? 1024 : b); }
-    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = b; }
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = b; }
     // runs of agents: where the lines are long against the camera image's columns ((Ht + Wt) / 2 >= 1.75 H_cam) the drawing
     // does not fit beside the camera fill; with several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside
     // the storing of earlier runs.  Measured (µs a step with 1 / 2 / 4 / 8 runs): 16×16 map, 512 rays, 16,384 agents (16 GiB of
@@ -805,6 +805,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
+    d.top_draw_r4 = 0;
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW")) d.top_draw_r4 = std::strcmp(v, "r4") == 0 ? 1 : 0;
     d.top_rotate = 33;                                                       // (measured: rcw_kernels.hip, rcw_top_store_flat_kernel)
     if (const char* v = RCW_DEV_ENV("RCW_TOP_ROTATE")) { const int r = std::atoi(v); if (r >= 0 && r < 65536) d.top_rotate = r; }
     d.fill_trips = -1;

@@ -1709,6 +1709,21 @@ __device__ __forceinline__ void top_prepare(const RcwDev& p, int a, const TopBuf
     for (int k = tid; k < nz; k += group) z[k] = zero;
 }
 
+#ifdef RCW_TRACE_WAVES
+// Measurement build only (tools/draw_trace.py): the first wavefront of the draw workgroups of agents 0..2047 leaves s_memrealtime at
+// entry | planes cleared, barrier | rays cast, lines set up | lines walked | barrier | planes copied out and acknowledged, and where it ran
+__device__ unsigned long long g_draw_trace[2048 * 20];
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int rcw_draw_trace_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_draw_trace), sizeof(unsigned long long) * 2048 * 20);
+}
+namespace {
+#define RCW_DRAW_STAMP(k) do { if (tid == 0 && a < 2048) g_draw_trace[a * 20 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RCW_DRAW_STAMP(k) do { } while (0)
+#endif
+
 // draw group, second half: one line per ray from the player to the ray's stop point (SR:473-477) and the player
 template <typename T, bool TIE_LE, bool DIST_PRE>
 __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b, int tid, bool with_circle = true, int group = kTopGroup)
@@ -1791,6 +1806,10 @@ __device__ __forceinline__ void top_draw(const RcwDev& p, int a, const TopBuf& b
         for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
         nmax = __builtin_amdgcn_readfirstlane(nmax);                         // (the trip count is the wavefront's longest segment: a scalar loop)
         char* const plane = reinterpret_cast<char*>(b.line);
+        if (i0 == 0) { RCW_DRAW_STAMP(2); }
+#ifdef RCW_TRACE_WAVES
+        if (i0 == 0 && tid == 0 && a < 2048) g_draw_trace[a * 20 + 8] = (unsigned long long)nmax;
+#endif
         for (int k = 0; k < nmax; ++k) {
             uint32_t* const w = reinterpret_cast<uint32_t*>(plane + (((unsigned)addr >> 3) & ~3u));
             __hip_atomic_fetch_or(w, 1u << (addr & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2066,19 +2085,25 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
 // quarters of one: pu in {8, 16, 32, 64, 128, 256}, H·pu a multiple of 256; and the player's circle fits one
 // 32-bit mask per image column (2·rp + 1 <= 32).  Other geometries keep the ring kernel.
 //
+#ifdef RCW_DEV_SWITCHES
+// ---- the ROUND-4 draw body (development build only, RCW_TOP_DRAW=r4): for the comparison with top_draw_body below ----
 // Draw kernel: one workgroup per agent; what the draw group of the ring kernel does, then the line plane is copied
 // out unpadded, with the player's pixel (SR:468) and, per (tile column, row block), the 2-bit fill codes of the
 // chunk's tiles packed into 64 bits.
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __restrict__ mask, int a, uint32_t* lds)
+__device__ __forceinline__ void top_draw_body_r4(const RcwDev& p, const uint8_t* __restrict__ mask, int a, uint32_t* lds)
 {
     const int tid = threadIdx.x, group = blockDim.x;                          // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
     if (mask != nullptr && mask[a] == 0) return;                             // workgroup-uniform
     const TopBuf b = top_buf(p, lds);
+    RCW_DRAW_STAMP(0);
     top_prepare(p, a, b, tid, group);
     __syncthreads();
+    RCW_DRAW_STAMP(1);
     top_draw<T, TIE_LE, DIST_PRE>(p, a, b, tid, false, group);
+    RCW_DRAW_STAMP(3);
     __syncthreads();
+    RCW_DRAW_STAMP(4);
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu;
     if (tid == 0) p.top_hdr[a] = make_int2(b.hdr[0], b.hdr[1]);
     if (p.top_flat) {
@@ -2111,6 +2136,10 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
             }
             out[w] = word;
         }
+#ifdef RCW_TRACE_WAVES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RCW_DRAW_STAMP(5);
+#endif
         return;
     }
     const int wpc = top_col_bits(p) >> 5, wpu = Ht >> 5, k = Ht / p.top_unit_px, tpc = p.top_unit_px / pu;   // (unit: 256 rows, or 128 / 64: rcw_top_store_units_kernel)
@@ -2132,12 +2161,441 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         }
         p.top_codes[((size_t)a * p.W + tj) * k + rb] = make_uint2(lo, hi);
     }
+#ifdef RCW_TRACE_WAVES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RCW_DRAW_STAMP(5);
+    if (tid == 0 && a < 2048) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        g_draw_trace[a * 20 + 6] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
+}
+
+#endif   // RCW_DEV_SWITCHES (top_draw_body_r4)
+
+// ---- the draw kernel's body (round 5) ------------------------------------------------------------------------------
+// One workgroup per agent: rays -> lines in an LDS bit plane -> the plane (1/32 of the image) to HBM, with the player's pixel
+// (SR:468) and, per (tile column, row block), the 2-bit fill codes of the chunk's tiles.  The kernel is bound by its INSTRUCTION
+// COUNT (profiles/r05_draw_kernel.txt: 15 issue slots per pixel-step of a wavefront, and as many again per agent in set-up at
+// cfg-2), so this body (a) asks for everything it needs from HBM in two batches, as rcw_cast_kernel does; (b) does not walk what
+// another lane walks anyway — see top_covered_prefix: exact, the planes are bit for bit those of the round-4 body —; (c) has no
+// integer or Float64 division in its set-up; (d) walks with a hand-scheduled loop of 8 vector instructions a pixel.
+constexpr int kDrawRays = 2;                // rays a lane holds from the early table loads (more rays a lane take a loop)
+constexpr uint32_t kNoLine = 0xFFFFFFFFu;   // the ray's line is not in the list: off-image end points (walked at once, clipped), or no such ray
+// words of the draw kernel's LDS: the one-kernel form's buffer | the rays' end pixels [N] | what is left of each ray's line [N] | the lines to walk,
+// sorted: end pixel [N], first pixel [N] | lines per length class [32] | where a class starts in the sorted list [32]
+__host__ __device__ __forceinline__ size_t top_draw_lds_words(const RcwDev& p) { return top_buf_words(p) + 4 * (size_t)((p.N + 3) & ~3) + 64; }
+
+// Wavefront-wide sums, maxima and prefix sums in the vector unit's data-parallel primitives (DPP: no LDS round trip, as __shfl takes
+// through ds_bpermute): the sequences of AMD's cross-lane guide.  dpp0: the other lane's x, 0 where there is none or the row / bank is masked.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int dpp0(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, true); }
+__device__ __forceinline__ int wave_sum_in_lane63(int x)                       // (x >= 0; quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, :8, row_bcast:15, :31)
+{
+    x += dpp0<0xB1>(x); x += dpp0<0x4E>(x); x += dpp0<0x124>(x); x += dpp0<0x128>(x);
+    x += dpp0<0x142, 0xA>(x); x += dpp0<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ int wave_max_in_lane63(int x)                       // (x >= 0)
+{
+    x = max(x, dpp0<0xB1>(x)); x = max(x, dpp0<0x4E>(x)); x = max(x, dpp0<0x124>(x)); x = max(x, dpp0<0x128>(x));
+    x = max(x, dpp0<0x142, 0xA>(x)); x = max(x, dpp0<0x143, 0xC>(x));
+    return x;
+}
+__device__ __forceinline__ int wave_prefix_sum(int x)                          // inclusive (row_shr:1, :2, :3, :4 banks 1-3, :8 banks 2-3, row_bcast:15, :31)
+{
+    int s = x + dpp0<0x111>(x);
+    s += dpp0<0x112>(x);
+    s += dpp0<0x113>(x);
+    s += dpp0<0x114, 0xF, 0xE>(s);
+    s += dpp0<0x118, 0xF, 0xC>(s);
+    s += dpp0<0x142, 0xA>(s);
+    s += dpp0<0x143, 0xC>(s);
+    return s;
+}
+
+// floor(2^32 · b / a) for 0 <= b < a < 2^15 without a Float64 division: two 16-bit digits of the quotient, each a Float32 estimate
+// repaired by fast_div's two corrections (its preconditions: n < 2^31 - d, quotient <= 2^16 at a relative error of ~2^-22)
+__device__ __forceinline__ uint32_t line_slope(int lb, int la)
+{
+    const float inv = __builtin_amdgcn_rcpf((float)la);
+    const int n1 = lb << 16;
+    const int q1 = fast_div(n1, la, inv);
+    const int n2 = (n1 - q1 * la) << 16;
+    const int q2 = fast_div(n2, la, inv);
+    return ((uint32_t)q1 << 16) + (uint32_t)q2;
+}
+
+// A line from the player's pixel (ip, jp) to (i2, j2) as SD.Line walks it (ASSUMED Bresenham, see top_draw): `a` steps along the
+// major axis, pixel k at floor(k·b/a + 1/2) steps along the minor one; oct = which axis is major and the two step signs.
+struct LineGeom { int a, b, oct; };
+__device__ __forceinline__ LineGeom line_geom(uint32_t key, int ip, int jp)
+{
+    const int i2 = (int)(key & 0xFFFFu), j2 = (int)(key >> 16);
+    const int di = abs(i2 - ip), dj = abs(j2 - jp);
+    LineGeom g;
+    const bool imaj = di >= dj;
+    g.a = imaj ? di : dj; g.b = imaj ? dj : di;
+    g.oct = (imaj ? 1 : 0) | (ip < i2 ? 2 : 0) | (jp < j2 ? 4 : 0);
+    return g;
+}
+// How many leading pixels k = 0 .. K-1 of the line `mine` need not be drawn because the lines `lo` and `hi` — the rays 2^t before
+// and behind it in the fan — draw them: all three start at the player's pixel; in the same octant pixel k of each sits k steps
+// along the major axis and floor(k·s + 1/2) along the minor one, s = b/a; with s_lo <= s_mine <= s_hi (or the reverse) the middle
+// line's pixel lies between the outer ones, and while k·|s_hi - s_lo| < 1 those are at most one apart: it IS one of them.  All in
+// exact integers (a, b < 2^14: the cross products fit 32 bits) but the last division, whose Float32 estimate is taken low (fewer
+// pixels skipped, never one too many).  Identical end points: the whole line (K = a + 1).  tests/test_host_logic.py replays this
+// against the union of all lines.
+__device__ __forceinline__ int top_covered_prefix(uint32_t key, const LineGeom& m, uint32_t key_lo, uint32_t key_hi, int ip, int jp)
+{
+    if (key_lo == kNoLine || key_hi == kNoLine) return 0;
+    if (key == key_lo || key == key_hi) return m.a + 1;
+    const LineGeom l = line_geom(key_lo, ip, jp), h = line_geom(key_hi, ip, jp);
+    if (l.oct != m.oct || h.oct != m.oct) return 0;
+    // (extents below 2^14: v_mul_i32_i24 — full rate — gives the whole product)
+    const int lm = __mul24(l.b, m.a) - __mul24(m.b, l.a), mh = __mul24(m.b, h.a) - __mul24(h.b, m.a);   // s_l - s_m and s_m - s_h, scaled by positive numbers
+    if (!((lm <= 0 && mh <= 0) || (lm >= 0 && mh >= 0))) return 0;          // not monotone
+    const int P = abs(__mul24(l.b, h.a) - __mul24(h.b, l.a)), Q = __mul24(l.a, h.a);   // |s_l - s_h| = P / Q
+    int kmax = l.a < h.a ? l.a : h.a;                                        // both outer lines have a pixel k only up to their own length
+    if (P > 0) {
+        const int kstar = (int)((float)(Q - 1) * __builtin_amdgcn_rcpf((float)P) * 0.99999f) - 1;   // < Q / P, taken low
+        kmax = kstar < kmax ? kstar : kmax;
+    }
+    kmax = kmax < m.a ? kmax : m.a;
+    return kmax < 0 ? 0 : kmax + 1;                                          // pixels 0 .. kmax
+}
+
+// SD.Line with an end point off the image (SimpleDraw skips the pixels off it): the error-term loop as written
+__device__ __forceinline__ void top_clipped_line(uint32_t* line, int cb_, int Ht, int Wt, int ip, int jp, int i2, int j2)
+{
+    int i1 = ip, j1 = jp;
+    const int di = abs(i2 - i1), dj = -abs(j2 - j1);
+    const int si = i1 < i2 ? 1 : -1, sj = j1 < j2 ? 1 : -1;
+    int err = di + dj;
+    for (long long guard = 0; guard <= (long long)di - dj; ++guard) {
+        if (i1 >= 1 && i1 <= Ht && j1 >= 1 && j1 <= Wt) {
+            const int q = (j1 - 1) * cb_ + (i1 - 1);
+            __hip_atomic_fetch_or(line + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (i1 == i2 && j1 == j2) break;
+        const int e2 = 2 * err;
+        if (e2 >= dj) { err += dj; i1 += si; }
+        if (e2 <= di) { err += di; j1 += sj; }
+    }
+}
+
+__device__ __forceinline__ uint32_t lds_address(const void* q) { return (uint32_t)reinterpret_cast<size_t>((__attribute__((address_space(3))) const uint8_t*)q); }
+
+// One pixel-step of the walk for every lane: OR the pixel's bit into the plane, advance along the line, count the steps to the end of
+// the lane's segment down; `wrapped` = the lanes whose segment just ended (they go back to its start: top_draw_body).  A is the BIT
+// address of the pixel in LDS (the plane's own address folded in), f the 32-bit fraction whose carry steps the minor axis (see
+// top_draw).  Hand-scheduled: a VALU instruction that reads vcc needs two others between it and the one that wrote it (gfx950).
+#define RCW_DRAW_STEP(A, f, rem, slope, smaj, sboth, t, m, dd, wrapped)                                                     \
+    asm volatile("v_add_co_u32_e32 %1, vcc, %1, %7\n\t"                                                                     \
+                 "v_lshrrev_b32_e32 %3, 3, %0\n\t"                                                                           \
+                 "v_lshlrev_b32_e64 %4, %0, 1\n\t"                                                                           \
+                 "v_cndmask_b32_e32 %5, %8, %9, vcc\n\t"                                                                     \
+                 "v_and_b32_e32 %3, 0x1ffffffc, %3\n\t"                                                                      \
+                 "v_sub_co_u32_e64 %2, %6, %2, 1\n\t"                                                                        \
+                 "ds_or_b32 %3, %4\n\t"                                                                                      \
+                 "v_add_u32_e32 %0, %0, %5"                                                                                  \
+                 : "+v"(A), "+v"(f), "+v"(rem), "=&v"(t), "=&v"(m), "=&v"(dd), "=s"(wrapped)                                 \
+                 : "v"(slope), "v"(smaj), "v"(sboth) : "vcc", "memory")
+
+// LDS atomic add that returns the old value, by name: through __hip_atomic_fetch_add the compiler wraps every such add in a
+// wavefront-wide reduction loop (its atomic optimizer), two dozen instructions where one is meant
+__device__ __forceinline__ uint32_t lds_add_return(uint32_t* counter, uint32_t v)
+{
+    uint32_t old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(lds_address(counter)), "v"(v) : "memory");
+    return old;
+}
+constexpr int kDrawBuckets = 32;            // the lines to walk are sorted by length into this many classes, longest first
+
+template <typename T, bool TIE_LE, bool DIST_PRE>
+__device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __restrict__ mask, int a, uint32_t* lds)
+{
+    typedef typename Real<T>::vec2 vec2;
+    const int tid = threadIdx.x, group = blockDim.x, lane = tid & 63;        // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
+    const int H = p.H, HW = p.H * p.W, N = p.N, pu = p.pu, Ht = H * pu, Wt = p.W * pu;
+    const TopBuf b = top_buf(p, lds);
+    const int npad4 = (N + 3) & ~3;
+    uint32_t* const ends = lds + top_buf_words(p);                           // [N] the rays' end pixels (i2 | j2 << 16), kNoLine: none
+    uint32_t* const meta = ends + npad4;                                     // [N] per ray: pixels left out | length class << 15 | rank in the class << 20
+    uint32_t* const sorted_key = meta + npad4;                               // [M] the lines to walk, longest first: end pixel
+    uint32_t* const sorted_first = sorted_key + npad4;                       // [M] ... and the first pixel to walk
+    uint32_t* const bcount = sorted_first + npad4;                           // [kDrawBuckets] lines per length class
+    volatile uint32_t* const bstart = bcount + kDrawBuckets;                 // [kDrawBuckets] ... and where the class starts in the sorted list
+    RCW_DRAW_STAMP(0);
+#ifdef RCW_TRACE_WAVES
+    if (tid == 0 && a < 2048) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        g_draw_trace[a * 20 + 6] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
+
+    // ---- batch 1: the agent's state (mask byte, heading, pose as scalar loads awaited once: load_cast_state), the lane's tile-map words
+    const uint32_t* const tm_hbm = p.tile_map + (size_t)a * p.nwords;
+    uint32_t tw[kCastTiles];
+#pragma unroll
+    for (int k = 0; k < kCastTiles; ++k) {
+        const int t = tid + k * group;
+        tw[k] = load_at(tm_hbm, (uint32_t)((t < HW ? t : HW - 1) >> 4) * 4u);
+    }
+    const uint8_t* const mask_q = mask != nullptr ? mask + a : p.done + a;
+    vec2 pos;
+    const CastState st = load_cast_state(mask_q, p.done + a, p.done + a, p.dir + a, Real<T>::pos(p) + a, pos);
+    if (mask != nullptr && byte_of_word(st.mask_w, mask_q) == 0) return;     // workgroup-uniform
+    // ---- batch 2: the heading's ray-table entries of this lane's first rays, in flight while LDS is set up
+    const T* const tab = Real<T>::ray_table(p) + (size_t)st.d * RCW_TABLE_ROWS * N;
+    T r_dx[kDrawRays], r_dy[kDrawRays], r_ddx[kDrawRays], r_ddy[kDrawRays];
+#pragma unroll
+    for (int k = 0; k < kDrawRays; ++k) {
+        const int i = tid + k * group;
+        const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);   // (lanes past the last ray re-read it)
+        r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o); r_ddy[k] = load_at(tab + 3 * N, o);
+    }
+    // ---- LDS: the tile bytes (the last tile an obstacle whatever HBM holds: stage_tile_bytes), the cleared line plane, the class counts
+#pragma unroll
+    for (int k = 0; k < kCastTiles; ++k) {
+        const int t = tid + k * group;
+        if (t < HW) { const uint32_t v = (tw[k] >> ((t & 15) * 2)) & 3u; b.tb[t] = (uint8_t)(t == HW - 1 ? (v | 1u) : v); }
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int t = tid + kCastTiles * group; t < HW; t += group) {
+        const uint32_t v = (tm_hbm[t >> 4] >> ((t & 15) * 2)) & 3u;
+        b.tb[t] = (uint8_t)(t == HW - 1 ? (v | 1u) : v);
+    }
+    {
+        u32x4* const z = reinterpret_cast<u32x4*>(b.line);
+        const int nz = (int)(top_line_words(p) >> 2);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int k = tid; k < nz; k += group) z[k] = zero;
+    }
+    if (tid < kDrawBuckets) bcount[tid] = 0u;
+    __syncthreads();
+    RCW_DRAW_STAMP(1);
+
+    // ---- the rays' end pixels (SR:476) ----------------------------------------------------------------------------------
+    const int ip = wu_to_pu<T>(pos.x, pu), jp = wu_to_pu<T>(pos.y, pu);      // SR:468 (1-based)
+    const bool start_inside = ip >= 1 && ip <= Ht && jp >= 1 && jp <= Wt;
+    const int cb_ = top_col_bits(p);
+    auto end_pixel = [&](int i, T dx, T dy, T ddx, T ddy) {
+        const RayHit<T> r = cast_ray<T, TIE_LE, DIST_PRE>(b.tb, p.H, p.W, pos.x, pos.y, dx, dy, ddx, ddy);
+        const T dist = r.oob ? (T)0 : r.dist;
+        const T ox = dist * dx, oy = dist * dy;                              // ray_distance_wu * ray_direction_wu
+        const T ex = pos.x + ox, ey = pos.y + oy;
+        const int i2 = wu_to_pu<T>(ex, pu), j2 = wu_to_pu<T>(ey, pu);       // SR:476
+        // a line whose end points are both on the image stays on it; anything else is walked here and now, clipped
+        const bool inside = start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt;
+        ends[i] = inside ? (uint32_t)i2 | ((uint32_t)j2 << 16) : kNoLine;
+        if (!inside) top_clipped_line(b.line, cb_, Ht, Wt, ip, jp, i2, j2);
+    };
+#pragma unroll
+    for (int k = 0; k < kDrawRays; ++k) {
+        const int i = tid + k * group;
+        if (i < N) end_pixel(i, r_dx[k], r_dy[k], r_ddx[k], r_ddy[k]);
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int i = tid + kDrawRays * group; i < N; i += group) end_pixel(i, tab[i], tab[N + i], tab[2 * N + i], tab[3 * N + i]);
+    __syncthreads();
+
+    // ---- which pixels of which lines have to be walked: ray r = 2^t (2 m + 1) leaves to the rays r - 2^t and r + 2^t what they
+    // draw of its line (top_covered_prefix; their own omissions are drawn by rays of still higher t: no cycle); ray 0 and rays
+    // without both such neighbours walk everything.  What is left is SORTED by length (a counting sort over kDrawBuckets classes of
+    // the image's longer side, longest first): the walk below is as long as a wavefront's longest line, and the remainders differ
+    // a lot — half the rays keep a fraction of their line or nothing, a few keep all of it.
+    int len_shift = 0;
+    while (((Ht > Wt ? Ht : Wt) >> len_shift) >= kDrawBuckets) ++len_shift;  // (a line has at most max(Ht, Wt) pixels)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int i = tid; i < N; i += group) {
+        const uint32_t key = ends[i];
+        if (key == kNoLine) continue;
+        const LineGeom g = line_geom(key, ip, jp);
+        int skip = 0;
+        if (i > 0) {
+            const int t = i & -i;                                            // 2^t, t = the trailing zeros of i (i - 2^t >= 0 by construction)
+            if (i + t < N) skip = top_covered_prefix(key, g, ends[i - t], ends[i + t], ip, jp);
+        }
+        const int n = g.a + 1 - skip;                                        // pixels skip .. a to walk
+        uint32_t m = 0x7FFFu;                                                // (nothing of this line is walked)
+        if (n > 0) {
+            const int cls = kDrawBuckets - 1 - min(kDrawBuckets - 1, (n - 1) >> len_shift);
+            m = (uint32_t)skip | ((uint32_t)cls << 15) | (lds_add_return(bcount + cls, 1u) << 20);
+        }
+        meta[i] = m;
+    }
+    __syncthreads();
+    int M;
+    {
+        const int mine = lane < kDrawBuckets ? (int)bcount[lane] : 0;
+        const int incl = wave_prefix_sum(mine);
+        M = __builtin_amdgcn_readlane(incl, 63);                             // the lines to walk
+        // lane c: the lines of longer classes = where class c starts in the sorted list.  Every wavefront writes the same 32 words and
+        // reads them back itself (a wavefront's LDS operations execute in order: no barrier)
+        if (lane < kDrawBuckets) bstart[lane] = (uint32_t)(incl - mine);
+        __builtin_amdgcn_wave_barrier();
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int i = tid; i < N; i += group) {
+            const uint32_t key = ends[i];
+            if (key == kNoLine) continue;
+            const uint32_t m = meta[i];
+            if ((m & 0x7FFFu) == 0x7FFFu) continue;
+            const uint32_t at = bstart[(m >> 15) & 31u] + (m >> 20);
+            sorted_key[at] = key; sorted_first[at] = m & 0x7FFFu;
+        }
+    }
+    __syncthreads();
+    RCW_DRAW_STAMP(2);
+
+    // ---- the walk: a lane per line, or — fewer lines than lanes — 2^lp lanes per line, a segment each; in passes of the workgroup ----
+    // Pixel k of a line sits k steps along the major axis and floor(k·b/a + 1/2) along the minor one.  The loop carries the
+    // FRACTION of k·slope/2^32 + 1/2 + 2^-18 in 32 bits and steps the minor axis on its carry (exact for lines of up to 2^14
+    // pixels: the argument is in top_draw).  Every lane walks its whole segment but starts somewhere along it and wraps round:
+    // walked in step from the player, the lanes of a wavefront sit on one small arc at every step — the same plane word or two
+    // for dozens of steps, and same-word LDS atomics serialise.  A lane that is through before the wavefront's longest segment
+    // goes round again (OR is idempotent); a lane without a segment ORs into a private dummy word.
+    if (M > 0) {
+        int lp = 0;
+        { const int mpad = (M + 63) & ~63, g64 = group >> 6; while ((mpad << (lp + 1)) <= group && (g64 & ((2 << lp) - 1)) == 0) ++lp; }
+        const int rpp = group >> lp;                                         // lines per pass, a multiple of 64: the part is wave-uniform
+        int part = 0;
+        { const int wpp = rpp >> 6, wv = tid >> 6; for (int t = wpp; t <= wv; t += wpp) ++part; }
+        const int pin = tid - part * rpp;
+        const uint32_t plane_bits = lds_address(b.line) * 8u;
+        const uint32_t dummy_A = lds_address(b.dummy + lane) * 8u;
+        const uint32_t frac0 = 0x80000000u + (1u << 14);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int q0 = 0; q0 < M; q0 += rpp) {
+            const int q = q0 + pin;
+            int ks = 0, len = 0, smaj = 0, sboth = 0;
+            uint32_t A0 = dummy_A, slope = 0u;
+            if (q < M) {
+                const uint32_t key = sorted_key[q];
+                const int first = (int)sorted_first[q];
+                const LineGeom g = line_geom(key, ip, jp);
+                const int n = g.a + 1 - first;
+                const int si = (g.oct & 2) ? 1 : -1, sj = (g.oct & 4) ? cb_ : -cb_;   // steps of the plane's bit index
+                smaj = (g.oct & 1) ? si : sj;
+                sboth = si + sj;
+                A0 = plane_bits + (uint32_t)((jp - 1) * cb_ + (ip - 1));
+                slope = g.b >= g.a ? 0xFFFFFFFFu : line_slope(g.b, g.a);      // floor(2^32 · b / a)
+                ks = first + ((part * n) >> lp);                             // this lane's pixels of the line: ks .. ke - 1
+                len = first + (((part + 1) * n) >> lp) - ks;
+                if (len == 0) { A0 = dummy_A; smaj = sboth = 0; slope = 0u; }
+            }
+            const int ke = ks + len;
+            const int k0 = len > 1 ? ks + (int)((((unsigned)(tid * 37) & 63u) * (unsigned)len) >> 6) : ks;   // neighbouring lanes start 37/64 of a segment apart
+            const unsigned long long at_ks = (unsigned long long)(unsigned)ks * slope + frac0;     // v_mad_u64_u32
+            const unsigned long long at_k0 = (unsigned long long)(unsigned)k0 * slope + frac0;
+            const uint32_t frac_s = (uint32_t)at_ks;
+            const uint32_t A_s = A0 + (uint32_t)(ks * smaj + (int)(at_ks >> 32) * (sboth - smaj));
+            uint32_t frac = (uint32_t)at_k0;
+            uint32_t A = A0 + (uint32_t)(k0 * smaj + (int)(at_k0 >> 32) * (sboth - smaj));
+            uint32_t rem = (uint32_t)(len > 0 ? ke - k0 : 0x7fffffff) - 1u;   // steps until the wrap, less one (the step that borrows wraps)
+            const uint32_t len_m1 = len > 0 ? (uint32_t)(len - 1) : 0x7ffffffeu;
+            const int nmax = __builtin_amdgcn_readlane(wave_max_in_lane63(len), 63);   // (the trip count is the wavefront's longest segment: a scalar loop)
+#ifdef RCW_TRACE_WAVES
+            if (q0 == 0 && tid == 0 && a < 2048) g_draw_trace[a * 20 + 8] = (unsigned long long)nmax | ((unsigned long long)M << 32);
+#endif
+            uint32_t t_, m_, d_;
+            unsigned long long wrapped;
+            // the lanes whose segment just ended go back to its start (rare against the steps — once per lane and time round its
+            // segment —: a branch; in volatile asm so that it stays one: if-converted, its selects ran in every step)
+            auto rewind = [&]() {
+                asm volatile("v_cndmask_b32_e64 %0, %0, %3, %6\n\tv_cndmask_b32_e64 %1, %1, %4, %6\n\tv_cndmask_b32_e64 %2, %2, %5, %6"
+                             : "+v"(rem), "+v"(frac), "+v"(A) : "v"(len_m1), "v"(frac_s), "v"(A_s), "s"(wrapped));
+            };
+            // four steps a trip (up to three more than the longest segment needs: lanes go round their own segments, harmless)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (int trips = (nmax + 3) >> 2; trips > 0; --trips) {
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
+            }
+        }
+    }
+    RCW_DRAW_STAMP(3);
+    __syncthreads();
+    RCW_DRAW_STAMP(4);
+    if (tid == 0) p.top_hdr[a] = make_int2(ip, jp);
+    if (p.top_flat) {
+        // rcw_top_store_flat_kernel's plane: the bit of agent pixel q = (j-1)·Ht + (i-1) sits at bit s + q of the agent's
+        // region of p.top_plane_words words, s = (a · Ht·Wt) mod 256 — where the agent's image starts inside its first
+        // 256-pixel chunk of the flat batch — so a chunk's plane bits are 8 whole words of the region, and the bits
+        // that belong to the neighbouring agents' pixels (in front of s, behind the image) are zero: a chunk that
+        // straddles two agents ORs the two regions' words.  An image column is at least 42 rows here, so a word holds
+        // bits of at most two columns.
+        const unsigned px_agent = (unsigned)Ht * (unsigned)Wt;
+        const int s_a = (int)(((unsigned long long)a * px_agent) & 255ull);
+        const unsigned cb = (unsigned)cb_, PW = (unsigned)p.top_plane_words;
+        const float inv_ht = 1.0f / (float)Ht;
+        uint32_t* const out = p.top_plane + (size_t)a * PW;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (unsigned w = tid; w < PW; w += group) {
+            const int q_start = (int)(32u * w) - s_a;                        // the agent pixel of the word's bit 0
+            uint32_t word = 0u;
+            if (q_start > -32 && q_start < (int)px_agent) {
+                const int lead = q_start < 0 ? -q_start : 0;
+                const unsigned q = (unsigned)(q_start + lead);
+                // (the image column of pixel q: the Float32 quotient repaired, where fast_div's precondition holds — q < 2^23, or a
+                // quotient of at most 2^13; every image the flat store kernel takes is at most 2^14 pixels wide: the second holds)
+                const unsigned j = (unsigned)fast_div((int)q, Ht, inv_ht), i = q - j * (unsigned)Ht;
+                const unsigned Ab = j * cb + i;
+                const unsigned long long two = (unsigned long long)b.line[Ab >> 5] | ((unsigned long long)b.line[(Ab >> 5) + 1] << 32);
+                uint32_t bits = (uint32_t)(two >> (Ab & 31u));
+                const unsigned n1 = (unsigned)Ht - i;                        // bits left in column j
+                if (n1 < 32u) {
+                    bits &= (1u << n1) - 1u;
+                    if (j + 1 < (unsigned)Wt) bits |= b.line[((j + 1) * cb) >> 5] << n1;
+                }
+                word = bits << lead;
+            }
+            out[w] = word;
+        }
+#ifdef RCW_TRACE_WAVES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RCW_DRAW_STAMP(5);
+#endif
+        return;
+    }
+    const int wpc = cb_ >> 5, wpu = Ht >> 5, k = Ht / p.top_unit_px, tpc = p.top_unit_px / pu;   // (unit: 256 rows, or 128 / 64: rcw_top_store_units_kernel)
+    uint32_t* const out = p.top_plane + (size_t)a * Wt * wpu;
+    const int total = Wt * wpu, qstep = group / wpu, rstep = group - qstep * wpu;
+    int j = tid / wpu, w = tid - j * wpu;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int idx = tid; idx < total; idx += group) {
+        out[idx] = b.line[j * wpc + w];
+        j += qstep; w += rstep;
+        if (w >= wpu) { w -= wpu; j += 1; }
+    }
+    for (int e = tid; e < p.W * k; e += group) {
+        const int tj = e / k, rb = e - tj * k;
+        const uint8_t* const tiles = b.tb + rb * tpc + p.H * tj;
+        uint32_t lo = 0u, hi = 0u;
+        for (int t = 0; t < tpc; ++t) {
+            const uint32_t code = (tiles[t] & 1u) ? 1u : (tiles[t] & 2u);          // wall (white) before goal (red)  SR:355-360
+            if (t < 16) lo |= code << (2 * t); else hi |= code << (2 * (t - 16));
+        }
+        p.top_codes[((size_t)a * p.W + tj) * k + rb] = make_uint2(lo, hi);
+    }
+#ifdef RCW_TRACE_WAVES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RCW_DRAW_STAMP(5);
+#endif
 }
 
 template <typename T, bool TIE_LE, bool DIST_PRE>
 __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, const uint8_t* __restrict__ mask, int first)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+#ifdef RCW_DEV_SWITCHES
+    if (p.top_draw_r4) { top_draw_body_r4<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x, lds); return; }
+#endif
     top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x, lds);
 }
 
@@ -2155,6 +2613,9 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_draw_kernel(const RcwDev p
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((int)blockIdx.x < fill_blocks) { fill256_body<false>(p, col_h, col_c, out, total_cols, mask, (int)blockIdx.x, fill_blocks); return; }
+#ifdef RCW_DEV_SWITCHES
+    if (p.top_draw_r4) { top_draw_body_r4<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x - fill_blocks, lds); return; }
+#endif
     top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x - fill_blocks, lds);
 }
 
@@ -3056,7 +3517,7 @@ hipError_t rcw_launch_top_view(const RcwDev& p, const uint8_t* mask_dev, hipStre
 int rcw_top_split_unit(const RcwDev& p)
 {
     const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
-    if (p.pu < 8 || 2 * p.top_rp > 31) return 0;
+    if (p.pu < 8 || 2 * p.top_rp > 31 || p.N > 4096) return 0;                                   // (the draw kernel ranks a line within its length class in 12 bits)
     int unit = 0;
     if (256 % p.pu == 0 && Ht % 256 == 0) unit = 256;
 #ifdef RCW_DEV_SWITCHES
@@ -3067,7 +3528,7 @@ int rcw_top_split_unit(const RcwDev& p)
     if (!unit) return 0;
     if ((long long)p.B * Wt * (Ht / unit) + 8ll * 64 * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;   // unit / chunk ids in 32 bits
     if ((long long)p.B * Wt * (Ht >> 5) >= (1ll << 31) - 64) return 0;                                               // plane word offsets
-    return 4 * top_buf_words(p) <= 156 * 1024 ? unit : 0;
+    return 4 * top_draw_lds_words(p) <= 159 * 1024 ? unit : 0;                                       // the draw kernel's LDS: plane + ray lists
 }
 // rcw_top_store_flat_kernel: the image columns a 256-pixel chunk can touch in this geometry; 0: the kernel does not take it
 static size_t top_circle_table_bytes(const RcwDev& p) { return (size_t)(p.top_rp + 1) * ((2 * p.top_rp + 1 + 31) / 32 + 2) * 4; }
@@ -3079,12 +3540,12 @@ static size_t top_store_flat_lds_bytes(const RcwDev& p, int K)             // pl
 int rcw_top_flat_cols(const RcwDev& p)
 {
     const long long Ht = (long long)p.H * p.pu, Wt = (long long)p.W * p.pu;
-    if (p.pu < 9 || (Ht & 3) != 0 || Ht > 16384 || Wt > 16384 || p.H > 65535 || p.top_rp > 8191) return 0;
+    if (p.pu < 9 || (Ht & 3) != 0 || Ht > 16384 || Wt > 16384 || p.H > 65535 || p.top_rp > 8191 || p.N > 4096) return 0;
     const int K = (int)(251 / Ht) + 2;
     if (K > 7) return 0;                                                              // (the store kernel is instantiated for 2..7)
     if (top_circle_table_bytes(p) > 16 * 1024) return 0;
     if (top_store_flat_lds_bytes(p, K) > 64 * 1024) return 0;                                 // (plane words, descriptors, circle rows, row table: the default limit is kept)
-    if (4 * top_buf_words(p) > 156 * 1024) return 0;                                          // the draw kernel's LDS plane
+    if (4 * top_draw_lds_words(p) > 159 * 1024) return 0;                                     // the draw kernel's LDS: plane + ray lists
     const long long chunks = ((long long)p.B * Ht * Wt + 255) / 256;
     if ((long long)p.B * Wt >= (1ll << 31) - 64) return 0;                                    // image columns of the flat batch in 32 bits
     if (chunks + 64ll * p.top_store_grid * (kBlock / 64) >= (1ll << 31)) return 0;            // chunk ids
@@ -3107,20 +3568,20 @@ size_t rcw_top_codes_bytes(const RcwDev& p)
 // whole number of 1 KiB chunks in every geometry rcw_top_split_unit takes)
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
 {
-    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(p.top_draw_block), 4 * top_buf_words(p), p, mask_dev, first);
+    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(p.top_draw_block), 4 * top_draw_lds_words(p), p, mask_dev, first);
     return hipGetLastError();
 }
 // the camera fill of the whole batch + the drawing of every agent in one launch (rcw_fill256_draw_kernel): whether this handle's
 // geometry takes it, and the launch
 int rcw_fill_draw_fusable(const RcwDev& p)
 {
-    return p.top_split && p.top_runs <= 1 && p.top_draw_block == kBlock && !p.fill_plain && 4 * top_buf_words(p) <= 64 * 1024 &&
+    return p.top_split && p.top_runs <= 1 && p.top_draw_block == kBlock && !p.fill_plain && 4 * top_draw_lds_words(p) <= 64 * 1024 &&
            fill_choice(p, (long long)p.B * p.N) == kFill256 && (long long)p.fill_grid + p.B < (1ll << 31);
 }
 hipError_t rcw_launch_fill256_draw(const RcwDev& p, const uint8_t* mask_dev, hipStream_t s)
 {
     u32x4* const frames4 = reinterpret_cast<u32x4*>(p.obs);
-    RCW_DISPATCH(rcw_fill256_draw_kernel, dim3(p.fill_grid + p.B), dim3(kBlock), 4 * top_buf_words(p), p, p.col_h, p.col_c, frames4,
+    RCW_DISPATCH(rcw_fill256_draw_kernel, dim3(p.fill_grid + p.B), dim3(kBlock), 4 * top_draw_lds_words(p), p, p.col_h, p.col_c, frames4,
                  (long long)p.B * p.N, mask_dev, p.fill_grid, 0);
     return hipGetLastError();
 }

@@ -665,3 +665,120 @@ def test_turning_chunk_assignment_replayed_against_plain_division():
                     assert (base - chunk_begin) % (G * 64) == slot                 # group k's slot, in the compact window of group k
         if waves.__class__ is range:
             assert sorted(seen) == list(range(chunk_begin, chunk_end)) and set(seen.values()) == {1}, (G, R, Ht, Wt, chunk_begin, chunk_end)
+
+
+def _line_geom(key, ip, jp):
+    i2, j2 = key & 0xFFFF, key >> 16
+    di, dj = abs(i2 - ip), abs(j2 - jp)
+    imaj = di >= dj
+    return (di if imaj else dj), (dj if imaj else di), (1 if imaj else 0) | (2 if ip < i2 else 0) | (4 if jp < j2 else 0)
+
+
+def _covered_prefix(key, key_lo, key_hi, ip, jp, exact=False):
+    """rcw_kernels.hip::top_covered_prefix, statement by statement (`exact`: the last division exactly instead of its low estimate)."""
+    NO = 0xFFFFFFFF
+    if key_lo == NO or key_hi == NO:
+        return 0
+    ma, mb, mo = _line_geom(key, ip, jp)
+    if key == key_lo or key == key_hi:
+        return ma + 1
+    la, lb, lo = _line_geom(key_lo, ip, jp)
+    ha, hb, ho = _line_geom(key_hi, ip, jp)
+    if lo != mo or ho != mo:
+        return 0
+    lm, mh = lb * ma - mb * la, mb * ha - hb * ma
+    if not ((lm <= 0 and mh <= 0) or (lm >= 0 and mh >= 0)):
+        return 0
+    P, Q = abs(lb * ha - hb * la), la * ha
+    kmax = min(la, ha)
+    if P > 0:
+        if exact:
+            kstar = (Q - 1) // P
+        else:
+            kstar = int(np.float32(np.float32(Q - 1) * (np.float32(1.0) / np.float32(P))) * np.float32(0.99999)) - 1
+        kmax = min(kmax, kstar)
+    kmax = min(kmax, ma)
+    return 0 if kmax < 0 else kmax + 1
+
+
+def _line_pixels(ip, jp, key, first=0):
+    """SD.Line from (ip, jp) to the key's pixel as the kernels walk it: pixel k sits k steps along the major axis and
+    floor((2 b k + a) / (2 a)) along the minor one (test_line_closed_form_equals_the_error_term_walk); pixels first .. a."""
+    i2, j2 = key & 0xFFFF, key >> 16
+    a, b, oct_ = _line_geom(key, ip, jp)
+    si, sj = (1 if ip < i2 else -1), (1 if jp < j2 else -1)
+    out = set()
+    for k in range(first, a + 1):
+        m = (2 * b * k + a) // (2 * a) if a else 0
+        out.add((ip + si * k, jp + sj * m) if oct_ & 1 else (ip + si * m, jp + sj * k))
+    return out
+
+
+def test_draw_kernel_leaves_out_only_pixels_that_other_lines_draw(oracle):
+    """Round 5: the top view's draw kernel does not walk the leading pixels of a ray's line that the rays 2^t before and behind it
+    in the fan draw anyway (rcw_kernels.hip::top_covered_prefix, and the class-by-class list in top_draw_body) — EXACTLY: the union
+    of what is still walked equals the union of all lines.  Replayed here on the rays of real agents (the oracle's end points, several
+    map / pixel-scale / ray-count shapes, incl. fans across an axis and rays that end in the same pixel), with the kernel's low
+    Float32 estimate of the one division and with the exact quotient; and the estimate never exceeds the exact quotient."""
+    rng = np.random.default_rng(11)
+    P = rng.integers(1, 1 << 28, 200000); Q = rng.integers(1, 1 << 28, 200000)
+    est = (np.float32(0.99999) * (np.float32(1.0) / P.astype(np.float32) * (Q - 1).astype(np.float32))).astype(np.int64) - 1
+    assert (est <= (Q - 1) // P).all()
+    # (the device's v_rcp_f32 is within an ulp of the division used here: 2^-23 against the 2^-16.6 the factor 0.99999 leaves)
+    total_all = total_walked = 0
+    for H, W, pu, N, B in ((8, 8, 32, 256, 12), (8, 16, 32, 512, 6), (8, 8, 10, 256, 12), (16, 16, 20, 64, 8), (6, 9, 13, 37, 10), (12, 12, 32, 1024, 3)):
+        orc = oracle.OracleBatch(B, seed=5, height_tile_map_tu=H, width_tile_map_tu=W, num_rays=N, out_of_bounds=1)
+        for _ in range(17):
+            orc.step(rng.integers(1, 5, B).astype(np.uint8))
+        pos = orc.position
+        dist = np.asarray(orc.ray_dist).reshape(B, N); dirs = np.asarray(orc.ray_dirs).reshape(B, N, 2)
+        f32 = np.float32
+        ex = (pos[:, None, 0] + (dist * dirs[:, :, 0]).astype(f32)).astype(f32); ey = (pos[:, None, 1] + (dist * dirs[:, :, 1]).astype(f32)).astype(f32)
+        i2 = np.floor(ex * f32(pu)).astype(np.int64) + 1; j2 = np.floor(ey * f32(pu)).astype(np.int64) + 1
+        ipa = np.floor(pos[:, 0] * f32(pu)).astype(np.int64) + 1; jpa = np.floor(pos[:, 1] * f32(pu)).astype(np.int64) + 1
+        for a in range(B):
+            ip, jp = int(ipa[a]), int(jpa[a])
+            ends = [int(i2[a, r]) | (int(j2[a, r]) << 16) for r in range(N)]
+            everything = set()
+            for r in range(N):
+                everything |= _line_pixels(ip, jp, ends[r])
+            for exact in (False, True):
+                walked = set(); nwalk = 0
+                for r in range(N):
+                    skip = 0
+                    if r > 0:
+                        t = (r & -r)
+                        if r + t < N:
+                            skip = _covered_prefix(ends[r], ends[r - t], ends[r + t], ip, jp, exact)
+                    px = _line_pixels(ip, jp, ends[r], skip)
+                    nwalk += max(0, _line_geom(ends[r], ip, jp)[0] + 1 - skip)
+                    walked |= px
+                assert walked == everything, (H, W, pu, N, a, exact)
+            total_all += sum(_line_geom(e, ip, jp)[0] + 1 for e in ends); total_walked += nwalk
+        orc.close()
+    assert total_walked < 0.75 * total_all          # (and it is worth it: a quarter of the pixel-steps, at least, over these shapes)
+
+
+def test_draw_kernel_ray_order_is_a_permutation_by_class():
+    """rcw_kernels.hip::draw_ray_of_position, restated: position p of N -> ray; every ray exactly once, in the order of the trailing
+    zeros of its index (every other ray first ... ray 0 last), for every N up to 300 and a few large ones."""
+    def clz(x):
+        return 32 - int(x).bit_length()
+
+    def ray_of(p, N):
+        last, r = N - 1, N - 1 - p
+        if r <= 0:
+            return 0
+        u = clz(r) - clz(last)
+        if (last >> u) < r:
+            u -= 1
+        return ((p - (last - (last >> u))) << (u + 1)) + (1 << u)
+
+    for N in list(range(1, 301)) + [512, 1000, 1024, 4095, 4096, 16383]:
+        rays = [ray_of(p, N) for p in range(N)]
+        assert sorted(rays) == list(range(N)), N
+        tz = [((r & -r).bit_length() - 1) if r else 99 for r in rays]
+        assert tz == sorted(tz), N                                         # class by class
+        for u in set(tz):
+            cls = [r for r, t in zip(rays, tz) if t == u]
+            assert cls == sorted(cls), (N, u)                              # ... and in ray order inside a class
