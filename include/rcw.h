@@ -362,7 +362,7 @@ RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, 
  *   RCW_TOP_VIEW_ONE_KERNEL   write-once: bit planes in LDS, draw and store groups of one persistent kernel
  *   RCW_TOP_VIEW_TWO_KERNELS  write-once, inside rcw_step / rcw_reset / rcw_set_state: the drawing (bit planes -> HBM) in the
  *                             camera fill's own launch, then the moving-window store kernel; rcw_update_top_view alone
- *                             takes the one-kernel form (except at pixel scales that are not a multiple of 4).
+ *                             takes draw -> store back to back where that is the faster one (rcw_update_top_view_form).
  *                             Geometries: H*pu a multiple of 256 rows with pu_per_tu in {8, 16, ..., 256} and a player
  *                             circle of <= 32 rows (rcw_top_store_kernel), any pu_per_tu >= 9 with H*pu a multiple of 4
  *                             and >= 42 rows (rcw_top_store_flat_kernel), 8-pixel tiles with H*pu a multiple of 64 or 32
@@ -372,6 +372,12 @@ RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, 
  *                             the one-kernel form is faster) unless rcw_set_top_view_form asks for it */
 enum { RCW_TOP_VIEW_NONE = 0, RCW_TOP_VIEW_IN_PLACE = 1, RCW_TOP_VIEW_ONE_KERNEL = 2, RCW_TOP_VIEW_TWO_KERNELS = 3 };
 RCW_API int rcw_top_view_form(rcw_handle* h, int32_t* form);
+/* ... and the form rcw_update_top_view takes when it is called ALONE (update_top_view!(env) outside a step, SR:446): nothing runs
+ * beside the drawing then.  Where the step takes the two-kernel form the stand-alone call takes it too (draw -> store back to back)
+ * for images from 256 x 256 px, for pixel scales that are no multiple of 4 and for tiles below 16 px — measured faster, round 5 —;
+ * the one-kernel form keeps images below 256 x 256 px at 16, 20, 24, ... px a tile, and every geometry that is not the two-kernel
+ * form's; RCW_TOP_VIEW_IN_PLACE where the bit planes do not fit in LDS. */
+RCW_API int rcw_update_top_view_form(rcw_handle* h, int32_t* form);
 /* Choose the form instead of the rule above (all forms write the same pixels; this is a performance choice, e.g. the
  * one-kernel form for a caller that does not want the handle's side stream, or the two-kernel form for a small batch):
  * form = 0 restores the automatic choice, else RCW_TOP_VIEW_IN_PLACE / ONE_KERNEL / TWO_KERNELS; RCW_ERR_UNSUPPORTED when

@@ -481,6 +481,12 @@ function top_view_form(env::BatchedSingleRoom)
     check(ccall((:rcw_top_view_form, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, f))
     return (:none, :in_place, :one_kernel, :two_kernels)[f[] + 1]
 end
+"The form `update_top_view!(env)` takes when it is called alone, outside a step (`rcw_update_top_view_form`)."
+function update_top_view_form(env::BatchedSingleRoom)
+    f = Ref{Int32}(0)
+    check(ccall((:rcw_update_top_view_form, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, f))
+    return (:none, :in_place, :one_kernel, :two_kernels)[f[] + 1]
+end
 """
     set_top_view_form!(env, form = :auto; runs = 0)
 

@@ -134,6 +134,7 @@ SIGNATURES = {
     "rcw_profile": [_vp, _i32],
     "rcw_profile_read": [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)],
     "rcw_top_view_form": [_vp, C.POINTER(_i32)],
+    "rcw_update_top_view_form": [_vp, C.POINTER(_i32)],
     "rcw_set_top_view_form": [_vp, _i32, _i32],
     "rcw_fill_kernel_name": [_vp, C.c_char_p, _i32],
     "rcw_comm_unique_id": [_vp],

@@ -124,7 +124,7 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         return between();
     }
     if (!beside) {                                           // stand-alone, two kernels back to back on the handle's stream
-        if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
+        if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream, d.top_draw_block_alone)) != hipSuccess) return e;
         if ((e = rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
         return between();
     }
@@ -358,7 +358,7 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr;
     d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
-    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256;
+    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256;
     if (!cfg->render_top_view) {
         if (want_form != 0 && !lenient) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
         return RCW_OK;
@@ -406,16 +406,26 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         else if (!lenient) return fail(RCW_ERR_UNSUPPORTED, "this geometry does not take the two-kernel form (pu_per_tu >= 8, image height a multiple of 4 and of at least 42 rows, bit plane within LDS)");
     }
     if (!d.top_split) { d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; }
-    // rcw_update_top_view alone has no camera fill to hide the drawing behind: the one-kernel form is the faster one
-    // (209 against 227 us at the default geometry) — except where only its generic paths apply (pixel scales that do not
-    // divide the four-pixel groups: 29 % of the roofline), i.e. the flat kernel's own geometries
-    d.top_alone_split = d.top_split && d.top_flat && (cfg->pu_per_tu & 3) != 0 ? 1 : 0;
+    // rcw_update_top_view alone has no camera fill to hide the drawing behind.  Measured, round 5 (draw -> store back to back against
+    // the one-kernel form, us per GiB of top view, profiles/r05_top_view_shapes.txt): images from 256 x 256 px 217 / 224 / 198 / 210 /
+    // 218 against 214 / 231 / 228 / 253 / 360 (256^2, 256 x 512, 512^2, 768^2, 1024^2 px); pixel scales that are no multiple of 4,
+    // where the one-kernel form has only its generic paths, 360 / 302 against 507 / 450 (10, 13 px a tile), and 12 px a tile 310
+    // against 347; the one-kernel form keeps what is left of the two-kernel form's geometries: images below 256^2 px at 16, 20, 24,
+    // 28 ... px a tile (264 / 228 / 229 against 268 / 246 / 233) — and every geometry the two-kernel form cannot take.
+    {
+        const long long px = (long long)H * cfg->pu_per_tu * W * cfg->pu_per_tu;
+        d.top_alone_split = d.top_split && (px >= 65536 || (cfg->pu_per_tu & 3) != 0 || cfg->pu_per_tu < 16) ? 1 : 0;
+    }
     if (const char* v = RCW_DEV_ENV("RCW_TOP_ALONE_SPLIT")) d.top_alone_split = d.top_split && std::atoi(v) ? 1 : 0;
     // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on
     // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top
     // view in a step with 256 / 512 / 1024 threads: 512² px, 256 rays 180 / 182 / 200; 768² px 212 / 200 / 203; 1024² px, 1024 rays 357 / 265 / 216)
     if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > 64 * 1024) { const int b = ((N + 255) / 256) * 256; d.top_draw_block = b < 512 ? 512 : (b > 1024 ? 1024 : b); }
-    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = b; }
+    // ... and alone, with tens of thousands of small images, one or two wavefronts an agent (the set-up per wavefront is what such a
+    // batch costs; 41,943 images of 80^2 px: 175 us with 64 threads against 193 with 256, 16,384 of 128^2 px: 103 with 128 against 109)
+    d.top_draw_block_alone = d.top_draw_block;
+    if (d.top_draw_block == 256) d.top_draw_block_alone = h->B >= 24576 ? 64 : (h->B >= 12288 ? 128 : 256);
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = d.top_draw_block_alone = b; }
     // runs of agents: where the lines are long against the camera image's columns ((Ht + Wt) / 2 >= 1.75 H_cam) the drawing
     // does not fit beside the camera fill; with several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside
     // the storing of earlier runs.  Measured (µs a step with 1 / 2 / 4 / 8 runs): 16×16 map, 512 rays, 16,384 agents (16 GiB of
@@ -1429,6 +1439,14 @@ int rcw_top_view_form(rcw_handle* h, int32_t* form)
     if (!h || !form) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
     const RcwDev& d = h->dev;
     *form = !d.top_view ? RCW_TOP_VIEW_NONE : d.top_split ? RCW_TOP_VIEW_TWO_KERNELS : d.top_lds ? RCW_TOP_VIEW_ONE_KERNEL : RCW_TOP_VIEW_IN_PLACE;
+    return RCW_OK;
+}
+
+int rcw_update_top_view_form(rcw_handle* h, int32_t* form)
+{
+    if (!h || !form) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    const RcwDev& d = h->dev;
+    *form = !d.top_view ? RCW_TOP_VIEW_NONE : (d.top_split && d.top_alone_split) ? RCW_TOP_VIEW_TWO_KERNELS : d.top_lds ? RCW_TOP_VIEW_ONE_KERNEL : RCW_TOP_VIEW_IN_PLACE;
     return RCW_OK;
 }
 

@@ -69,6 +69,7 @@ struct RcwDev {
     int32_t top_runs;        // the batch is drawn and stored in this many runs of agents (store of run r beside the drawing of run r + 1)
     int32_t top_fused;       // a step's camera fill and top-view drawing go in ONE launch (rcw_fill256_draw_kernel) instead of two streams
     int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU
+    int32_t top_draw_block_alone;   // ... in rcw_update_top_view alone: 64 / 128 for batches of tens of thousands of small images
     int32_t top_store_plain; // its store kernel: 1 plain stores, 0 non-temporal
     int32_t top_store_grid;  // ... and its workgroups (the moving window = top_store_grid KiB x 4)
     uint32_t* top_plane;     // [B][W*pu][H*pu/32] ray-line bit plane of every agent (two-kernel top view)
@@ -115,7 +116,7 @@ int rcw_fill_flat_cols(const RcwDev& p);   // rcw_fill_flat_kernel: columns a ch
 const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // the kernel rcw_launch_fill takes
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
-hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);    // agents [first, first + count)
+hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block = 0);    // agents [first, first + count); block: threads a workgroup, 0 = p.top_draw_block
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
 #ifdef RCW_DEV_SWITCHES
 bool rcw_step_fusable(const RcwDev& p);       // development experiment (RCW_STEP_FUSED): cast + camera fill in one launch

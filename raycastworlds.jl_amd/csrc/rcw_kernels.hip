@@ -3566,9 +3566,9 @@ size_t rcw_top_codes_bytes(const RcwDev& p)
 
 // agents [first, first + count): the draw kernel's workgroups / the store kernel's chunks of that run (an image is a
 // whole number of 1 KiB chunks in every geometry rcw_top_split_unit takes)
-hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
+hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block)
 {
-    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(p.top_draw_block), 4 * top_draw_lds_words(p), p, mask_dev, first);
+    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(block > 0 ? block : p.top_draw_block), 4 * top_draw_lds_words(p), p, mask_dev, first);
     return hipGetLastError();
 }
 // the camera fill of the whole batch + the drawing of every agent in one launch (rcw_fill256_draw_kernel): whether this handle's

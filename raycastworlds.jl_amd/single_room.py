@@ -739,6 +739,12 @@ class SingleRoom:
         self._check(self._lib.rcw_top_view_form(self._h, C.byref(f)))
         return ("none", "in-place", "one-kernel", "two-kernels")[f.value]
 
+    def update_top_view_form(self) -> str:
+        """The form `update_top_view_(env)` takes when called alone, outside a step (rcw_update_top_view_form)."""
+        f = C.c_int32()
+        self._check(self._lib.rcw_update_top_view_form(self._h, C.byref(f)))
+        return ("none", "in-place", "one-kernel", "two-kernels")[f.value]
+
     def timer_start(self):
         self._check(self._lib.rcw_timer_start(self._h))
 

@@ -99,6 +99,9 @@ int main(int argc, char** argv)
         int32_t form = -1;
         CHECK(rcw_set_top_view_form(ht, RCW_TOP_VIEW_TWO_KERNELS, 0));   /* (64 agents: the two-kernel form only when asked for) */
         CHECK(rcw_top_view_form(ht, &form));
+        int32_t form_alone = -1;
+        CHECK(rcw_update_top_view_form(ht, &form_alone));
+        printf("top_view_form_alone=%d\n", (int)form_alone);
         char kname[64];
         CHECK(rcw_fill_kernel_name(ht, kname, (int32_t)sizeof kname));
         printf("fill_kernel=%s\n", kname);

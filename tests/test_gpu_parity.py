@@ -1067,6 +1067,54 @@ def test_masked_render_right_after_a_change_of_form(rcw, oracle):
         env.close()
 
 
+def test_stand_alone_top_view_takes_the_measured_form(rcw, oracle):
+    """`update_top_view!(env)` ALONE (nothing runs beside the drawing) takes draw -> store back to back where
+    that was measured faster than the one-kernel form (profiles/r05_top_view_shapes.txt): every image of the two-kernel form's
+    geometries from 256 x 256 px, every pixel scale that is no multiple of 4, every tile below 16 px.  The one-kernel form
+    (rcw_top_view_kernel) keeps exactly: images below 256 x 256 px at 16, 20, 24, 28 ... px a tile, and the geometries the two-kernel
+    form cannot take (tiles below 8 px off the unit kernels' grid, image heights that are no multiple of 4, batches the side stream does
+    not pay for).  The list is asserted here, and for every case the stand-alone call's pixels against the oracle."""
+    cases = (   # kwargs, batch, form inside a step, form of the stand-alone call
+        (dict(pu_per_tu=32, **CFG2), 64, "two-kernels", "two-kernels"),                                            # 256 x 256 px
+        (dict(pu_per_tu=32), 8, "two-kernels", "two-kernels"),                                                     # the reference default: 256 x 512 px, 512 rays
+        (dict(pu_per_tu=32, **CFG4), 8, "two-kernels", "two-kernels"),                                             # 512 x 512
+        (dict(pu_per_tu=32, height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 114, "two-kernels", "two-kernels"),  # 768 x 768 (256 MiB: planes beyond a
+        (dict(pu_per_tu=32, **CFG5), 64, "two-kernels", "two-kernels"),                                            #  256-thread workgroup take the side stream) / 1024 x 1024, 1024 rays
+        (dict(pu_per_tu=32, **CFG5), 8, "one-kernel", "one-kernel"),                                               # ... and below 256 MiB of them: no side stream, no planes in HBM
+        (dict(pu_per_tu=8, height_tile_map_tu=32, width_tile_map_tu=32, num_rays=256), 16, "two-kernels", "two-kernels"),   # 8-px tiles, 256 x 256
+        (dict(pu_per_tu=10, **CFG2), 64, "two-kernels", "two-kernels"),                                            # 10, 13: no multiple of 4
+        (dict(pu_per_tu=13, **CFG2), 64, "two-kernels", "two-kernels"),
+        (dict(pu_per_tu=12, **CFG2), 64, "two-kernels", "two-kernels"),                                            # tiles below 16 px
+        (dict(pu_per_tu=16, **CFG2), 64, "two-kernels", "one-kernel"),                                             # 128 x 128 px ... 224 x 224: the one-kernel form's
+        (dict(pu_per_tu=20, **CFG2), 64, "two-kernels", "one-kernel"),
+        (dict(pu_per_tu=24, **CFG2), 64, "two-kernels", "one-kernel"),
+        (dict(pu_per_tu=28, **CFG2), 64, "two-kernels", "one-kernel"),
+        (dict(pu_per_tu=24, height_tile_map_tu=12, width_tile_map_tu=12, num_rays=128), 16, "two-kernels", "two-kernels"),   # 288 x 288 at 24 px
+        (dict(pu_per_tu=13, height_tile_map_tu=9, width_tile_map_tu=9, num_rays=64), 16, "one-kernel", "one-kernel"),       # 117 rows: no multiple of 4
+        (dict(pu_per_tu=6, height_tile_map_tu=10, width_tile_map_tu=9, num_rays=64), 16, "one-kernel", "one-kernel"),       # 6-px tiles, 60 rows
+        (dict(pu_per_tu=32, height_camera_view_pu=128, **CFG2), 16, "one-kernel", "one-kernel"),                   # 4 MiB of top view beside a 128-row camera view: no side stream
+        (dict(pu_per_tu=32, height_tile_map_tu=50, width_tile_map_tu=40, num_rays=128), 2, "in-place", "in-place"),         # bit plane beyond LDS
+    )
+    import torch
+
+    rng = np.random.default_rng(8)
+    for kw, batch, in_step, alone in cases:
+        env, orc = _make(rcw, oracle, batch, seed=6, render_top_view=1, out_of_bounds=1, **kw)
+        assert (env.top_view_form(), env.update_top_view_form()) == (in_step, alone), (kw, env.top_view_form(), env.update_top_view_form())
+        for _ in range(3):
+            a = rng.integers(1, 5, batch).astype(np.uint8)
+            rcw.act_(env, a); orc.step(a)
+        env.sync()
+        env.top_view.torch().zero_()                                        # what the call alone writes, all of it
+        torch.cuda.synchronize()
+        rcw.update_top_view_(env)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view, err_msg=f"stand-alone {kw}")
+        env.close()
+    env = rcw.SingleRoomModule.SingleRoom(batch=2, seed=1, **CFG1)           # no top view at all
+    assert env.update_top_view_form() == "none"
+    env.close()
+
+
 def test_top_view_form_of_other_geometries(rcw):
     """What is not eligible for the two-kernel form keeps the one-kernel (LDS bit planes) or the in-place form.  Where a step's
     camera fill and the drawing go in one launch (256-row camera view, planes of a 256-thread draw workgroup) the two-kernel

@@ -757,28 +757,3 @@ def test_draw_kernel_leaves_out_only_pixels_that_other_lines_draw(oracle):
             total_all += sum(_line_geom(e, ip, jp)[0] + 1 for e in ends); total_walked += nwalk
         orc.close()
     assert total_walked < 0.75 * total_all          # (and it is worth it: a quarter of the pixel-steps, at least, over these shapes)
-
-
-def test_draw_kernel_ray_order_is_a_permutation_by_class():
-    """rcw_kernels.hip::draw_ray_of_position, restated: position p of N -> ray; every ray exactly once, in the order of the trailing
-    zeros of its index (every other ray first ... ray 0 last), for every N up to 300 and a few large ones."""
-    def clz(x):
-        return 32 - int(x).bit_length()
-
-    def ray_of(p, N):
-        last, r = N - 1, N - 1 - p
-        if r <= 0:
-            return 0
-        u = clz(r) - clz(last)
-        if (last >> u) < r:
-            u -= 1
-        return ((p - (last - (last >> u))) << (u + 1)) + (1 << u)
-
-    for N in list(range(1, 301)) + [512, 1000, 1024, 4095, 4096, 16383]:
-        rays = [ray_of(p, N) for p in range(N)]
-        assert sorted(rays) == list(range(N)), N
-        tz = [((r & -r).bit_length() - 1) if r else 99 for r in rays]
-        assert tz == sorted(tz), N                                         # class by class
-        for u in set(tz):
-            cls = [r for r, t in zip(rays, tz) if t == u]
-            assert cls == sorted(cls), (N, u)                              # ... and in ray order inside a class

@@ -40,6 +40,8 @@ for H, W, pu, N in SHAPES:
     for _ in range(10):
         RCW.update_top_view_(env)
     alone = env.timer_stop() / 10
+    gib = by / 2 ** 30
     print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d} {env.top_view_form():11s}: in a step {t * 1e3:7.1f} us "
-          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %), camera fill beside it {f * 1e3:7.1f} us, stand-alone {alone * 1e3:7.1f} us", flush=True)
+          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %), camera fill beside it {f * 1e3:7.1f} us, stand-alone ({env.update_top_view_form()}) {alone * 1e3:7.1f} us "
+          f"= {alone * 1e3 / gib:6.1f} us / GiB", flush=True)
     env.sync(); env.close()
