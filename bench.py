@@ -141,6 +141,19 @@ def reduce_rank_times(rows, steps):
     }
 
 
+def gather_rank_rows(dist, world, values, device="cpu"):
+    """Every rank's row of figures on every rank, [world][len(values)]: ONE all-gather (flat output, the form gloo and RCCL both
+    take), always OUTSIDE a timed region.  `dist` None (a single rank without a process group): the one row."""
+    if dist is None:
+        return [[float(v) for v in values]]
+    import torch
+
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    allt = torch.empty(world * len(values), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(allt, t)
+    return allt.view(world, len(values)).cpu().tolist()
+
+
 def top_view_scratch_bytes(H, W, pu, B):
     """What the top view's drawing leaves in HBM for the store kernel, per launch: the ray-line bit plane (one bit a
     pixel), the player's pixel (8 B an agent) and the 2-bit tile codes (8 B per tile column and 256-row run)."""
@@ -338,13 +351,7 @@ def main():
     cpu_coll = args.rehearse_on_one_gpu              # gloo moves host tensors only
 
     def gather_rows(values):
-        """Every rank's row of figures on every rank, [world][len(values)] (one all-gather, OUTSIDE every timed region)."""
-        if dist is None:
-            return [[float(v) for v in values]]
-        t = torch.tensor(values, dtype=torch.float64, device="cpu" if cpu_coll else "cuda")
-        allt = torch.empty((world, len(values)), dtype=torch.float64, device=t.device)
-        dist.all_gather_into_tensor(allt, t)
-        return allt.cpu().tolist()
+        return gather_rank_rows(dist, world, values, "cpu" if cpu_coll else "cuda")
 
     for s in range(args.warmup):
         RCW.act_(env, actions[s])

@@ -177,7 +177,7 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
     if (prof && (e = hipEventRecord(ev[0], h->stream)) != hipSuccess) return e;
 #ifdef RCW_DEV_SWITCHES
     if (h->step_pieces == 2 && !d.top_view && h->top_stream && d.B >= 2) {
-        // Development experiment (RCW_STEP_PIECES=2): the batch in two halves, the second half's cast kernel on
+        // Development experiment (RCW_STEP_PIECES=2, docs/experiments.md): the batch in two halves, the second half's cast kernel on
         // the side stream BESIDE the first half's fill: cast(1) | fork | fill(1) ∥ cast(2) | join | fill(2).
         const int B1 = d.B / 2, B2 = d.B - B1;
         const long long cols1 = (long long)B1 * d.N;
@@ -200,7 +200,7 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
 #endif
 #ifdef RCW_DEV_SWITCHES
     if (d.step_fused && rcw_step_fusable(d)) {
-        // Development experiment (RCW_STEP_FUSED=1): cast and camera fill in ONE launch
+        // Development experiment (RCW_STEP_FUSED=1, docs/experiments.md): cast and camera fill in ONE launch
         if (prof && ((e = hipEventRecord(ev[1], h->stream)) != hipSuccess || (e = hipEventRecord(ev[2], h->stream)) != hipSuccess)) return e;
         h->dev.step_epoch = ++h->step_epoch;
         if ((e = rcw_launch_step256(d, actions_dev, mask_dev, h->step_epoch, h->stream)) != hipSuccess) return e;
@@ -815,6 +815,8 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_PLAIN")) d.fill_plain = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
+    d.fill_pairs = 0;
+    if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT_PAIRS")) d.fill_pairs = std::atoi(v) ? 1 : 0;
     d.top_draw_r4 = 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW")) d.top_draw_r4 = std::strcmp(v, "r4") == 0 ? 1 : 0;
     d.top_rotate = 33;                                                       // (measured: rcw_kernels.hip, rcw_top_store_flat_kernel)

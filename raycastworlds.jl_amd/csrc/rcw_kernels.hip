@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kBlock) void rcw_cast_kernel(const RcwDev p,
 }
 
 #ifdef RCW_DEV_SWITCHES
-// Development build only (RCW_CAST_WAVES=1), measured and rejected: the same with a WAVEFRONT per agent, four agents a
+// Development build only (RCW_CAST_WAVES=1), measured and rejected (docs/experiments.md): the same with a WAVEFRONT per agent, four agents a
 // workgroup — a quarter of the workgroups for the dispatcher to hand out, no s_barrier.  The 4096 workgroups of cfg-2 then enter within
 // 0.9 us instead of 1.6, and the kernel takes 11.5 us instead of 11.2 (cfg-4's shard: 20.2 vs 19.3): the wavefronts live longer by what
 // they no longer wait to be dispatched — the SIMDs' issue slots bound the kernel, not the dispatcher.  agents [first, last).
@@ -865,7 +865,7 @@ __device__ __forceinline__ void fill256_body(const RcwDev& p, const int32_t* __r
         uint32_t colour_l = 0u;
         if (mine < total_cols && (mask == nullptr || mask[mine / p.N] != 0)) {
             // THREE DEPENDENT round trips, on purpose: height -> colour id -> colour.  This prefetch is part of the kernel's pace
-            // (DESIGN.md §4.2 / §4.6): every shorter form measured — the two loads issued together, a packed word, the colour by
+            // (docs/experiments.md): every shorter form measured — the two loads issued together, a packed word, the colour by
             // selects — makes the kernel SLOWER, and the more so the larger the batch.  Round 4 found that out a fourth time: with
             // this body moved into a function the compiler issued both loads at once, and the fill of an 8 GiB batch took 1420 us
             // instead of 1250 (1 GiB: 158 instead of 156.5).  The empty asm statements pin the order the round-1 kernel had.
@@ -1187,8 +1187,12 @@ __device__ __forceinline__ u32x4 flat_fill_pixels(int r, int Hc, uint4 d0, uint4
     return v;
 }
 
-template <bool ALIGNED, int K>                                           // K = the columns a chunk may touch (254 / H_cam + 2)
-__global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
+// PAIR (development build, RCW_FILL_FLAT_PAIRS=1: measured, profiles/r05_flat_kernels.txt): workgroups of EIGHT wavefronts, two to a
+// slot of the window — wavefronts w and w + 4 make the same group's descriptors and take its chunks by turns (t even / odd) —: the
+// same compact window, twice the issue slots (a wavefront alone on its SIMD issues a vector instruction every four cycles, two
+// wavefronts one every two).
+template <bool ALIGNED, int K, bool PAIR = false>                       // K = the columns a chunk may touch (254 / H_cam + 2)
+__global__ __launch_bounds__(PAIR ? 2 * kBlock : kBlock) void rcw_fill_flat_kernel(const RcwDev p,
                                                                const int32_t* __restrict__ col_h,
                                                                const uint8_t* __restrict__ col_c,
                                                                uint32_t* __restrict__ out, long long total_cols,
@@ -1196,8 +1200,10 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63;
+    constexpr int STEP = PAIR ? 2 : 1;                                    // chunks of a group between two of this wavefront's
+    const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;   // which of a slot's two wavefronts
     const uint32_t G = gridDim.x * (kBlock / 64);
-    const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3u);
     uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
     asm volatile("" : "+v"(ceil_c), "+v"(floor_c));                         // (in vector registers once: a v_cndmask reads at most one scalar)
     const int Hc = p.Hc;
@@ -1258,20 +1264,20 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
             grp += 1;
         }
 #endif
-        u32x4* dst = out4 + base * 64;                                       // wave-uniform
+        u32x4* dst = out4 + base * 64 + (unsigned long long)half * dstep;    // wave-uniform
         if (__ballot(state_l == 3) == ~0ull) {
             // every chunk of the group is whole and unmasked: no branch in the loop, the next chunk's pair(s) on their way
             int rel, r, rel_n, r_n;
-            flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Hc, rel, r);
-            uint4 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
+            flat_locate(L, __builtin_amdgcn_readlane(rem_l, half), Hc, rel, r);
+            uint4 d0 = desc[half * KS + rel], d1 = ALIGNED ? d0 : desc[half * KS + rel + 1];
             // (measured, µs per GiB: four-pixel groups inside one column 162 / 163 / 173 / 182 unrolled by 1 / 2 / 4 / 8 — unrolled, the
             // compiler bunches the stores of several chunks together, and the memory system takes evenly spaced stores best —;
             // groups that straddle columns, with their longer arithmetic, 182 / 177 / 171 / 171)
 #pragma unroll (ALIGNED ? 1 : 4)
-            for (int t = 0; t < 64; ++t, dst += dstep) {
+            for (int t = half; t < 64; t += STEP, dst += STEP * dstep) {
                 // (the last trip fetches a 65th chunk's pair: lane 0's row again, and whatever lies behind in LDS; unused)
-                flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Hc, rel_n, r_n);
-                const uint4 n0 = desc[(t + 1) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + 1) * KS + rel_n + 1];
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + STEP), Hc, rel_n, r_n);
+                const uint4 n0 = desc[(t + STEP) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + STEP) * KS + rel_n + 1];
                 bool ok[4];
                 const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
                 __builtin_nontemporal_store(v, dst + lane);
@@ -1285,21 +1291,22 @@ __global__ __launch_bounds__(kBlock) void rcw_fill_flat_kernel(const RcwDev p,
             const int n_fast = (int)__builtin_ctzll(~whole);                 // (not all ones here)
             if (n_fast >= 4) {
                 int rel, r, rel_n, r_n;
-                flat_locate(L, __builtin_amdgcn_readlane(rem_l, 0), Hc, rel, r);
-                uint4 d0 = desc[rel], d1 = ALIGNED ? d0 : desc[rel + 1];
+                flat_locate(L, __builtin_amdgcn_readlane(rem_l, half), Hc, rel, r);
+                uint4 d0 = desc[half * KS + rel], d1 = ALIGNED ? d0 : desc[half * KS + rel + 1];
 #pragma unroll 1
-                for (int t = 0; t < n_fast; ++t, dst += dstep) {
-                    flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + 1), Hc, rel_n, r_n);
-                    const uint4 n0 = desc[(t + 1) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + 1) * KS + rel_n + 1];
+                for (int t = half; t < n_fast; t += STEP, dst += STEP * dstep) {
+                    flat_locate(L, __builtin_amdgcn_readlane(rem_l, t + STEP), Hc, rel_n, r_n);
+                    const uint4 n0 = desc[(t + STEP) * KS + rel_n], n1 = ALIGNED ? n0 : desc[(t + STEP) * KS + rel_n + 1];
                     bool ok[4];
                     const u32x4 v = flat_fill_pixels<ALIGNED>(r, Hc, d0, d1, ceil_c, floor_c, ok);
                     __builtin_nontemporal_store(v, dst + lane);
                     d0 = n0; d1 = n1; r = r_n;
                 }
             }
-            const int t_first = n_fast >= 4 ? n_fast : 0;
+            int t_first = n_fast >= 4 ? n_fast : 0;
+            if (PAIR) { t_first += ((t_first ^ half) & 1); dst = out4 + base * 64 + (unsigned long long)t_first * dstep; }   // this wavefront's next chunk of the group
 #pragma unroll 2
-            for (int t = t_first; t < 64; ++t, dst += dstep) {
+            for (int t = t_first; t < 64; t += STEP, dst += STEP * dstep) {
                 const int s_state = __builtin_amdgcn_readlane(state_l, t);
                 if (!(s_state & 1)) continue;                                // wave-uniform: past the end
                 int rel, r;
@@ -3413,8 +3420,13 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
     case kFillFlat: {
         // the moving window over 256-pixel chunks of the flat batch
         const int K = rcw_fill_flat_cols(p);
-        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint4) + 256;   // (+ the fast loop reads a 65th chunk's pairs behind the last wavefront's)
+        const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint4) + 512;   // (+ the fast loop reads a 65th chunk's pairs behind the last wavefront's)
+#ifdef RCW_DEV_SWITCHES
+#define RCW_FILL_FLAT(AL, KK) do { if (p.fill_pairs) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK, true>), dim3(grid), dim3(2 * kBlock), 2 * lds, s, p, col_h, col_c, frames, total_cols, mask_dev); \
+                                   else hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev); } while (0)
+#else
 #define RCW_FILL_FLAT(AL, KK) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev)
+#endif
 #define RCW_FILL_FLAT_K(KK) case KK: if ((p.Hc & 3) == 0) RCW_FILL_FLAT(true, KK); else RCW_FILL_FLAT(false, KK); break
         switch (K) { RCW_FILL_FLAT_K(2); RCW_FILL_FLAT_K(3); RCW_FILL_FLAT_K(4); RCW_FILL_FLAT_K(5); RCW_FILL_FLAT_K(6); RCW_FILL_FLAT_K(7); RCW_FILL_FLAT_K(8);
                      RCW_FILL_FLAT_K(9); RCW_FILL_FLAT_K(11); RCW_FILL_FLAT_K(12);

@@ -59,7 +59,7 @@ def test_the_checker_sees_a_hazard_when_there_is_one(tmp_path):
 
 
 def test_the_fill_kernels_prefetch_keeps_its_three_dependent_round_trips():
-    """rcw_fill256_kernel's descriptor prefetch is part of its pace: height -> colour id -> colour, each
+    """rcw_fill256_kernel's descriptor prefetch is part of its pace (docs/experiments.md): height -> colour id -> colour, each
     load awaited before the next is issued.  Every shorter form measured makes the kernel slower, the more so the larger the
     batch — round 4 lost 13 % at 8 GiB when a refactoring let the compiler issue the first two loads together.  Checked on the
     ISA of the kernel proper and of rcw_fill256_draw_kernel (the same body beside the top view's drawing)."""

@@ -1271,7 +1271,7 @@ def test_lds_staged_ray_table_gives_the_same_rays(rcw, oracle, monkeypatch):
 
 @pytest.mark.parametrize("form", ["1", "2"])
 def test_whole_step_in_one_launch_gives_the_same_frames(rcw, oracle, monkeypatch, form):
-    """Development switch RCW_STEP_FUSED of the development build (measured and rejected): cast and camera fill
+    """Development switch RCW_STEP_FUSED of the development build (measured and rejected, docs/experiments.md): cast and camera fill
     in ONE launch, the column descriptors handed from the casting wavefronts to the fill workgroups inside it — through a
     per-agent flag (1) or through words that carry the step's epoch (2).  Same frames, same state, with masked resets and
     auto-reset; also in Float64 and with a batch that is not a multiple of a workgroup's four agents."""

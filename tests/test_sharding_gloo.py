@@ -183,3 +183,46 @@ def test_unique_id_hand_over_between_two_ranks():
     want = bytes((7 * k + 3) & 0xFF for k in range(128))
     assert results[0] == [("unique_id",), ("init", want, 0, 2)]
     assert results[1] == [("init", want, 1, 2)]
+
+
+def _rows_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    rows = bench.gather_rank_rows(dist, world, [0.1 * (rank + 1), 10.0 + rank, 0.011, 0.156 + 0.01 * rank, 0.0])
+    warm = bench.gather_rank_rows(dist, world, [0.0])                 # (the warm-up collective in front of the timed region)
+    q.put((rank, rows, warm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gathers_every_ranks_own_clock():
+    """bench.py, N > 1: the ranks stop their own clocks and the figures are gathered AFTERWARDS — one
+    all-gather in the flat form both gloo and RCCL take.  Three ranks over gloo on the CPU: every rank sees every rank's row in rank
+    order, and the reduction keeps the slowest rank's time and the spread."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    world = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [[0.1 * (r + 1), 10.0 + r, 0.011, 0.156 + 0.01 * r, 0.0] for r in range(world)]
+    for rank, rows, warm in got:
+        assert np.allclose(rows, want) and warm == [[0.0]] * world, (rank, rows)
+    red = bench.reduce_rank_times(got[0][1], steps=20)
+    assert abs(red["dt"] - 0.3) < 1e-12 and abs(red["fill_ms"] - 0.176) < 1e-12 and len(red["per_rank"]) == 3
+    assert abs(red["ms_per_step_min"] - 5.0) < 1e-9 and abs(red["ms_per_step_max"] - 15.0) < 1e-9
