@@ -13,7 +13,8 @@ launch (65,536 agents at most; round 3 capped the batch at 16,384, i.e. 0.4-0.7 
       and the store kernel's bandwidth on the algorithmic bytes 4*(H*pu)*(W*pu)*B against the 8 TB/s HBM peak;
   (b) HIP events on the handle's stream: the top view's time INSIDE a step (the store kernel incl. the wait for the draw
       kernel's event — what the draw kernel does not hide behind the camera fill shows up here), the camera fill of the same
-      step, and rcw_update_top_view alone (one-kernel form; draw + store back to back where the pixel scale is not a multiple of 4).
+      step, and rcw_update_top_view alone with the form it takes (round 5: draw -> store back to back from 256 x 256 px, at pixel scales that
+      are no multiple of 4 and below 16 px a tile; else the one-kernel form), also in us per GiB of top view.
 Kernels: rcw_top_store_kernel (whole 256-row chunks: pu in {{8..256}} dividing 256, H*pu % 256 == 0), rcw_top_store_flat_kernel
 <STRADDLE, NARROW, K> (any pu >= 9, H*pu % 4 == 0 — 256-pixel chunks of the flat batch, K columns a chunk), rcw_top_draw_kernel.
 
