@@ -28,7 +28,7 @@ def _b(x):
 
 
 def fill_flat_label(hc):
-    return f"rcw_fill_flat_kernel<{_b(hc % 4 == 0)}, {254 // hc + 2}>"
+    return f"rcw_fill_flat_kernel<{_b(hc % 4 == 0)}, {254 // hc + 2}, false>"      # (the third parameter: two wavefronts to a slot — the development build's only)
 
 
 def top_flat_label(H, W, pu):
@@ -62,6 +62,7 @@ def test_the_case_lists_cover_every_shipped_instantiation_of_the_flat_kernels():
     # no plain-store variant, no 128-row units kernel: the development build's only
     assert not [n for n in names if re.match(r"rcw_(fill256|top_store|top_store_units)_kernel<true", n)], names
     assert "rcw_top_store_units_kernel<false, 2>" not in names
+    assert not [n for n in names if re.match(r"rcw_fill_flat_kernel<\w+, \d+, true>", n)], names
 
 
 def _steps(rcw, env, orc, rng, n, top):
