@@ -2294,21 +2294,28 @@ __device__ __forceinline__ void top_clipped_line(uint32_t* line, int cb_, int Ht
 
 __device__ __forceinline__ uint32_t lds_address(const void* q) { return (uint32_t)reinterpret_cast<size_t>((__attribute__((address_space(3))) const uint8_t*)q); }
 
-// One pixel-step of the walk for every lane: OR the pixel's bit into the plane, advance along the line, count the steps to the end of
-// the lane's segment down; `wrapped` = the lanes whose segment just ended (they go back to its start: top_draw_body).  A is the BIT
-// address of the pixel in LDS (the plane's own address folded in), f the 32-bit fraction whose carry steps the minor axis (see
-// top_draw).  Hand-scheduled: a VALU instruction that reads vcc needs two others between it and the one that wrote it (gfx950).
-#define RCW_DRAW_STEP(A, f, rem, slope, smaj, sboth, t, m, dd, wrapped)                                                     \
-    asm volatile("v_add_co_u32_e32 %1, vcc, %1, %7\n\t"                                                                     \
+// One pixel-step of the walk for every lane, one asm statement: OR the pixel's bit into the plane, advance along the line, count the
+// steps to the end of the lane's segment down — and, where some lane's segment just ended (vcc, rare against the steps: once per lane
+// and time round its segment), send those lanes back to its start.  A is the BIT address of the pixel in LDS (the plane's own
+// address folded in), f the 32-bit fraction whose carry steps the minor axis (see top_draw).  Hand-scheduled: a VALU instruction that
+// reads vcc needs two others between it and the one that wrote it (gfx950); 8 vector instructions, the ds_or and one branch a pixel
+// (the compiler's loop of round 4: 9 + 1 + a nop + 4 scalar).
+#define RCW_DRAW_STEP(A, f, rem, slope, smaj, sboth, t, m, dd, rem0, f0, A_0)                                               \
+    asm volatile("v_add_co_u32_e32 %1, vcc, %1, %6\n\t"                                                                     \
                  "v_lshrrev_b32_e32 %3, 3, %0\n\t"                                                                           \
                  "v_lshlrev_b32_e64 %4, %0, 1\n\t"                                                                           \
-                 "v_cndmask_b32_e32 %5, %8, %9, vcc\n\t"                                                                     \
+                 "v_cndmask_b32_e32 %5, %7, %8, vcc\n\t"                                                                     \
                  "v_and_b32_e32 %3, 0x1ffffffc, %3\n\t"                                                                      \
-                 "v_sub_co_u32_e64 %2, %6, %2, 1\n\t"                                                                        \
+                 "v_subrev_co_u32_e32 %2, vcc, 1, %2\n\t"                                                                    \
                  "ds_or_b32 %3, %4\n\t"                                                                                      \
-                 "v_add_u32_e32 %0, %0, %5"                                                                                  \
-                 : "+v"(A), "+v"(f), "+v"(rem), "=&v"(t), "=&v"(m), "=&v"(dd), "=s"(wrapped)                                 \
-                 : "v"(slope), "v"(smaj), "v"(sboth) : "vcc", "memory")
+                 "v_add_u32_e32 %0, %0, %5\n\t"                                                                              \
+                 "s_cbranch_vccz 1f\n\t"                                                                                     \
+                 "v_cndmask_b32_e32 %2, %2, %9, vcc\n\t"                                                                     \
+                 "v_cndmask_b32_e32 %1, %1, %10, vcc\n\t"                                                                    \
+                 "v_cndmask_b32_e32 %0, %0, %11, vcc\n"                                                                      \
+                 "1:"                                                                                                        \
+                 : "+v"(A), "+v"(f), "+v"(rem), "=&v"(t), "=&v"(m), "=&v"(dd)                                                \
+                 : "v"(slope), "v"(smaj), "v"(sboth), "v"(rem0), "v"(f0), "v"(A_0) : "vcc", "memory")
 
 // LDS atomic add that returns the old value, by name: through __hip_atomic_fetch_add the compiler wraps every such add in a
 // wavefront-wide reduction loop (its atomic optimizer), two dozen instructions where one is meant
@@ -2509,20 +2516,13 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
             if (q0 == 0 && tid == 0 && a < 2048) g_draw_trace[a * 20 + 8] = (unsigned long long)nmax | ((unsigned long long)M << 32);
 #endif
             uint32_t t_, m_, d_;
-            unsigned long long wrapped;
-            // the lanes whose segment just ended go back to its start (rare against the steps — once per lane and time round its
-            // segment —: a branch; in volatile asm so that it stays one: if-converted, its selects ran in every step)
-            auto rewind = [&]() {
-                asm volatile("v_cndmask_b32_e64 %0, %0, %3, %6\n\tv_cndmask_b32_e64 %1, %1, %4, %6\n\tv_cndmask_b32_e64 %2, %2, %5, %6"
-                             : "+v"(rem), "+v"(frac), "+v"(A) : "v"(len_m1), "v"(frac_s), "v"(A_s), "s"(wrapped));
-            };
             // four steps a trip (up to three more than the longest segment needs: lanes go round their own segments, harmless)
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int trips = (nmax + 3) >> 2; trips > 0; --trips) {
-                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
-                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
-                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
-                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, wrapped); if (wrapped != 0ull) rewind();
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
             }
         }
     }
