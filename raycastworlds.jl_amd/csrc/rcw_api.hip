@@ -816,7 +816,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT")) d.fill_flat = std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DEBUG")) d.top_debug = std::atoi(v);
     d.fill_pairs = 0;
-    if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT_PAIRS")) d.fill_pairs = std::atoi(v) ? 1 : 0;
+    if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT_PAIRS")) d.fill_pairs = std::atoi(v);   // 1: two wavefronts a slot; 2: timing only, a prefetch without loads
     d.top_draw_r4 = 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW")) d.top_draw_r4 = std::strcmp(v, "r4") == 0 ? 1 : 0;
     d.top_rotate = 33;                                                       // (measured: rcw_kernels.hip, rcw_top_store_flat_kernel)

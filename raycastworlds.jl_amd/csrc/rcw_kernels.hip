@@ -1241,6 +1241,9 @@ __global__ __launch_bounds__(PAIR ? 2 * kBlock : kBlock) void rcw_fill_flat_kern
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             const uint32_t c = min(col + (unsigned)j, last_col);
+#ifdef RCW_DEV_SWITCHES
+            if (p.fill_pairs == 2) { hh[j] = (int32_t)(c & 127u); cc[j] = c & 3u; mm[j] = 1u; continue; }   // (timing only, wrong frames: a prefetch without loads — what is the prefetch's latency worth?)
+#endif
             hh[j] = col_h[c];
             cc[j] = (uint32_t)col_c[c];
             mm[j] = mask != nullptr ? (uint32_t)mask[c / (unsigned)p.N] : 1u;   // (wave-uniform branch; the division only with a mask)
@@ -1250,6 +1253,9 @@ __global__ __launch_bounds__(PAIR ? 2 * kBlock : kBlock) void rcw_fill_flat_kern
             const bool valid = j <= touched && col + (unsigned)j <= last_col && mm[j] != 0u;
             const uint32_t pad = (uint32_t)column_padding(Hc, hh[j]);
             if (j <= touched && !valid) all_valid = false;
+#ifdef RCW_DEV_SWITCHES
+            if (p.fill_pairs == 2) { desc[lane * KS + j] = make_uint4(pad, (uint32_t)Hc - pad, 0x808080u + cc[j], valid ? 1u : 0u); continue; }
+#endif
             desc[lane * KS + j] = make_uint4(pad, (uint32_t)Hc - pad, p.colour[cc[j] & 3], valid ? 1u : 0u);
         }
         const int state_l = (exists ? 1 : 0) | (all_valid ? 2 : 0);
@@ -3422,7 +3428,7 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
         const int K = rcw_fill_flat_cols(p);
         const size_t lds = (size_t)(kBlock / 64) * 64 * (K + 1) * sizeof(uint4) + 512;   // (+ the fast loop reads a 65th chunk's pairs behind the last wavefront's)
 #ifdef RCW_DEV_SWITCHES
-#define RCW_FILL_FLAT(AL, KK) do { if (p.fill_pairs) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK, true>), dim3(grid), dim3(2 * kBlock), 2 * lds, s, p, col_h, col_c, frames, total_cols, mask_dev); \
+#define RCW_FILL_FLAT(AL, KK) do { if (p.fill_pairs == 1) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK, true>), dim3(grid), dim3(2 * kBlock), 2 * lds, s, p, col_h, col_c, frames, total_cols, mask_dev); \
                                    else hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev); } while (0)
 #else
 #define RCW_FILL_FLAT(AL, KK) hipLaunchKernelGGL((rcw_fill_flat_kernel<AL, KK>), dim3(grid), dim3(kBlock), lds, s, p, col_h, col_c, frames, total_cols, mask_dev)
