@@ -2204,13 +2204,7 @@ __host__ __device__ __forceinline__ size_t top_draw_lds_words(const RcwDev& p) {
 // through ds_bpermute): the sequences of AMD's cross-lane guide.  dpp0: the other lane's x, 0 where there is none or the row / bank is masked.
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ int dpp0(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, true); }
-__device__ __forceinline__ int wave_sum_in_lane63(int x)                       // (x >= 0; quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, :8, row_bcast:15, :31)
-{
-    x += dpp0<0xB1>(x); x += dpp0<0x4E>(x); x += dpp0<0x124>(x); x += dpp0<0x128>(x);
-    x += dpp0<0x142, 0xA>(x); x += dpp0<0x143, 0xC>(x);
-    return x;
-}
-__device__ __forceinline__ int wave_max_in_lane63(int x)                       // (x >= 0)
+__device__ __forceinline__ int wave_max_in_lane63(int x)                       // (x >= 0; quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, :8, row_bcast:15, :31)
 {
     x = max(x, dpp0<0xB1>(x)); x = max(x, dpp0<0x4E>(x)); x = max(x, dpp0<0x124>(x)); x = max(x, dpp0<0x128>(x));
     x = max(x, dpp0<0x142, 0xA>(x)); x = max(x, dpp0<0x143, 0xC>(x));
@@ -3036,7 +3030,7 @@ __device__ __forceinline__ u32x4 top_flat_pixels(const TopFlatConst& C, int r, u
 // than the 63 newest, i.e. all loads that were followed by at least 63 stores — the stores stay in flight while the
 // descriptors are made.  The destination registers must not be read or copied between the load and the wait: they are
 // written and awaited inside ONE loop iteration (no loop-carried copies), and the wait names them as in/out operands.
-__device__ __forceinline__ void flat_load_b32(uint32_t& dst, const uint32_t* addr) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
+[[maybe_unused]] __device__ __forceinline__ void flat_load_b32(uint32_t& dst, const uint32_t* addr) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
 __device__ __forceinline__ void flat_load_u8(uint32_t& dst, const uint8_t* addr) { asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
 __device__ __forceinline__ void flat_load_b64(unsigned long long& dst, const void* addr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory"); }
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
@@ -3085,7 +3079,7 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     const uint32_t g = blockIdx.x * (kBlock / 64) + (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     const int pu = p.pu, Ht = p.H * pu, Wt = p.W * pu, rp = p.top_rp;
     constexpr int KS = K;
-    const float inv_ht = 1.0f / (float)Ht, inv_pu = 1.0f / (float)pu;
+    const float inv_pu = 1.0f / (float)pu;
     const unsigned px_agent = (unsigned)Ht * (unsigned)Wt;
     const unsigned long long total_px = (unsigned long long)p.B * px_agent;
     const unsigned PW = (unsigned)p.top_plane_words;
@@ -3146,7 +3140,6 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     uint32_t a_cur = col / (unsigned)Wt, j_cur = col - a_cur * (unsigned)Wt;      // (agent, image column) of this lane's next chunk
     const uint32_t dqa = dq / (unsigned)Wt, dqj = dq - dqa * (unsigned)Wt;        // ... move by this much a group (+ 1 column on a row wrap)
     const uint32_t dqa_w = dq_w / (unsigned)Wt, dqj_w = dq_w - dqa_w * (unsigned)Wt;
-    const uint32_t chunks_agent_lo = (uint32_t)(px_agent >> 8);                   // (floor of an image's chunks; the exact first chunk: 64-bit product)
     auto issue = [&](uint32_t base, TopFlatPre<K>& P) {
         const uint32_t id = base + (uint32_t)lane * G;
         const bool exists = id < chunk_end;

@@ -25,7 +25,7 @@ def regs(tok):
 
 def analyse(name, lines):
     # instructions: (text, in_asm); labels -> instruction index
-    ins, labels, in_asm = [], {}, False
+    ins, labels, local, in_asm = [], {}, {}, False
     for t in lines:
         if t.startswith(";;#ASMSTART"):
             in_asm = True; continue
@@ -34,19 +34,29 @@ def analyse(name, lines):
         m = re.match(r"^(\.LBB\w+):", t)
         if m:
             labels[m.group(1)] = len(ins); continue
+        m = re.match(r"^(\d+):$", t)                      # a numeric local label of an asm statement ("1:", branched to as 1f / 1b)
+        if m:
+            local.setdefault(m.group(1), []).append(len(ins)); continue
         if not t or t.startswith((";", ".", "//")):
             continue
         ins.append((t, in_asm))
     n = len(ins)
     succ = [[] for _ in range(n)]
+
+    def target(i, name):
+        m = re.match(r"^(\d+)([fb])$", name)
+        if not m:
+            return labels[name]
+        at = local[m.group(1)]
+        return min(x for x in at if x > i) if m.group(2) == "f" else max(x for x in at if x <= i)
     for i, (t, _) in enumerate(ins):
         op = t.split()[0]
         if op == "s_endpgm":
             continue
         if op == "s_branch":
-            succ[i].append(labels[t.split()[1]]); continue
+            succ[i].append(target(i, t.split()[1])); continue
         if op.startswith("s_cbranch"):
-            succ[i].append(labels[t.split()[1]])
+            succ[i].append(target(i, t.split()[1]))
         if i + 1 < n:
             succ[i].append(i + 1)
     state = [None] * n          # pending registers BEFORE instruction i
