@@ -325,6 +325,13 @@ def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
     assert orc.step(a) == 0
     verify(3)
     every_pixel()
+    if batch >= 12288 and 4 * cfg["height_tile_map_tu"] * cfg["width_tile_map_tu"] * pu * pu * batch <= (4 << 30):
+        # update_top_view!(env) ALONE on a batch of tens of thousands of small images: the draw kernel in workgroups of 64 / 128 threads
+        env.sync()
+        env.top_view.torch().zero_()
+        torch.cuda.synchronize()
+        rcw.update_top_view_(env)
+        every_pixel()
     env.close()
 
 
