@@ -77,6 +77,7 @@ struct rcw_handle {
     void* d_top_view = nullptr;
     // two-kernel top view: planes / player pixels / tile codes in HBM, the side stream the draw kernel runs on
     void* d_top_plane = nullptr; void* d_top_hdr = nullptr; void* d_top_codes = nullptr;
+    void* d_top_flags = nullptr; uint32_t top_epoch = 0;   // the store kernel follows the draw kernel (rcw_kernels.hip: top_publish)
     hipStream_t top_stream = nullptr;
     hipEvent_t ev_top_fork = nullptr;
     hipEvent_t ev_top_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per run of agents
@@ -123,6 +124,31 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         if ((e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;
         return between();
     }
+#ifdef RCW_DEV_SWITCHES
+    // Development experiment (RCW_TOP_FOLLOW = 1 inside a step | 2 alone; measured slower, docs/experiments.md): the store kernel FOLLOWS
+    // the draw kernel where that is safe (rcw_kernels.hip, top_publish): an unmasked whole batch, the two
+    // kernels' workgroups fitting on a CU together (d.top_follow_ok), and no stream capture (a graph would replay this call's number,
+    // and promises no concurrency between its branches).  The draw kernel goes to the side stream, the store kernel to the handle's
+    // WITHOUT waiting for it — agent by agent it waits in memory —, and the handle's stream joins the side stream behind it.
+    bool follow = mask_dev == nullptr && (d.top_follow_ok & (beside ? 1 : 2)) != 0 && !(beside && d.top_fused);
+    if (follow) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) follow = false;
+    }
+    if (follow) {
+        RcwDev dd = d;
+        dd.top_epoch = ++h->top_epoch;                       // (the counters wrap with it: the comparison is modulo 2^32)
+        dd.top_signal = 1; dd.top_follow = 1;
+        if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
+        e = rcw_launch_top_draw(dd, nullptr, 0, d.B, h->top_stream, beside ? 0 : d.top_draw_block_alone);
+        const hipError_t rec = hipEventRecord(h->ev_top_join[0], h->top_stream);
+        if (e == hipSuccess) e = between();
+        if (e == hipSuccess) e = rcw_launch_top_store(dd, nullptr, 0, d.B, h->stream);
+        if (rec == hipSuccess) { const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[0], 0); if (e == hipSuccess) e = w; }
+        return e == hipSuccess ? rec : e;
+    }
+#endif
     if (!beside) {                                           // stand-alone, two kernels back to back on the handle's stream
         if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream, d.top_draw_block_alone)) != hipSuccess) return e;
         if ((e = rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
@@ -249,7 +275,7 @@ void free_all(rcw_handle* h)
     }
     for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
     if (h->top_stream) (void)hipStreamSynchronize(h->top_stream);          // (a draw kernel of a failed step may still run)
-    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_step_flags, &h->d_step_hc}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_top_flags, &h->d_step_flags, &h->d_step_hc}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (h->ev_top_fork) (void)hipEventDestroy(h->ev_top_fork);
     for (hipEvent_t& q : h->ev_top_join) { if (q) (void)hipEventDestroy(q); q = nullptr; }
     if (h->top_stream) (void)hipStreamDestroy(h->top_stream);
@@ -355,8 +381,9 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     const int H = cfg->height_tile_map_tu, W = cfg->width_tile_map_tu, N = cfg->num_rays, Hc = cfg->height_camera_view_pu;
     const size_t B = (size_t)h->B;
     if (h->top_stream) RCW_HIP(hipStreamSynchronize(h->top_stream));
-    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-    d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr;
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_top_flags}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr; d.top_flags = nullptr; h->top_epoch = 0;
+    d.top_blk_shift = 0; d.top_epoch = 0; d.top_signal = 0; d.top_follow = 0; d.top_follow_ok = 0;
     d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
     d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256;
     if (!cfg->render_top_view) {
@@ -457,11 +484,25 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         if (e == hipSuccess) e = hipMalloc(&h->d_top_hdr, (size_t)h->B * sizeof(int2));
         if (e == hipSuccess) e = hipMemsetAsync(h->d_top_hdr, 0, (size_t)h->B * sizeof(int2), h->stream);
         if (e == hipSuccess) e = hipMalloc(&h->d_top_codes, rcw_top_codes_bytes(d));
+#ifdef RCW_DEV_SWITCHES
+        if (e == hipSuccess) e = hipMalloc(&h->d_top_flags, (size_t)h->B * sizeof(uint32_t));                      // (experiment RCW_TOP_FOLLOW)
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_top_flags, 0, (size_t)h->B * sizeof(uint32_t), h->stream);
+#endif
         if (e == hipSuccess && !h->top_stream) e = hipStreamCreateWithFlags(&h->top_stream, hipStreamNonBlocking);
         if (e == hipSuccess && !h->ev_top_fork) e = hipEventCreateWithFlags(&h->ev_top_fork, hipEventDisableTiming);
         for (hipEvent_t& q : h->ev_top_join) if (e == hipSuccess && !q) e = hipEventCreateWithFlags(&q, hipEventDisableTiming);
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "top view planes: %s", hipGetErrorString(e));
         d.top_plane = (uint32_t*)h->d_top_plane; d.top_hdr = (int2*)h->d_top_hdr; d.top_codes = (uint2*)h->d_top_codes;
+#ifdef RCW_DEV_SWITCHES
+        d.top_flags = (uint32_t*)h->d_top_flags;
+        while ((((size_t)h->B + ((size_t)1 << d.top_blk_shift) - 1) >> d.top_blk_shift) > 1024) ++d.top_blk_shift;   // at most 1024 blocks: sixteen looks of a wavefront see them all
+        // the store kernel follows the draw kernel (no event between them) where their workgroups fit on a CU together:
+        // bit 0 inside a step (side-stream form, one run), bit 1 in rcw_update_top_view alone
+        d.top_follow_ok = (!d.top_fused && d.top_runs <= 1 && rcw_top_follow_fits(d, d.top_draw_block, true, h->num_cus) ? 1 : 0) |
+                          (d.top_alone_split && rcw_top_follow_fits(d, d.top_draw_block_alone, false, h->num_cus) ? 2 : 0);
+        { const char* v = RCW_DEV_ENV("RCW_TOP_FOLLOW"); d.top_follow_ok &= v ? std::atoi(v) : 0; }   // (off unless asked for)
+        if (d.top_draw_r4) d.top_follow_ok = 0;
+#endif
     }
     hipError_t e = rcw_prepare_top_view(d, h->device);
     if (e != hipSuccess) return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e));
@@ -528,6 +569,7 @@ int sync_and_check(rcw_handle* h)
     const int32_t e = h->h_err[0];
     if (e == RCW_ERR_INVALID_ACTION) return fail(e, "invalid action (must be in 1..%d); the agents it was given to were not stepped (rcw_status)", RCW_NUM_ACTIONS);
     if (e == RCW_ERR_OUT_OF_BOUNDS) return fail(e, "a tile index left the tile map (BoundsError in the reference)");
+    if (e == RCW_ERR_HIP) return fail(e, "a kernel gave up waiting for another one after about a second (the top view's store kernel for its draw kernel): the images of that call are not valid");
     if (e != 0) return fail(e, "device error %d", e);
     return RCW_OK;
 }

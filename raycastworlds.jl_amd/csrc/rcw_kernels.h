@@ -75,6 +75,13 @@ struct RcwDev {
     uint32_t* top_plane;     // [B][W*pu][H*pu/32] ray-line bit plane of every agent (two-kernel top view)
     int2* top_hdr;           // [B] the player's pixel (ip, jp), 1-based  SR:468
     uint2* top_codes;        // [B][W][H*pu/256] 2-bit fill codes of a chunk's tiles
+    // the store kernel FOLLOWS the draw kernel (round 5): both run at once on two streams, ordered through memory instead of an event
+    uint32_t* top_flags;     // [blocks of 2^top_blk_shift agents] how many of the block's agents' planes, headers and codes were written, over all calls
+    int32_t top_blk_shift;
+    uint32_t top_epoch;      // this call's number among the calls that count: a complete block stands at top_epoch x its agents
+    int32_t top_signal;      // draw kernel: publish each agent as it is done
+    int32_t top_follow;      // store kernels: wait for the agents of a group of chunks before loading anything of theirs
+    int32_t top_follow_ok;   // (host) the geometry's draw and store workgroups fit on a CU together, in a step (bit 0) / alone (bit 1)
     int32_t top_rotate;      // rcw_top_store_flat_kernel's wavefront -> chunk assignment turns by this many slots from group to group (33; development: RCW_TOP_ROTATE)
     int32_t fill_trips;      // development only (RCW_FILL_TRIPS=0..3): rcw_fill256_kernel's body with that many more dependent round trips a prefetch; -1: the kernel proper
     int32_t step_fused;      // development only (RCW_STEP_FUSED=1): cast and camera fill in ONE launch (rcw_step256_kernel), handed off through the two arrays below
@@ -117,6 +124,7 @@ int rcw_fill_flat_cols(const RcwDev& p);   // rcw_fill_flat_kernel: columns a ch
 const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // the kernel rcw_launch_fill takes
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
+int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int cus);   // draw + store (+ camera fill) workgroups resident on one CU together
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block = 0);    // agents [first, first + count); block: threads a workgroup, 0 = p.top_draw_block
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
 #ifdef RCW_DEV_SWITCHES

@@ -2098,6 +2098,31 @@ __global__ __launch_bounds__(kTopBlock, 6) void rcw_top_view_kernel(const RcwDev
 // quarters of one: pu in {8, 16, 32, 64, 128, 256}, H·pu a multiple of 256; and the player's circle fits one
 // 32-bit mask per image column (2·rp + 1 <= 32).  Other geometries keep the ring kernel.
 //
+// ---- EXPERIMENT, development build only (RCW_TOP_FOLLOW, docs/experiments.md): the store kernel FOLLOWS the draw kernel.  Launched
+// on two streams with no event between them, the two run at once: the draw workgroup of agent a, when its plane, header and codes
+// are in memory, adds one to the counter of the agent's BLOCK (2^p.top_blk_shift consecutive agents; the counters are never reset:
+// after the call numbered p.top_epoch a complete block stands at epoch x its agents); a storing wavefront, before it loads anything
+// of a group of 64 chunks, waits until every block up to the group's last agent is complete — 64 counters a look, one per lane.
+// What the draw kernel publishes goes out as write-through stores (sc0 sc1: through the XCD's L2 to memory) — a release fence in
+// front of the counter writes the WHOLE L2 back instead, the store kernel's gigabyte of pixels included, once per agent (100 us an
+// agent); the counters are relaxed agent-scope atomics; a wavefront that has seen its blocks complete invalidates its caches once
+// (acquire) and reads on with ordinary loads.  Bit-exact — and SLOWER than draw -> store back to back at every shape (a wavefront's
+// look drains its stores, every advance invalidates an L2 under the window): rejected, not in the shipped library.
+#ifdef RCW_DEV_SWITCHES
+__device__ __forceinline__ void store_through(uint32_t* q, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(uint2* q, uint2 v)
+{
+    const unsigned long long w = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(q), "v"(w) : "memory");
+}
+__device__ __forceinline__ void top_publish(const RcwDev& p, int a)         // one thread of the draw workgroup, behind its last barrier
+{
+    if (p.top_debug & 16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a full release in front of the counter)
+    if (p.top_debug & 128) return;                                             // (nothing is published — the store kernel must give up)
+    (void)__hip_atomic_fetch_add(p.top_flags + ((uint32_t)a >> p.top_blk_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 #ifdef RCW_DEV_SWITCHES
 // ---- the ROUND-4 draw body (development build only, RCW_TOP_DRAW=r4): for the comparison with top_draw_body below ----
 // Draw kernel: one workgroup per agent; what the draw group of the ring kernel does, then the line plane is copied
@@ -2194,6 +2219,11 @@ __device__ __forceinline__ void top_draw_body_r4(const RcwDev& p, const uint8_t*
 // cfg-2), so this body (a) asks for everything it needs from HBM in two batches, as rcw_cast_kernel does; (b) does not walk what
 // another lane walks anyway — see top_covered_prefix: exact, the planes are bit for bit those of the round-4 body —; (c) has no
 // integer or Float64 division in its set-up; (d) walks with a hand-scheduled loop of 8 vector instructions a pixel.
+#ifdef RCW_DEV_SWITCHES
+#define RCW_PLANE_STORE(q, v) do { if (p.top_signal) store_through((q), (v)); else *(q) = (v); } while (0)   // (the experiment above: write-through where the draw kernel publishes)
+#else
+#define RCW_PLANE_STORE(q, v) (*(q) = (v))
+#endif
 constexpr int kDrawRays = 2;                // rays a lane holds from the early table loads (more rays a lane take a loop)
 constexpr uint32_t kNoLine = 0xFFFFFFFFu;   // the ray's line is not in the list: off-image end points (walked at once, clipped), or no such ray
 // words of the draw kernel's LDS: the one-kernel form's buffer | the rays' end pixels [N] | what is left of each ray's line [N] | the lines to walk,
@@ -2529,7 +2559,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
     RCW_DRAW_STAMP(3);
     __syncthreads();
     RCW_DRAW_STAMP(4);
-    if (tid == 0) p.top_hdr[a] = make_int2(ip, jp);
+    if (tid == 0) RCW_PLANE_STORE(reinterpret_cast<uint2*>(p.top_hdr + a), make_uint2((uint32_t)ip, (uint32_t)jp));
     if (p.top_flat) {
         // rcw_top_store_flat_kernel's plane: the bit of agent pixel q = (j-1)·Ht + (i-1) sits at bit s + q of the agent's
         // region of p.top_plane_words words, s = (a · Ht·Wt) mod 256 — where the agent's image starts inside its first
@@ -2562,11 +2592,16 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
                 }
                 word = bits << lead;
             }
-            out[w] = word;
+            RCW_PLANE_STORE(out + w, word);
         }
 #ifdef RCW_TRACE_WAVES
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         RCW_DRAW_STAMP(5);
+#endif
+#ifdef RCW_DEV_SWITCHES
+    #ifdef RCW_DEV_SWITCHES
+    if (p.top_signal) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) top_publish(p, a); }   // (the write-through stores above: written by name, awaited by name)
+#endif
 #endif
         return;
     }
@@ -2576,7 +2611,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
     int j = tid / wpu, w = tid - j * wpu;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int idx = tid; idx < total; idx += group) {
-        out[idx] = b.line[j * wpc + w];
+        RCW_PLANE_STORE(out + idx, b.line[j * wpc + w]);
         j += qstep; w += rstep;
         if (w >= wpu) { w -= wpu; j += 1; }
     }
@@ -2588,11 +2623,14 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
             const uint32_t code = (tiles[t] & 1u) ? 1u : (tiles[t] & 2u);          // wall (white) before goal (red)  SR:355-360
             if (t < 16) lo |= code << (2 * t); else hi |= code << (2 * (t - 16));
         }
-        p.top_codes[((size_t)a * p.W + tj) * k + rb] = make_uint2(lo, hi);
+        RCW_PLANE_STORE(p.top_codes + ((size_t)a * p.W + tj) * k + rb, make_uint2(lo, hi));
     }
 #ifdef RCW_TRACE_WAVES
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RCW_DRAW_STAMP(5);
+#endif
+#ifdef RCW_DEV_SWITCHES
+    if (p.top_signal) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) top_publish(p, a); }   // (the write-through stores above: written by name, awaited by name)
 #endif
 }
 
@@ -2718,6 +2756,34 @@ __device__ __forceinline__ u32x4 top_chunk_pixels(const TopLane& L, uint32_t wor
     return o;
 }
 
+#ifdef RCW_DEV_SWITCHES   // (the experiment in front of the draw bodies: the store kernel's half)
+constexpr int kFollowSpins = 400000;        // x (s_sleep 32 ~ 0.9 us + a load's round trip): about a second
+// wave-uniform: returns when every block of agents up to agent `need`'s is complete; `have` = the leading complete blocks this wavefront knows of
+__device__ __forceinline__ void top_follow_wait(const RcwDev& p, uint32_t need, uint32_t& have)
+{
+    const uint32_t sh = (uint32_t)p.top_blk_shift, need_blk = need >> sh;
+    if (need_blk < have) return;
+    const uint32_t nblk = ((uint32_t)p.B + (1u << sh) - 1u) >> sh, lane = threadIdx.x & 63u;
+    for (int spins = 0; ; ++spins) {
+        const uint32_t b = min(have + lane, nblk - 1u);                      // (lanes past the last block look at it again)
+        const uint32_t agents = min(1u << sh, (uint32_t)p.B - (b << sh));
+        uint32_t c = __hip_atomic_load(p.top_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.top_debug & 32) c = __hip_atomic_fetch_add(p.top_flags + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (look with a read-modify-write)
+        if (p.top_debug & 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const unsigned long long done = __ballot(c == p.top_epoch * agents);
+        const uint32_t run = done == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~done);
+        have = min(have + run, nblk);
+        if (have > need_blk) {                                               // one acquire per advance, not per look: it invalidates the XCD's L2
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return;
+        }
+        if (run == 64u) continue;                                            // (all 64 complete: look at the next 64 at once)
+        if (spins >= kFollowSpins) { p.err[0] = RCW_ERR_HIP; have = 0xFFFFFFFFu; return; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+#endif
+
 // A group = the next 64 chunks of a wavefront; lane l holds the descriptor of the l-th.
 struct TopGroup {
     int flags, r0, woff;         // bit 0 valid, bit 1 frame column | chunk row of the circle mask's bit 0 | plane word offset
@@ -2792,8 +2858,15 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_kernel(const RcwDev p, c
     uint32_t* const lw_write = plane_words + (threadIdx.x >> 6) * 512 + lane;
     const uint32_t* const lw_read = plane_words + (threadIdx.x >> 6) * 512 + (lane >> 3);
     uint32_t base = chunk_begin + g;
+    [[maybe_unused]] uint32_t have = 0u;                                     // (development experiment RCW_TOP_FOLLOW: blocks of agents known to be drawn)
     for (; base < total; base += G * 64) {
         TopGroup cur;
+#ifdef RCW_DEV_SWITCHES
+        if (p.top_follow) {                                                  // the agent of the group's last chunk
+            const uint32_t id_last = min(base + 63u * G, total - 1u);
+            top_follow_wait(p, id_last / (((uint32_t)(p.H * p.pu) >> 8) * (uint32_t)(p.W * p.pu)), have);
+        }
+#endif
         top_group_issue(p, mask, base, G, total, lane, cur);
         top_group_finish(p, L, cur);
         // the plane words go through a wave-private 2 KiB of LDS (index 8 t + word: lane l's register m is entry
@@ -2858,7 +2931,15 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_units_kernel(const RcwDe
     uint32_t* const desc = ws + 512;                                         // [64 chunks][U]
     uint32_t* const circ = desc + 64 * U;
     uint32_t* const crow = circ + 64 * U;
+    [[maybe_unused]] uint32_t have = 0u;                                     // (development experiment RCW_TOP_FOLLOW: blocks of agents known to be drawn)
     for (uint32_t base = chunk_begin + g; base < total; base += G * 64) {
+#ifdef RCW_DEV_SWITCHES
+        if (p.top_follow) {                                                  // the agent of the last unit of the group's last chunk
+            const uint32_t id_last = min(base + 63u * G, total - 1u);
+            const uint32_t un_last = min(id_last * U + (U - 1), total_units - 1u);
+            top_follow_wait(p, un_last / (k * (uint32_t)Wt), have);
+        }
+#endif
         const uint32_t id = base + (uint32_t)lane * G;
         uint32_t packed[U], cmask[U];
         int r0[U];
@@ -3140,9 +3221,14 @@ __global__ __launch_bounds__(kBlock) void rcw_top_store_flat_kernel(const RcwDev
     uint32_t a_cur = col / (unsigned)Wt, j_cur = col - a_cur * (unsigned)Wt;      // (agent, image column) of this lane's next chunk
     const uint32_t dqa = dq / (unsigned)Wt, dqj = dq - dqa * (unsigned)Wt;        // ... move by this much a group (+ 1 column on a row wrap)
     const uint32_t dqa_w = dq_w / (unsigned)Wt, dqj_w = dq_w - dqa_w * (unsigned)Wt;
+    [[maybe_unused]] uint32_t have = 0u;                                     // (development experiment RCW_TOP_FOLLOW: blocks of agents known to be drawn)
     auto issue = [&](uint32_t base, TopFlatPre<K>& P) {
         const uint32_t id = base + (uint32_t)lane * G;
         const bool exists = id < chunk_end;
+#ifdef RCW_DEV_SWITCHES
+        if (p.top_follow)                                                    // the last agent any of the group's chunks touches (the assignment turns: no lane order)
+            top_follow_wait(p, (uint32_t)__builtin_amdgcn_readlane(wave_max_in_lane63(exists ? (int)min(a_cur + 1u, last_agent) : 0), 63), have);
+#endif
         P.rem = rem; P.a0 = a_cur; P.j0 = j_cur;
         int touched = 0;
 #pragma unroll
@@ -3595,6 +3681,21 @@ hipError_t rcw_launch_fill256_draw(const RcwDev& p, const uint8_t* mask_dev, hip
     RCW_DISPATCH(rcw_fill256_draw_kernel, dim3(p.fill_grid + p.B), dim3(kBlock), 4 * top_draw_lds_words(p), p, p.col_h, p.col_c, frames4,
                  (long long)p.B * p.N, mask_dev, p.fill_grid, 0);
     return hipGetLastError();
+}
+// The store kernel may FOLLOW the draw kernel (top_follow_wait) only where a draw workgroup still finds room on a CU whose store
+// workgroups — resident for the whole launch, and waiting — are already there (and, inside a step, the camera fill's): wavefronts
+// (32 a CU; 28 counted, what the draw kernel was seen to reach) and LDS (160 KiB).
+int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int cus)
+{
+    if (!p.top_split || cus <= 0) return 0;
+    const int store_wgs = (p.top_store_grid + cus - 1) / cus;               // per CU
+    size_t store_lds = (kBlock / 64) * 512 * 4;                              // rcw_top_store_kernel's plane words
+    if (p.top_flat) store_lds = top_store_flat_lds_bytes(p, p.top_flat);
+    else if (p.top_unit_px != 256) store_lds = (size_t)(kBlock / 64) * (512 + 3 * 64 * (256 / p.top_unit_px)) * 4;
+    const int fill_wgs = beside_fill ? (p.fill_grid + cus - 1) / cus : 0;
+    const int waves = draw_block / 64 + (store_wgs + fill_wgs) * (kBlock / 64);
+    const size_t lds = 4 * top_draw_lds_words(p) + store_wgs * (store_lds + 512) + fill_wgs * (size_t)(8 * 1024);
+    return waves <= 28 && lds <= 156 * 1024 ? 1 : 0;
 }
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s)
 {
