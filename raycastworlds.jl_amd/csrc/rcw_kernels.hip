@@ -2226,9 +2226,17 @@ __device__ __forceinline__ void top_draw_body_r4(const RcwDev& p, const uint8_t*
 #endif
 constexpr int kDrawRays = 2;                // rays a lane holds from the early table loads (more rays a lane take a loop)
 constexpr uint32_t kNoLine = 0xFFFFFFFFu;   // the ray's line is not in the list: off-image end points (walked at once, clipped), or no such ray
-// words of the draw kernel's LDS: the one-kernel form's buffer | the rays' end pixels [N] | what is left of each ray's line [N] | the lines to walk,
+// words of the draw kernel's LDS: header, tile bytes, line plane | the rays' end pixels [N] | what is left of each ray's line [N] | the lines to walk,
 // sorted: end pixel [N], first pixel [N] | lines per length class [32] | where a class starts in the sorted list [32]
-__host__ __device__ __forceinline__ size_t top_draw_lds_words(const RcwDev& p) { return top_buf_words(p) + 4 * (size_t)((p.N + 3) & ~3) + 64; }
+// (no circle plane here — the store kernels make the circle themselves — and no dummy words: lanes without a line aim at the class
+// counters, which are dead by then.  At 768 x 768 px this is what lets TWO draw workgroups share a CU's 160 KiB: 79.8 KiB each.)
+__host__ __device__ __forceinline__ size_t top_draw_lds_words(const RcwDev& p)
+{
+#ifdef RCW_DEV_SWITCHES
+    if (p.top_draw_r4) return top_buf_words(p) + 4 * (size_t)((p.N + 3) & ~3) + 64;      // (the round-4 body: the one-kernel form's whole buffer in front)
+#endif
+    return 4 + top_tile_words(p) + top_line_words(p) + 4 * (size_t)((p.N + 3) & ~3) + 64;
+}
 
 // Wavefront-wide sums, maxima and prefix sums in the vector unit's data-parallel primitives (DPP: no LDS round trip, as __shfl takes
 // through ds_bpermute): the sequences of AMD's cross-lane guide.  dpp0: the other lane's x, 0 where there is none or the row / bank is masked.
@@ -2365,7 +2373,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
     const int H = p.H, HW = p.H * p.W, N = p.N, pu = p.pu, Ht = H * pu, Wt = p.W * pu;
     const TopBuf b = top_buf(p, lds);
     const int npad4 = (N + 3) & ~3;
-    uint32_t* const ends = lds + top_buf_words(p);                           // [N] the rays' end pixels (i2 | j2 << 16), kNoLine: none
+    uint32_t* const ends = b.line + top_line_words(p);                       // [N] the rays' end pixels (i2 | j2 << 16), kNoLine: none
     uint32_t* const meta = ends + npad4;                                     // [N] per ray: pixels left out | length class << 15 | rank in the class << 20
     uint32_t* const sorted_key = meta + npad4;                               // [M] the lines to walk, longest first: end pixel
     uint32_t* const sorted_first = sorted_key + npad4;                       // [M] ... and the first pixel to walk
@@ -2510,7 +2518,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         { const int wpp = rpp >> 6, wv = tid >> 6; for (int t = wpp; t <= wv; t += wpp) ++part; }
         const int pin = tid - part * rpp;
         const uint32_t plane_bits = lds_address(b.line) * 8u;
-        const uint32_t dummy_A = lds_address(b.dummy + lane) * 8u;
+        const uint32_t dummy_A = lds_address(bcount + lane) * 8u;              // (the 64 words of the class counters and starts: used up by now)
         const uint32_t frac0 = 0x80000000u + (1u << 14);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int q0 = 0; q0 < M; q0 += rpp) {
