@@ -116,13 +116,13 @@ constexpr int kProfileSlots = 256;
 // the draw kernel runs on the side stream: fork after what is already queued (the cast kernel), join before the store.
 // The stand-alone call (`beside` = false) has no camera fill to run beside and takes the one-kernel form.
 template <typename Between>
-hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between, hipEvent_t fused_event = nullptr)
+hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between, hipEvent_t fused_event = nullptr)   // between(stream): the caller's camera fill
 {
     const RcwDev& d = h->dev;
     hipError_t e;
     if (!d.top_split || (!beside && !d.top_alone_split)) {   // (nothing to hide the draw kernel behind: the one-kernel form is the faster one)
         if ((e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;
-        return between();
+        return between(h->stream);
     }
 #ifdef RCW_DEV_SWITCHES
     // Development experiment (RCW_TOP_FOLLOW = 1 inside a step | 2 alone; measured slower, docs/experiments.md): the store kernel FOLLOWS
@@ -143,7 +143,7 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
         e = rcw_launch_top_draw(dd, nullptr, 0, d.B, h->top_stream, beside ? 0 : d.top_draw_block_alone);
         const hipError_t rec = hipEventRecord(h->ev_top_join[0], h->top_stream);
-        if (e == hipSuccess) e = between();
+        if (e == hipSuccess) e = between(h->stream);
         if (e == hipSuccess) e = rcw_launch_top_store(dd, nullptr, 0, d.B, h->stream);
         if (rec == hipSuccess) { const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[0], 0); if (e == hipSuccess) e = w; }
         return e == hipSuccess ? rec : e;
@@ -152,7 +152,7 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
     if (!beside) {                                           // stand-alone, two kernels back to back on the handle's stream
         if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream, d.top_draw_block_alone)) != hipSuccess) return e;
         if ((e = rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream)) != hipSuccess) return e;
-        return between();
+        return between(h->stream);
     }
     if (d.top_fused) {
         // the camera fill and the drawing in ONE launch (rcw_fill256_draw_kernel), then the store: three launches on one
@@ -161,6 +161,22 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         if ((e = rcw_launch_fill256_draw(d, mask_dev, h->stream)) != hipSuccess) return e;
         if (fused_event && (e = hipEventRecord(fused_event, h->stream)) != hipSuccess) return e;
         return rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream);
+    }
+    if (d.top_draw_first && d.top_runs <= 1) {
+        // The DRAWING stays on the handle's stream, right behind the cast kernel, and the store kernel right behind the drawing; the camera
+        // fill — which nothing of the top view depends on — goes to the side stream.  Measured with rocprofv3's kernel trace (tools/
+        // step_timeline.sh): a kernel behind an event of the other stream starts ~13 us later than one behind a kernel of its own stream (19
+        // against 6 us after the cast kernel's end), and the store kernel behind the join another 13 us after the drawing's end — with the
+        // drawing on the side stream both lie on the step's critical path wherever the drawing outlasts the fill.  This way the late start
+        // is the fill's, which has the drawing's whole time to spare, and the join at the end waits for a fill that ended long ago.
+        if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
+        e = between(h->top_stream);                              // (its profiling event is recorded on that stream too)
+        const hipError_t rec = hipEventRecord(h->ev_top_join[0], h->top_stream);
+        if (e == hipSuccess) e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream);
+        if (e == hipSuccess) e = rcw_launch_top_store(d, mask_dev, 0, d.B, h->stream);
+        if (rec == hipSuccess) { const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[0], 0); if (e == hipSuccess) e = w; }
+        return e == hipSuccess ? rec : e;
     }
     if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
@@ -180,7 +196,7 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         if (rec == hipSuccess) recorded = r + 1;
         if (e == hipSuccess) e = rec;
     }
-    if (e == hipSuccess) e = between();
+    if (e == hipSuccess) e = between(h->stream);
     for (int r = 0; r < recorded; ++r) {
         const int first = (int)((long long)d.B * r / runs), count = (int)((long long)d.B * (r + 1) / runs) - first;
         const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[r], 0);
@@ -236,11 +252,11 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
 #endif
     if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream)) != hipSuccess) return e;
     if (prof && (e = hipEventRecord(ev[1], h->stream)) != hipSuccess) return e;
-    auto fill = [&]() -> hipError_t {
+    auto fill = [&](hipStream_t fs) -> hipError_t {            // (fs: the handle's stream, or its side stream: launch_top_view)
         hipError_t f;
-        if (prof && !d.top_split && (f = hipEventRecord(ev[2], h->stream)) != hipSuccess) return f;
-        if ((f = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return f;
-        if (prof && d.top_split && (f = hipEventRecord(ev[2], h->stream)) != hipSuccess) return f;
+        if (prof && !d.top_split && (f = hipEventRecord(ev[2], fs)) != hipSuccess) return f;
+        if ((f = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, fs)) != hipSuccess) return f;
+        if (prof && d.top_split && (f = hipEventRecord(ev[2], fs)) != hipSuccess) return f;
         return hipSuccess;
     };
     if (d.top_view) { if ((e = launch_top_view(h, mask_dev, true, fill, prof ? ev[2] : nullptr)) != hipSuccess) return e; }   // SR:337
@@ -385,7 +401,7 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr; d.top_flags = nullptr; h->top_epoch = 0;
     d.top_blk_shift = 0; d.top_epoch = 0; d.top_signal = 0; d.top_follow = 0; d.top_follow_ok = 0;
     d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
-    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256;
+    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256; d.top_draw_first = 0;
     if (!cfg->render_top_view) {
         if (want_form != 0 && !lenient) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
         return RCW_OK;
@@ -471,6 +487,19 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) {
         d.top_split = 0; d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; d.top_alone_split = 0;
     }
+    // The drawing first on the handle's stream and the camera fill on the side stream (launch_top_view) where the fill is the SHORTER of the
+    // two: it then ends before the store kernel starts.  Where it is the longer one it runs into the store kernel — two moving windows on one
+    // HBM — and the step takes up to 60 % longer (measured, us a step, drawing on the side stream -> drawing first; tools/r05_draw_first.sh:
+    // 768^2 px 226 -> 211, 1024^2 250 -> 239, 704^2 251 -> 236, 512^2 px beside a 128-row camera view 231 -> 216 — and 256^2 px beside 128 /
+    // 300 / 512 rows 267 -> 376, 374 -> 563, 495 -> 801, 256 x 512 px beside 128 rows 265 -> 328).  Both are estimated from the sizes: the
+    // fill at 6.5 TB/s plus its late start, the drawing at its measured floor per GiB of top view (34 us with up to 256 rays, 55 beyond).
+    {
+        const double fill_us = (double)B * N * Hc * 4.0 / 6.5e6 + 12.0;
+        const double top_gib = (double)B * H * W * cfg->pu_per_tu * cfg->pu_per_tu * 4.0 / (double)(1u << 30);
+        const double draw_us = top_gib * (N > 256 ? 55.0 : 34.0);
+        d.top_draw_first = d.top_split && !d.top_fused && d.top_runs <= 1 && fill_us <= draw_us ? 1 : 0;
+    }
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_FIRST")) d.top_draw_first = d.top_split && !d.top_fused && std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
     if (d.top_split) {
         hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));
@@ -1090,7 +1119,7 @@ int rcw_update_top_view(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
     if (!h->d_top_view) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
-    RCW_HIP(launch_top_view(h, nullptr, false, []() { return hipSuccess; }));
+    RCW_HIP(launch_top_view(h, nullptr, false, [](hipStream_t) { return hipSuccess; }));
     return RCW_OK;
 }
 

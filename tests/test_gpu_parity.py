@@ -1239,6 +1239,48 @@ def test_captured_step_with_top_view_replays(rcw, oracle, shape):
     env.close()
 
 
+def test_drawing_first_and_camera_fill_on_the_side_stream(rcw, oracle, monkeypatch):
+    """Round 5: where the camera fill is the shorter of the two, a step keeps the top view's DRAWING on the handle's stream (cast -> draw ->
+    store, no event between them) and sends the camera fill to the side stream (rcw_api.hip, launch_top_view).  The rule takes it for big
+    batches only (768^2 x 455 and 1024^2 x 256 in test_full_size_top_view run through it); here it is forced on small ones through the
+    development build (RCW_TOP_DRAW_FIRST=1): plain steps, a masked reset, a change of stream, and a step captured into a HIP graph
+    and replayed — both images and the state against the oracle every time."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("RCW_TOP_DRAW_FIRST", "1")
+    rng = np.random.default_rng(21)
+    for kw, batch in ((dict(pu_per_tu=32, height_camera_view_pu=128, **CFG2), 48), (dict(pu_per_tu=13, height_camera_view_pu=100, **CFG2), 37),
+                      (dict(pu_per_tu=32, height_tile_map_tu=24, width_tile_map_tu=24, num_rays=128), 5)):
+        env, orc = _make(rcw, oracle, batch, seed=17, render_top_view=1, out_of_bounds=1, library="dev", **kw)
+        env.set_top_view_form("two-kernels")
+        assert env.top_view_form() == "two-kernels"
+        for s in range(4):
+            a = rng.integers(1, 5, batch).astype(np.uint8)
+            rcw.act_(env, a); orc.step(a)
+        assert_state_equal(env, orc, where=f"drawing first, {kw}")
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        mask = (rng.random(batch) < 0.5).astype(np.uint8); mask[0] = 1
+        rcw.reset_(env, mask=mask, seed=99); orc.reset(mask=mask, seed=99)
+        a = rng.integers(1, 5, batch).astype(np.uint8)
+        rcw.act_(env, a); orc.step(a)
+        assert_state_equal(env, orc, where=f"drawing first, after a masked reset, {kw}")
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        stream = torch.cuda.Stream()
+        env.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            actions = torch.from_numpy(a).cuda()
+            rcw.act_(env, actions); orc.step(a)
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                rcw.act_(env, actions)
+            for _ in range(5):
+                g.replay(); orc.step(a)
+            stream.synchronize()
+        assert_state_equal(env, orc, where=f"drawing first, after 5 graph replays, {kw}")
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        env.close()
+
+
 def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
     """The ballot-bounded march (the form north_star words; development switch RCW_CAST_MARCH=ballot of the development
     build librcw_hip_dev.so, measured against the shipped exec-masked march in profiles/) is the same function: bit-exact

@@ -11,10 +11,15 @@ launch (65,536 agents at most; round 3 capped the batch at 16,384, i.e. 0.4-0.7 
   (a) rocprofv3 --kernel-trace --stats per shape (tools/kprof.sh): the kernels' own average / minimum / median durations over 240 steps (a run's first ten to twenty
       launches are 5-15 % slower than the rest — clocks —: the median says what a launch takes once they are up),
       and the store kernel's bandwidth on the algorithmic bytes 4*(H*pu)*(W*pu)*B against the 8 TB/s HBM peak;
-  (b) HIP events on the handle's stream: the top view's time INSIDE a step (the store kernel incl. the wait for the draw
-      kernel's event — what the draw kernel does not hide behind the camera fill shows up here), the camera fill of the same
-      step, and rcw_update_top_view alone with the form it takes (round 5: draw -> store back to back from 256 x 256 px, at pixel scales that
-      are no multiple of 4 and below 16 px a tile; else the one-kernel form), also in us per GiB of top view.
+  (b) HIP events of the step (start | behind the cast kernel | behind the camera fill | end): "in a step" = from the camera fill's end to the
+      step's end (the store kernel incl. any wait for the draw kernel — what the draw kernel does not hide behind the camera fill shows
+      up here), the camera fill beside it (from the cast kernel's end to the fill's end), and rcw_update_top_view alone with the form it takes
+      (round 5: draw -> store back to back from 256 x 256 px, at pixel scales that are no multiple of 4 and below 16 px a tile; else the
+      one-kernel form), also in us per GiB of top view.  Round 5 also sends the camera fill to the side stream where it is the shorter of
+      the two (768^2, 1024^2 px below): the drawing then hides the FILL, "in a step" shrinks to the store kernel and the fill's column
+      grows — so the line ends with the measure that does not depend on who hides whom: the whole step (start -> end) with the top view,
+      the whole step of the same geometry WITHOUT one (cast + fill), and their difference = what the top view ADDS to a step, as a
+      share of the HBM peak on the top view's bytes.
 Kernels: rcw_top_store_kernel (whole 256-row chunks: pu in {{8..256}} dividing 256, H*pu % 256 == 0), rcw_top_store_flat_kernel
 <STRADDLE, NARROW, K> (any pu >= 9, H*pu % 4 == 0 — 256-pixel chunks of the flat batch, K columns a chunk), rcw_top_draw_kernel.
 
@@ -34,7 +39,7 @@ for line in open(f"gpurun_out/{tag}_top_shapes_kernels.txt"):
         row += (f"    {by / avg / 1e6:4.2f} TB/s = {by / avg / 1e6 / 8 * 100:4.1f} %" + (f" (median launch {by / p50 / 1e6 / 8 * 100:4.1f} %," if p50 else " (")
                 + f" best launch {by / mn / 1e6 / 8 * 100:4.1f} %)")
     out.append(row)
-out.append("\n== (b) inside a step, HIP events (store kernel + any wait for the draw kernel; 240 steps)")
+out.append("\n== (b) inside a step, HIP events (240 steps)")
 out += [l.rstrip("\n") for l in open(f"gpurun_out/{tag}_top_shapes_steps.txt")]
 open(f"profiles/{tag}_top_view_shapes.txt", "w").write("\n".join(out) + "\n")
 print(f"profiles/{tag}_top_view_shapes.txt: {len(out)} lines")

@@ -19,6 +19,8 @@ for H, W, pu, N in SHAPES:
     if os.environ.get("TOPSHAPES_BATCH"):                 # development: another batch than ~1 GiB of top view
         B = int(os.environ["TOPSHAPES_BATCH"])
     extra = {}
+    if os.environ.get("TOPSHAPES_HCAM"):                  # development: another camera height (no fused fill + draw launch then: the side stream)
+        extra["height_camera_view_pu"] = int(os.environ["TOPSHAPES_HCAM"])
     if os.environ.get("TOPSHAPES_RADIUS"):                # development: another player radius (the circle drawn into the top view, SR:480)
         extra["player_radius_wu"] = float(os.environ["TOPSHAPES_RADIUS"])
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H,
@@ -41,7 +43,21 @@ for H, W, pu, N in SHAPES:
         RCW.update_top_view_(env)
     alone = env.timer_stop() / 10
     gib = by / 2 ** 30
-    print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d} {env.top_view_form():11s}: in a step {t * 1e3:7.1f} us "
-          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %), camera fill beside it {f * 1e3:7.1f} us, stand-alone ({env.update_top_view_form()}) {alone * 1e3:7.1f} us "
-          f"= {alone * 1e3 / gib:6.1f} us / GiB", flush=True)
+    form, alone_form = env.top_view_form(), env.update_top_view_form()
     env.sync(); env.close()
+    # ... and the same step WITHOUT a top view (cast + camera fill): what the top view ADDS to a step is the difference of the two
+    # steps' whole times — the measure that does not depend on which kernel runs on which stream, or on what "beside" hides
+    bare = RCW.SingleRoomModule.SingleRoom(batch=B, seed=1, auto_reset=True, out_of_bounds=1, height_tile_map_tu=H, width_tile_map_tu=W, num_rays=N, **extra)
+    bare.set_stream(st.cuda_stream)
+    for _ in range(max(3, STEPS // 4)):
+        RCW.act_(bare, a)
+    bare.profile(True)
+    for _ in range(STEPS):
+        RCW.act_(bare, a)
+    c0, t0, f0, n0 = bare.profile_read(); bare.profile(False)
+    bare.sync(); bare.close()
+    adds = (c + t + f) - (c0 + t0 + f0)
+    print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d} {form:11s}: in a step {t * 1e3:7.1f} us "
+          f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %), camera fill beside it {f * 1e3:7.1f} us, stand-alone ({alone_form}) {alone * 1e3:7.1f} us "
+          f"= {alone * 1e3 / gib:6.1f} us / GiB; a step {1e3 * (c + t + f):7.1f} us, without the top view {1e3 * (c0 + t0 + f0):7.1f}: it adds {adds * 1e3:7.1f} us "
+          f"= {by / adds / 1e6 / 80:4.1f} % of the HBM peak on its bytes", flush=True)
