@@ -90,6 +90,7 @@ struct RcwDev {
     uint32_t* step_hc;       // ... (N, B) the column's padding (SR:436, 0..256) | colour id << 9 | the step's epoch << 11 by image column
     uint32_t step_epoch;     // ... this launch's epoch (the handle counts its fused steps)
     int32_t top_debug;       // development only (RCW_TOP_DEBUG): bit 0 skip drawing, bit 1 skip storing — for timing the halves
+    int32_t top_draw_banks;  // development only (RCW_TOP_DRAW=banks): wavefronts of one kind of line (axis, direction), every lane starting on its own LDS bank
     int32_t top_draw_r4;     // development only (RCW_TOP_DRAW=r4): the round-4 body of the draw kernel, for the comparison
     int32_t fill_pairs;      // development only (RCW_FILL_FLAT_PAIRS=1): rcw_fill_flat_kernel with two wavefronts to a slot of the window
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step

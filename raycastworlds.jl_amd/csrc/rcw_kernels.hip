@@ -2475,7 +2475,13 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         const int n = g.a + 1 - skip;                                        // pixels skip .. a to walk
         uint32_t m = 0x7FFFu;                                                // (nothing of this line is walked)
         if (n > 0) {
-            const int cls = kDrawBuckets - 1 - min(kDrawBuckets - 1, (n - 1) >> len_shift);
+            int cls = kDrawBuckets - 1 - min(kDrawBuckets - 1, (n - 1) >> len_shift);
+#ifdef RCW_DEV_SWITCHES
+            if (p.top_draw_banks) {                                          // (experiment) four kinds of line x eight classes of length: a wavefront's lanes then move through the banks alike
+                const int kind = (g.oct & 1) | ((((g.oct & 1) ? (g.oct >> 1) : (g.oct >> 2)) & 1) << 1);
+                cls = kind * 8 + 7 - min(7, (n - 1) >> (len_shift + 2));
+            }
+#endif
             m = (uint32_t)skip | ((uint32_t)cls << 15) | (lds_add_return(bcount + cls, 1u) << 20);
         }
         meta[i] = m;
@@ -2540,7 +2546,24 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
                 if (len == 0) { A0 = dummy_A; smaj = sboth = 0; slope = 0u; }
             }
             const int ke = ks + len;
-            const int k0 = len > 1 ? ks + (int)((((unsigned)(tid * 37) & 63u) * (unsigned)len) >> 6) : ks;   // neighbouring lanes start 37/64 of a segment apart
+            int k0 = len > 1 ? ks + (int)((((unsigned)(tid * 37) & 63u) * (unsigned)len) >> 6) : ks;   // neighbouring lanes start 37/64 of a segment apart
+#ifdef RCW_DEV_SWITCHES
+            if (p.top_draw_banks && len > 48) {
+                // (experiment) move the start on by up to 31 bank steps so that lane l of a half-wavefront starts on bank l: a step along a
+                // column-major line, or a minor step of a row-major one, moves the word by the plane's (odd) column stride
+                const unsigned long long at0 = (unsigned long long)(unsigned)k0 * slope + frac0;
+                const uint32_t Ab = A0 + (uint32_t)(k0 * smaj + (int)(at0 >> 32) * (sboth - smaj));
+                const int w = cb_ >> 5, inv_w = (w * (2 - w * w)) & 31;    // the stride's inverse modulo 32 (w odd)
+                const int col_step = (abs(smaj) > 1) ? smaj : (sboth - smaj);                  // the one of the two steps that changes the column
+                int turns = ((((lane & 31) - (int)((Ab >> 5) & 31u)) & 31) * inv_w) & 31;      // column steps forward to the wanted bank ...
+                if (col_step < 0) turns = (32 - turns) & 31;                                    // ... or as many backward
+                int kn = k0;
+                if (abs(smaj) > 1) kn = k0 + turns;                                             // column-major line: a column a step
+                else if (slope != 0u) kn = k0 + (int)((float)turns * 4294967296.0f / (float)slope);   // row-major line: a column every 2^32 / slope steps (roughly: any start is a valid start)
+                if (kn >= ke) kn -= 32;
+                if (kn >= ks && kn < ke) k0 = kn;
+            }
+#endif
             const unsigned long long at_ks = (unsigned long long)(unsigned)ks * slope + frac0;     // v_mad_u64_u32
             const unsigned long long at_k0 = (unsigned long long)(unsigned)k0 * slope + frac0;
             const uint32_t frac_s = (uint32_t)at_ks;
