@@ -352,7 +352,9 @@ RCW_API int rcw_timer_stop(rcw_handle* h, float* elapsed_ms);
  * rcw_profile_read returns their mean durations over the recorded steps (top_view_ms = 0 without it).
  * With the two-kernel top view (RCW_TOP_VIEW_TWO_KERNELS below) top_view_ms is its store kernel — the one that
  * writes the image; its drawing runs inside the camera fill's launch (or, at camera heights other than 256 rows, on a
- * side stream beside it): inside fill_ms. */
+ * side stream beside it): inside fill_ms.  Where the camera fill is the shorter of the two (big images) it is the FILL
+ * that goes to the side stream: fill_ms then runs from the cast kernel's end to the fill's end beside the drawing, and
+ * top_view_ms from there to the step's end; cast_ms + top_view_ms + fill_ms is the whole step in every case. */
 RCW_API int rcw_profile(rcw_handle* h, int32_t enable);
 RCW_API int rcw_profile_read(rcw_handle* h, float* cast_ms, float* top_view_ms, float* fill_ms, int32_t* steps);
 
