@@ -56,8 +56,7 @@ def test_plain_c_caller(oracle, tmp_path):
     assert "top_view_form_alone=3" in res.stdout                         # 256 x 256 px: the stand-alone call takes draw -> store too
     ort = oracle.OracleBatch(64, seed=2024, out_of_bounds=1, render_top_view=1, pu_per_tu=32,
                              height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
-    for t in range(steps):
-        assert ort.step(acts[t]) == 0
+    ort.set_state(orc.goal, orc.position, orc.direction)                     # (the image is a function of the state: rendered once, from the rollout's last)
     top = ort.top_view.reshape(-1).astype(np.uint64)
     weights = np.arange(top.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
     with np.errstate(over="ignore"):
