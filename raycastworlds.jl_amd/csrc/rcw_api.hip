@@ -492,10 +492,14 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     // HBM — and the step takes up to 60 % longer (measured, us a step, drawing on the side stream -> drawing first; tools/r05_draw_first.sh:
     // 768^2 px 226 -> 211, 1024^2 250 -> 239, 704^2 251 -> 236, 512^2 px beside a 128-row camera view 231 -> 216 — and 256^2 px beside 128 /
     // 300 / 512 rows 267 -> 376, 374 -> 563, 495 -> 801, 256 x 512 px beside 128 rows 265 -> 328).  Both are estimated from the sizes: the
-    // fill at 6.5 TB/s plus its late start, the drawing at its measured floor per GiB of top view (34 us with up to 256 rays, 55 beyond).
+    // fill at 6.5 TB/s plus its late start, the drawing at its measured floor per GiB of top view (34 us with up to 256 rays, 55 beyond) —
+    // of the batch or, for a small one, of most of one round of workgroups (a partial round takes about as long as a full one: 768^2 px x
+    // 114 / 228 / 341 agents 90 -> 75, 129 -> 115, 169 -> 155 us; 1024^2 x 64 / 128 / 192: 113 -> 99, 147 -> 133, 178 -> 164).
     {
         const double fill_us = (double)B * N * Hc * 4.0 / 6.5e6 + 12.0;
-        const double top_gib = (double)B * H * W * cfg->pu_per_tu * cfg->pu_per_tu * 4.0 / (double)(1u << 30);
+        const double image_gib = (double)H * W * cfg->pu_per_tu * cfg->pu_per_tu * 4.0 / (double)(1u << 30);
+        const double round_gib = (double)h->num_cus * rcw_top_draw_per_cu(d, d.top_draw_block) * image_gib;
+        const double top_gib = std::max((double)B * image_gib, 0.7 * round_gib);
         const double draw_us = top_gib * (N > 256 ? 55.0 : 34.0);
         d.top_draw_first = d.top_split && !d.top_fused && d.top_runs <= 1 && fill_us <= draw_us ? 1 : 0;
     }

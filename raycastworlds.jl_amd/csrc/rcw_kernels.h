@@ -126,6 +126,7 @@ int rcw_fill_flat_cols(const RcwDev& p);   // rcw_fill_flat_kernel: columns a ch
 const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // the kernel rcw_launch_fill takes
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
+int rcw_top_draw_per_cu(const RcwDev& p, int draw_block);   // draw workgroups resident on a CU together
 int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int cus);   // draw + store (+ camera fill) workgroups resident on one CU together
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block = 0);    // agents [first, first + count); block: threads a workgroup, 0 = p.top_draw_block
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
