@@ -401,7 +401,7 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr; d.top_flags = nullptr; h->top_epoch = 0;
     d.top_blk_shift = 0; d.top_epoch = 0; d.top_signal = 0; d.top_follow = 0; d.top_follow_ok = 0;
     d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
-    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256; d.top_draw_first = 0;
+    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256; d.top_draw_first = 0; d.top_parts = 1;
     if (!cfg->render_top_view) {
         if (want_form != 0 && !lenient) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
         return RCW_OK;
@@ -487,6 +487,20 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) {
         d.top_split = 0; d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; d.top_alone_split = 0;
     }
+    // Several draw workgroups an agent (rcw_top_draw_kernel: each walks a part of the fan and ORs its plane into the agent's) where a batch
+    // of big images leaves draw slots empty: as many parts as fill them, at most four, at least 128 rays each.  Only with
+    // rcw_top_store_kernel, which reads every plane word exactly once and leaves the zero the next drawing needs.  Measured (tools/
+    // r05_draw_parts.sh; draw kernel, us, 1 / 2 / 4 parts): 1024^2 px, 1024 rays x 64 agents 53.6 / 38.6 / 30.5, x 128: 58.8 / 40.4 / 59.0,
+    // x 256 (every CU has its agent): 61.4 / 78.7 / 110 — a part's fixed costs (the plane cleared, every ray's end point, the plane
+    // scanned) are most of a workgroup's life, so parts only pay where they fill empty CUs; 768^2 px, 256 rays x 114: 24.7 / 19.4 / 21.2.
+    d.top_parts = 1;
+    if (d.top_split && !d.top_flat && d.top_unit_px == 256 && !d.top_fused && !d.top_draw_r4) {
+        const long long slots = (long long)h->num_cus * rcw_top_draw_per_cu(d, d.top_draw_block);
+        int parts = (int)std::min<long long>(4, slots / (long long)B);
+        while (parts > 1 && N / parts < 128) --parts;
+        d.top_parts = parts < 1 ? 1 : parts;
+        if (const char* v = RCW_DEV_ENV("RCW_TOP_PARTS")) { const int q = std::atoi(v); if (q >= 1 && q <= 4 && N / q >= 16) d.top_parts = q; }
+    }
     // The drawing first on the handle's stream and the camera fill on the side stream (launch_top_view) where the fill is the SHORTER of the
     // two: it then ends before the store kernel starts.  Where it is the longer one it runs into the store kernel — two moving windows on one
     // HBM — and the step takes up to 60 % longer (measured, us a step, drawing on the side stream -> drawing first; tools/r05_draw_first.sh:
@@ -534,7 +548,7 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         d.top_follow_ok = (!d.top_fused && d.top_runs <= 1 && rcw_top_follow_fits(d, d.top_draw_block, true, h->num_cus) ? 1 : 0) |
                           (d.top_alone_split && rcw_top_follow_fits(d, d.top_draw_block_alone, false, h->num_cus) ? 2 : 0);
         { const char* v = RCW_DEV_ENV("RCW_TOP_FOLLOW"); d.top_follow_ok &= v ? std::atoi(v) : 0; }   // (off unless asked for)
-        if (d.top_draw_r4) d.top_follow_ok = 0;
+        if (d.top_draw_r4 || d.top_parts > 1) d.top_follow_ok = 0;
 #endif
     }
     hipError_t e = rcw_prepare_top_view(d, h->device);

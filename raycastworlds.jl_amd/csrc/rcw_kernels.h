@@ -67,6 +67,7 @@ struct RcwDev {
     int32_t top_plane_words; // ... and the words of one agent's region of top_plane in that form
     int32_t top_alone_split; // rcw_update_top_view alone (no camera fill beside it) also takes the two-kernel form, back to back
     int32_t top_runs;        // the batch is drawn and stored in this many runs of agents (store of run r beside the drawing of run r + 1)
+    int32_t top_parts;       // draw workgroups an agent (two-kernel form on the side-stream / stand-alone path with rcw_top_store_kernel): 1, or 2..4 for few big images
     int32_t top_draw_first;  // (host) inside a step the drawing stays on the handle's stream and the camera fill goes to the side stream
     int32_t top_fused;       // a step's camera fill and top-view drawing go in ONE launch (rcw_fill256_draw_kernel) instead of two streams
     int32_t top_draw_block;  // threads of a draw-kernel workgroup: 256; a lane per ray (up to 1024) when the plane leaves room for few workgroups on a CU

@@ -2366,12 +2366,15 @@ __device__ __forceinline__ uint32_t lds_add_return(uint32_t* counter, uint32_t v
 constexpr int kDrawBuckets = 32;            // the lines to walk are sorted by length into this many classes, longest first
 
 template <typename T, bool TIE_LE, bool DIST_PRE>
-__device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __restrict__ mask, int a, uint32_t* lds)
+__device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __restrict__ mask, int a, uint32_t* lds, int part = 0, int parts = 1)
 {
+    // (parts > 1: this workgroup walks the lines of rays [ray_lo, ray_hi) of the agent's fan only — the other parts' workgroups, on
+    // other CUs, the rest — and ORs its plane into the agent's plane in HBM, which the store kernel leaves zeroed: rcw_top_draw_kernel)
     typedef typename Real<T>::vec2 vec2;
     const int tid = threadIdx.x, group = blockDim.x, lane = tid & 63;        // p.top_draw_block threads: 256, or up to 1024 (a lane per ray) for big planes
     const int H = p.H, HW = p.H * p.W, N = p.N, pu = p.pu, Ht = H * pu, Wt = p.W * pu;
     const TopBuf b = top_buf(p, lds);
+    const int ray_lo = (int)((long long)N * part / parts), ray_hi = (int)((long long)N * (part + 1) / parts);
     const int npad4 = (N + 3) & ~3;
     uint32_t* const ends = b.line + top_line_words(p);                       // [N] the rays' end pixels (i2 | j2 << 16), kNoLine: none
     uint32_t* const meta = ends + npad4;                                     // [N] per ray: pixels left out | length class << 15 | rank in the class << 20
@@ -2444,7 +2447,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         // a line whose end points are both on the image stays on it; anything else is walked here and now, clipped
         const bool inside = start_inside && i2 >= 1 && i2 <= Ht && j2 >= 1 && j2 <= Wt;
         ends[i] = inside ? (uint32_t)i2 | ((uint32_t)j2 << 16) : kNoLine;
-        if (!inside) top_clipped_line(b.line, cb_, Ht, Wt, ip, jp, i2, j2);
+        if (!inside && i >= ray_lo && i < ray_hi) top_clipped_line(b.line, cb_, Ht, Wt, ip, jp, i2, j2);
     };
 #pragma unroll
     for (int k = 0; k < kDrawRays; ++k) {
@@ -2466,6 +2469,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
     for (int i = tid; i < N; i += group) {
         const uint32_t key = ends[i];
         if (key == kNoLine) continue;
+        if (i < ray_lo || i >= ray_hi) { meta[i] = 0x7FFFu; continue; }      // another part's line
         const LineGeom g = line_geom(key, ip, jp);
         int skip = 0;
         if (i > 0) {
@@ -2590,7 +2594,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
     RCW_DRAW_STAMP(3);
     __syncthreads();
     RCW_DRAW_STAMP(4);
-    if (tid == 0) RCW_PLANE_STORE(reinterpret_cast<uint2*>(p.top_hdr + a), make_uint2((uint32_t)ip, (uint32_t)jp));
+    if (tid == 0 && part == 0) RCW_PLANE_STORE(reinterpret_cast<uint2*>(p.top_hdr + a), make_uint2((uint32_t)ip, (uint32_t)jp));
     if (p.top_flat) {
         // rcw_top_store_flat_kernel's plane: the bit of agent pixel q = (j-1)·Ht + (i-1) sits at bit s + q of the agent's
         // region of p.top_plane_words words, s = (a · Ht·Wt) mod 256 — where the agent's image starts inside its first
@@ -2640,6 +2644,18 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
     uint32_t* const out = p.top_plane + (size_t)a * Wt * wpu;
     const int total = Wt * wpu, qstep = group / wpu, rstep = group - qstep * wpu;
     int j = tid / wpu, w = tid - j * wpu;
+    if (parts > 1) {
+        // several workgroups an agent: every one ORs the words it has bits in into the agent's plane (relaxed atomics without a
+        // return value; the store kernel has left the plane zero: top_group_issue)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int idx = tid; idx < total; idx += group) {
+            const uint32_t word = b.line[j * wpc + w];
+            if (word != 0u) (void)__hip_atomic_fetch_or(out + idx, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            j += qstep; w += rstep;
+            if (w >= wpu) { w -= wpu; j += 1; }
+        }
+        if (part != 0) return;                                               // (the tile codes: the first part's)
+    } else
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int idx = tid; idx < total; idx += group) {
         RCW_PLANE_STORE(out + idx, b.line[j * wpc + w]);
@@ -2672,7 +2688,12 @@ __global__ __launch_bounds__(1024) void rcw_top_draw_kernel(const RcwDev p, cons
 #ifdef RCW_DEV_SWITCHES
     if (p.top_draw_r4) { top_draw_body_r4<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x, lds); return; }
 #endif
-    top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x, lds);
+    // p.top_parts workgroups an agent (1, or 2 .. 4 where a batch of big images leaves CUs without a workgroup, or one agent has a CU to
+    // itself and the slowest agent is the kernel): workgroup q draws part q mod parts of agent q / parts — neighbours in the dispatch
+    // order, i.e. on different XCDs
+    const int parts = p.top_parts > 1 ? p.top_parts : 1;
+    if (parts == 1) { top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x, lds); return; }
+    top_draw_body<T, TIE_LE, DIST_PRE>(p, mask, first + (int)blockIdx.x / parts, lds, (int)blockIdx.x % parts, parts);
 }
 
 // The camera fill and the top view's drawing in ONE launch (a step that renders both images, H_cam = 256, planes that fit a
@@ -2846,6 +2867,15 @@ __device__ __forceinline__ void top_group_issue(const RcwDev& p, const uint8_t* 
     for (int m = 0; m < 8; ++m) {
         const int wo = __shfl(g.woff, 8 * m + (lane >> 3), 64);
         g.pw[m] = wo >= 0 ? p.top_plane[(size_t)wo + (lane & 7)] : 0u;
+    }
+    if (p.top_parts > 1) {
+        // several draw workgroups an agent OR their bits into this plane: it has to be zero when they start, and every word of it is read
+        // exactly once, here — the reader leaves a zero behind (only words that hold a bit: most of a plane is zero already)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int wo = __shfl(g.woff, 8 * m + (lane >> 3), 64);
+            if (wo >= 0 && g.pw[m] != 0u) p.top_plane[(size_t)wo + (lane & 7)] = 0u;
+        }
     }
 }
 // second half: everything that uses a loaded value.  The loads are waited for HERE, once per 64 chunks: left to the
@@ -3696,7 +3726,7 @@ size_t rcw_top_codes_bytes(const RcwDev& p)
 // whole number of 1 KiB chunks in every geometry rcw_top_split_unit takes)
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block)
 {
-    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count), dim3(block > 0 ? block : p.top_draw_block), 4 * top_draw_lds_words(p), p, mask_dev, first);
+    RCW_DISPATCH(rcw_top_draw_kernel, dim3(count * (p.top_parts > 1 ? p.top_parts : 1)), dim3(block > 0 ? block : p.top_draw_block), 4 * top_draw_lds_words(p), p, mask_dev, first);
     return hipGetLastError();
 }
 // the camera fill of the whole batch + the drawing of every agent in one launch (rcw_fill256_draw_kernel): whether this handle's

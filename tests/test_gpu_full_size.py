@@ -234,10 +234,12 @@ def test_batches_beyond_2_32_pixels(rcw, oracle, hc, cfg, batch):
                                                (CFG2, 24576, "two-kernels", 13), (CFG2, 3000, "two-kernels", 20),
                                                (dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 1999, "two-kernels", 12),
                                                (dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 455, "two-kernels", 32), (CFG5, 256, "two-kernels", 32),
+                                               (CFG5, 64, "two-kernels", 32), (dict(height_tile_map_tu=24, width_tile_map_tu=24, num_rays=256), 130, "two-kernels", 32),
                                                (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64), 70000, "two-kernels", 32),
                                                (dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=32), 420000, "two-kernels", 13)],
                          ids=["cfg2_4096", "reference_default_2048", "cfg4_1024", "cfg4_4100_in_runs",
                               "cfg2_24576_of_104x104", "cfg2_3000_of_320x320", "room24_1999_of_288x288", "room24_455_of_768x768", "cfg5_256_of_1024x1024",
+                              "cfg5_64_in_four_parts", "room24_130_in_two_parts",
                               "beyond_2_32_pixels_of_256x256", "beyond_2_32_pixels_of_104x104"])
 def test_full_size_top_view(rcw, oracle, cfg, batch, form, pu):
     """The opt-in top view at full batch sizes (1 GiB of pixels a step: the two-kernel form's store kernel sweeps its

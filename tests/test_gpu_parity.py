@@ -1281,6 +1281,41 @@ def test_drawing_first_and_camera_fill_on_the_side_stream(rcw, oracle, monkeypat
         env.close()
 
 
+@pytest.mark.parametrize("parts", [2, 3, 4])
+def test_several_draw_workgroups_an_agent(rcw, oracle, monkeypatch, parts):
+    """Round 5: where a batch of big images leaves CUs without a draw workgroup, an agent's fan is split over 2 .. 4 workgroups that OR
+    their planes into the agent's plane in HBM, and rcw_top_store_kernel leaves the plane zeroed behind it (rcw_top_draw_kernel,
+    top_group_issue).  The rule takes it for few big images only (test_full_size_top_view: 1024^2 x 64 in four parts, 768^2 x 130 in
+    two); here it is forced through the development build (RCW_TOP_PARTS) on small batches: steps, the stand-alone call, a masked
+    reset (only the masked agents' planes are drawn and consumed), a change of form and back — every pixel against the oracle."""
+    monkeypatch.setenv("RCW_TOP_PARTS", str(parts))
+    rng = np.random.default_rng(30 + parts)
+    for kw, batch in ((dict(pu_per_tu=32, height_camera_view_pu=128, **CFG2), 21), (dict(pu_per_tu=32, height_tile_map_tu=24, width_tile_map_tu=24, num_rays=128), 5),
+                      (dict(pu_per_tu=32, height_camera_view_pu=300, num_rays=67, height_tile_map_tu=8, width_tile_map_tu=16), 9)):
+        env, orc = _make(rcw, oracle, batch, seed=23, render_top_view=1, out_of_bounds=1, library="dev", **kw)
+        env.set_top_view_form("two-kernels")
+        for s in range(3):
+            a = rng.integers(1, 5, batch).astype(np.uint8)
+            rcw.act_(env, a); orc.step(a)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        env.sync(); env.top_view.torch().zero_()
+        import torch
+        torch.cuda.synchronize()
+        rcw.update_top_view_(env)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        mask = (rng.random(batch) < 0.5).astype(np.uint8); mask[-1] = 1
+        rcw.reset_(env, mask=mask, seed=5); orc.reset(mask=mask, seed=5)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        a = rng.integers(1, 5, batch).astype(np.uint8)
+        rcw.act_(env, a); orc.step(a)
+        assert_state_equal(env, orc, where=f"{parts} draw workgroups an agent, {kw}")
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        env.set_top_view_form("one-kernel"); rcw.act_(env, a); orc.step(a)
+        env.set_top_view_form("two-kernels"); rcw.act_(env, a); orc.step(a)
+        np.testing.assert_array_equal(env.top_view_host(), orc.top_view)
+        env.close()
+
+
 def test_ballot_bounded_march_gives_the_same_rays(rcw, oracle, monkeypatch):
     """The ballot-bounded march (the form north_star words; development switch RCW_CAST_MARCH=ballot of the development
     build librcw_hip_dev.so, measured against the shipped exec-masked march in profiles/) is the same function: bit-exact
