@@ -908,7 +908,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (const char* v = RCW_DEV_ENV("RCW_FILL_FLAT_PAIRS")) d.fill_pairs = std::atoi(v);   // 1: two wavefronts a slot; 2: timing only, a prefetch without loads
     d.top_draw_r4 = 0;
     d.top_draw_banks = 0;
-    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW")) { d.top_draw_r4 = std::strcmp(v, "r4") == 0 ? 1 : 0; d.top_draw_banks = std::strcmp(v, "banks") == 0 ? 1 : 0; }
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW")) { d.top_draw_r4 = std::strcmp(v, "r4") == 0 ? 1 : 0; d.top_draw_banks = std::strcmp(v, "banks") == 0 ? 1 : (std::strcmp(v, "halfds") == 0 ? 2 : (std::strcmp(v, "nods") == 0 ? 3 : 0)); }
     d.top_rotate = 33;                                                       // (measured: rcw_kernels.hip, rcw_top_store_flat_kernel)
     if (const char* v = RCW_DEV_ENV("RCW_TOP_ROTATE")) { const int r = std::atoi(v); if (r >= 0 && r < 65536) d.top_rotate = r; }
     d.fill_trips = -1;

@@ -2355,6 +2355,24 @@ __device__ __forceinline__ uint32_t lds_address(const void* q) { return (uint32_
                  : "+v"(A), "+v"(f), "+v"(rem), "=&v"(t), "=&v"(m), "=&v"(dd)                                                \
                  : "v"(slope), "v"(smaj), "v"(sboth), "v"(rem0), "v"(f0), "v"(A_0) : "vcc", "memory")
 
+#ifdef RCW_DEV_SWITCHES   // (timing probe RCW_TOP_DRAW=halfds: the same step without its LDS atomic — wrong pixels, see profiles/r05_draw_kernel.txt)
+#define RCW_DRAW_STEP_NO_LDS(A, f, rem, slope, smaj, sboth, t, m, dd, rem0, f0, A_0)                                               \
+    asm volatile("v_add_co_u32_e32 %1, vcc, %1, %6\n\t"                                                                     \
+                 "v_lshrrev_b32_e32 %3, 3, %0\n\t"                                                                           \
+                 "v_lshlrev_b32_e64 %4, %0, 1\n\t"                                                                           \
+                 "v_cndmask_b32_e32 %5, %7, %8, vcc\n\t"                                                                     \
+                 "v_and_b32_e32 %3, 0x1ffffffc, %3\n\t"                                                                      \
+                 "v_subrev_co_u32_e32 %2, vcc, 1, %2\n\t"                                                                    \
+                 "v_add_u32_e32 %0, %0, %5\n\t"                                                                              \
+                 "s_cbranch_vccz 1f\n\t"                                                                                     \
+                 "v_cndmask_b32_e32 %2, %2, %9, vcc\n\t"                                                                     \
+                 "v_cndmask_b32_e32 %1, %1, %10, vcc\n\t"                                                                    \
+                 "v_cndmask_b32_e32 %0, %0, %11, vcc\n"                                                                      \
+                 "1:"                                                                                                        \
+                 : "+v"(A), "+v"(f), "+v"(rem), "=&v"(t), "=&v"(m), "=&v"(dd)                                                \
+                 : "v"(slope), "v"(smaj), "v"(sboth), "v"(rem0), "v"(f0), "v"(A_0) : "vcc", "memory")
+#endif
+
 // LDS atomic add that returns the old value, by name: through __hip_atomic_fetch_add the compiler wraps every such add in a
 // wavefront-wide reduction loop (its atomic optimizer), two dozen instructions where one is meant
 __device__ __forceinline__ uint32_t lds_add_return(uint32_t* counter, uint32_t v)
@@ -2481,7 +2499,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         if (n > 0) {
             int cls = kDrawBuckets - 1 - min(kDrawBuckets - 1, (n - 1) >> len_shift);
 #ifdef RCW_DEV_SWITCHES
-            if (p.top_draw_banks) {                                          // (experiment) four kinds of line x eight classes of length: a wavefront's lanes then move through the banks alike
+            if (p.top_draw_banks == 1) {                                     // (experiment) four kinds of line x eight classes of length: a wavefront's lanes then move through the banks alike
                 const int kind = (g.oct & 1) | ((((g.oct & 1) ? (g.oct >> 1) : (g.oct >> 2)) & 1) << 1);
                 cls = kind * 8 + 7 - min(7, (n - 1) >> (len_shift + 2));
             }
@@ -2552,7 +2570,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
             const int ke = ks + len;
             int k0 = len > 1 ? ks + (int)((((unsigned)(tid * 37) & 63u) * (unsigned)len) >> 6) : ks;   // neighbouring lanes start 37/64 of a segment apart
 #ifdef RCW_DEV_SWITCHES
-            if (p.top_draw_banks && len > 48) {
+            if (p.top_draw_banks == 1 && len > 48) {
                 // (experiment) move the start on by up to 31 bank steps so that lane l of a half-wavefront starts on bank l: a step along a
                 // column-major line, or a minor step of a row-major one, moves the word by the plane's (odd) column stride
                 const unsigned long long at0 = (unsigned long long)(unsigned)k0 * slope + frac0;
@@ -2582,6 +2600,25 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
 #endif
             uint32_t t_, m_, d_;
             // four steps a trip (up to three more than the longest segment needs: lanes go round their own segments, harmless)
+#ifdef RCW_DEV_SWITCHES
+            if (p.top_draw_banks == 2) {                                     // (timing probe: every other step without its LDS atomic)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int trips = (nmax + 3) >> 2; trips > 0; --trips) {
+                    RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                    RCW_DRAW_STEP_NO_LDS(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                    RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                    RCW_DRAW_STEP_NO_LDS(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                }
+            } else if (p.top_draw_banks == 3) {                              // (timing probe: no step with an LDS atomic)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int trips = (nmax + 3) >> 2; trips > 0; --trips) {
+                    RCW_DRAW_STEP_NO_LDS(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                    RCW_DRAW_STEP_NO_LDS(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                    RCW_DRAW_STEP_NO_LDS(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                    RCW_DRAW_STEP_NO_LDS(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
+                }
+            } else
+#endif
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int trips = (nmax + 3) >> 2; trips > 0; --trips) {
                 RCW_DRAW_STEP(A, frac, rem, slope, smaj, sboth, t_, m_, d_, len_m1, frac_s, A_s);
