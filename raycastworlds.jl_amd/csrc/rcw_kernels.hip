@@ -2692,6 +2692,18 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
             if (w >= wpu) { w -= wpu; j += 1; }
         }
         if (part != 0) return;                                               // (the tile codes: the first part's)
+    } else if ((wpu & 3) == 0 && !p.top_signal) {
+        // four words of a column a thread, one 16-byte store (a column is a multiple of 8 words here; in LDS its stride is odd: four 4-byte reads)
+        const int qpc = wpu >> 2, quads = Wt * qpc, qs = group / qpc, rs = group - qs * qpc;
+        int jq = tid / qpc, wq = tid - jq * qpc;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int q = tid; q < quads; q += group) {
+            const uint32_t* const src = b.line + jq * wpc + 4 * wq;
+            const u32x4 v = {src[0], src[1], src[2], src[3]};
+            *reinterpret_cast<u32x4*>(out + jq * wpu + 4 * wq) = v;
+            jq += qs; wq += rs;
+            if (wq >= qpc) { wq -= qpc; jq += 1; }
+        }
     } else
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int idx = tid; idx < total; idx += group) {
