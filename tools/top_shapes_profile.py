@@ -19,7 +19,9 @@ launch (65,536 agents at most; round 3 capped the batch at 16,384, i.e. 0.4-0.7 
       the two (768^2, 1024^2 px below): the drawing then hides the FILL, "in a step" shrinks to the store kernel and the fill's column
       grows — so the line ends with the measure that does not depend on who hides whom: the whole step (start -> end) with the top view,
       the whole step of the same geometry WITHOUT one (cast + fill), and their difference = what the top view ADDS to a step, as a
-      share of the HBM peak on the top view's bytes.
+      share of the HBM peak on the top view's bytes.  (Where the camera fill is 0.6-1.6 ms — the four shapes of 80^2 ... 128^2 px images —
+      that difference of two whole steps moves by +-25 us from run to run, 1.5 % of a step: two collections of this table gave 175 and 214 us
+      at 80^2 px, 172 / 193 at 96^2, 173 / 190 at 104^2, 177 / 184 at 128^2; "in a step" is the steadier number there: 176-181 us.)
 Kernels: rcw_top_store_kernel (whole 256-row chunks: pu in {{8..256}} dividing 256, H*pu % 256 == 0), rcw_top_store_flat_kernel
 <STRADDLE, NARROW, K> (any pu >= 9, H*pu % 4 == 0 — 256-pixel chunks of the flat batch, K columns a chunk), rcw_top_draw_kernel.
 
