@@ -43,5 +43,10 @@ for line in open(f"gpurun_out/{tag}_top_shapes_kernels.txt"):
     out.append(row)
 out.append("\n== (b) inside a step, HIP events (240 steps)")
 out += [l.rstrip("\n") for l in open(f"gpurun_out/{tag}_top_shapes_steps.txt")]
+import os
+if os.path.exists(f"gpurun_out/{tag}_top_shapes_plain.txt"):
+    out.append("\n== (c) the same tool run WITHOUT rocprofv3 (its tracing moves cross-stream timings by a few us; 240 steps): the line's last part is the whole-step\n"
+               "difference WITHOUT the per-kernel events as well — two events around all the steps, with and without the top view: the cleanest figure of what the top view adds")
+    out += [l.rstrip("\n") for l in open(f"gpurun_out/{tag}_top_shapes_plain.txt")]
 open(f"profiles/{tag}_top_view_shapes.txt", "w").write("\n".join(out) + "\n")
 print(f"profiles/{tag}_top_view_shapes.txt: {len(out)} lines")

@@ -36,6 +36,10 @@ for H, W, pu, N in SHAPES:
     for _ in range(STEPS):
         RCW.act_(env, a)
     c, t, f, n = env.profile_read(); env.profile(False)
+    env.sync(); env.timer_start()                         # ... and the same steps without the per-kernel events: two events around all of them
+    for _ in range(STEPS):
+        RCW.act_(env, a)
+    plain = env.timer_stop() / STEPS
     by = 4 * px * B
     # the stand-alone call (two-kernel form: draw, then store, back to back on one stream)
     env.sync(); env.timer_start()
@@ -55,9 +59,14 @@ for H, W, pu, N in SHAPES:
     for _ in range(STEPS):
         RCW.act_(bare, a)
     c0, t0, f0, n0 = bare.profile_read(); bare.profile(False)
+    bare.sync(); bare.timer_start()
+    for _ in range(STEPS):
+        RCW.act_(bare, a)
+    plain0 = bare.timer_stop() / STEPS
     bare.sync(); bare.close()
     adds = (c + t + f) - (c0 + t0 + f0)
     print(f"map {H:2d}x{W:2d} pu {pu:2d} N {N:4d} image {H * pu:4d}x{W * pu:4d} B {B:5d} {form:11s}: in a step {t * 1e3:7.1f} us "
           f"{by / t / 1e6:6.0f} GB/s ({by / t / 1e6 / 80:4.1f} %), camera fill beside it {f * 1e3:7.1f} us, stand-alone ({alone_form}) {alone * 1e3:7.1f} us "
           f"= {alone * 1e3 / gib:6.1f} us / GiB; a step {1e3 * (c + t + f):7.1f} us, without the top view {1e3 * (c0 + t0 + f0):7.1f}: it adds {adds * 1e3:7.1f} us "
-          f"= {by / adds / 1e6 / 80:4.1f} % of the HBM peak on its bytes", flush=True)
+          f"= {by / adds / 1e6 / 80:4.1f} % of the HBM peak on its bytes; without the per-kernel events ({STEPS} steps between two events): "
+          f"{plain * 1e3:7.1f} - {plain0 * 1e3:7.1f} = {(plain - plain0) * 1e3:7.1f} us = {by / (plain - plain0) / 1e6 / 80:4.1f} %", flush=True)
