@@ -388,10 +388,30 @@ RCW_API int rcw_update_top_view_form(rcw_handle* h, int32_t* form);
  * scratch in HBM.  The library reads no environment variable other than RCW_RCCL_LIBRARY: what used to be development
  * switches (RCW_TOP_SPLIT, RCW_TOP_RUNS, ...) exists only in the development build (make dev -> librcw_hip_dev.so). */
 RCW_API int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs);
+/* How many launches a step — RCW.act!(env, a) SR:333-340 — takes; both forms leave the same state and the same pixels:
+ *   RCW_STEP_TWO_LAUNCHES  the cast kernel (dynamics SR:139-191, cast_rays! SR:195-231, the columns of update_camera_view!
+ *                          SR:401-429 as compact descriptors), then the fill kernel (SR:431-440) — the reference's own order.
+ *   RCW_STEP_ONE_LAUNCH    the frame of the NEXT step depends only on this step's state and the next action, and there are four
+ *                          actions: the casting workgroups of a launch commit the dynamics and also cast the four successor states
+ *                          (a blocked / goal / raising move keeps the current frame; an agent that is done under cfg.auto_reset gets
+ *                          the re-sampled world's, drawn ahead without being committed) into slots in HBM (10 bytes a view column, two
+ *                          buffers), and the fill workgroups of the NEXT launch, in the same launch as that step's casting, write the
+ *                          frames the actions select.  Nothing inside a launch waits for anything else in it; the cast kernel and a
+ *                          launch boundary leave the step's critical path.  rcw_reset / rcw_set_state (and a first step) cast as a
+ *                          launch of their own, which leaves the slots of the agents it touches ready.
+ * The rule: one launch wherever the geometry allows — a 256-row camera view (every BASELINE configuration) without a top view
+ * (cfg.render_top_view = 0), fewer than 2^29 view columns in the batch.  A step captured into a HIP graph (hipStreamBeginCapture on
+ * the handle's stream) takes the two-launch form, and so does every later step of that handle: the one-launch form alternates its
+ * two buffers from launch to launch on the host, which a replayed graph cannot.  rcw_set_step_form: 0 = the rule,
+ * RCW_STEP_ONE_LAUNCH fails with RCW_ERR_UNSUPPORTED where the geometry cannot take it. */
+enum { RCW_STEP_TWO_LAUNCHES = 1, RCW_STEP_ONE_LAUNCH = 2 };
+RCW_API int rcw_step_form(rcw_handle* h, int32_t* form);
+RCW_API int rcw_set_step_form(rcw_handle* h, int32_t form);
 /* The kernel update_camera_view! (SR:374-444) runs in INSIDE A STEP of this handle (what bench.py labels its roofline block
  * with): "rcw_fill256_kernel", "rcw_fill_window_kernel", "rcw_fill_flat_kernel", ... by camera height and batch — and
  * "rcw_fill256_draw_kernel" where the handle also renders the top view and the camera fill and the top view's drawing go in
- * one launch (rcw_update_camera_view alone always takes the plain fill kernel). */
+ * one launch, and "rcw_fill256_cast_kernel" for the one-launch step (rcw_update_camera_view alone always takes the plain fill
+ * kernel). */
 RCW_API int rcw_fill_kernel_name(rcw_handle* h, char* buf, int32_t buflen);
 
 /* Introspection */

@@ -499,6 +499,24 @@ function set_top_view_form!(env::BatchedSingleRoom, form::Symbol = :auto; runs::
     check(ccall((:rcw_set_top_view_form, librcw), Cint, (Ptr{Cvoid}, Int32, Int32), env.handle, code, runs))
     return nothing
 end
+"How many launches a step takes (`rcw_step_form`): `:two_launches` (cast kernel, then fill kernel) or `:one_launch`."
+function step_form(env::BatchedSingleRoom)
+    f = Ref{Int32}(0)
+    check(ccall((:rcw_step_form, librcw), Cint, (Ptr{Cvoid}, Ref{Int32}), env.handle, f))
+    return (:two_launches, :one_launch)[f[]]
+end
+"""
+    set_step_form!(env, form = :auto)
+
+Choose the step's form instead of the library's rule (`rcw_set_step_form`): `:auto`, `:two_launches` or `:one_launch`
+(the fill workgroups of a launch write the frames the actions select among the successor states the previous launch cast).
+Both leave the same state and the same pixels.  Throws where the geometry cannot take the one-launch form.
+"""
+function set_step_form!(env::BatchedSingleRoom, form::Symbol = :auto)
+    code = Dict(:auto => 0, :two_launches => 1, :one_launch => 2)[form]
+    check(ccall((:rcw_set_step_form, librcw), Cint, (Ptr{Cvoid}, Int32), env.handle, code))
+    return nothing
+end
 "The kernel `update_camera_view!` takes for this camera height and batch (`rcw_fill_kernel_name`)."
 function fill_kernel_name(env::BatchedSingleRoom)
     buf = Vector{UInt8}(undef, 64)

@@ -28,6 +28,7 @@ RCW_REWARD_FLOAT32, RCW_REWARD_FLOAT64, RCW_REWARD_INT32, RCW_REWARD_INT64 = 0, 
 RCW_GATHER_COLUMNS, RCW_GATHER_FRAMES = 0, 1
 RCW_UNIQUE_ID_BYTES = 128
 RCW_TOP_VIEW_NONE, RCW_TOP_VIEW_IN_PLACE, RCW_TOP_VIEW_ONE_KERNEL, RCW_TOP_VIEW_TWO_KERNELS = 0, 1, 2, 3
+RCW_STEP_TWO_LAUNCHES, RCW_STEP_ONE_LAUNCH = 1, 2   # rcw_step_form / rcw_set_step_form
 
 
 class RcwConfig(C.Structure):
@@ -136,6 +137,8 @@ SIGNATURES = {
     "rcw_top_view_form": [_vp, C.POINTER(_i32)],
     "rcw_update_top_view_form": [_vp, C.POINTER(_i32)],
     "rcw_set_top_view_form": [_vp, _i32, _i32],
+    "rcw_step_form": [_vp, C.POINTER(_i32)],
+    "rcw_set_step_form": [_vp, _i32],
     "rcw_fill_kernel_name": [_vp, C.c_char_p, _i32],
     "rcw_comm_unique_id": [_vp],
     "rcw_comm_init": [_vp, _vp, _i32, _i32],

@@ -90,6 +90,12 @@ struct rcw_handle {
     bool profiling = false;
     int step_pieces = 1;               // development experiment only (RCW_STEP_PIECES)
     void* d_step_flags = nullptr; void* d_step_hc = nullptr; uint32_t step_epoch = 0;   // development experiment only (RCW_STEP_FUSED)
+    // the one-launch step (rcw_fill256_cast_kernel): two buffers of [5][B][N] packed column words — d_spec[spec_cur] holds the frames of the
+    // CURRENT state (slot 0) and of its four successors (slots 1..4), written by the last casting launch; spec_primed: for every agent
+    void* d_spec[2] = {nullptr, nullptr}; int spec_cur = 0; bool spec_primed = false;
+    int spec_on = 0;                   // a step is ONE launch (rcw_fill256_cast_kernel)
+    int step_form_want = 0;            // rcw_set_step_form: 0 = the rule, or RCW_STEP_TWO_LAUNCHES / RCW_STEP_ONE_LAUNCH
+    bool step_captured = false;        // a step of this handle was captured into a graph: it keeps the two-launch form from then on
     int prof_count = 0;
     std::vector<hipEvent_t> prof_ev;   // 4 per recorded step: start | after cast | after top view | after fill
     void* d_rays[4] = {nullptr, nullptr, nullptr, nullptr};   // rcw_rays scratch (grow-only)
@@ -216,7 +222,35 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
     const bool prof = h->profiling && h->prof_count < kProfileSlots;
     hipEvent_t* ev = prof ? &h->prof_ev[4 * h->prof_count] : nullptr;
     hipError_t e;
+    if (h->spec_on) {
+        // The one-launch step keeps its place in the slot buffers on the HOST (which of the two the next launch reads): a graph would replay
+        // one launch's pointers for ever.  A handle whose step is captured keeps the two-launch form from then on (replays advance the
+        // state behind the library's back, so its slots can never be trusted again): rcw_step_form says so.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { h->spec_on = 0; h->step_captured = true; h->spec_primed = false; }
+    }
     if (prof && (e = hipEventRecord(ev[0], h->stream)) != hipSuccess) return e;
+    if (h->spec_on) {
+        uint16_t* const cur = (uint16_t*)h->d_spec[h->spec_cur];
+        if (actions_dev && !mask_dev && h->spec_primed) {
+            // act!(env, a) SR:333-340 in ONE launch: the fill workgroups write the frames the actions select among the successors the last
+            // casting launch left in `cur`; the casting workgroups commit the actions and cast the new states' successors into the other buffer
+            uint16_t* const next = (uint16_t*)h->d_spec[h->spec_cur ^ 1];
+            if (prof && ((e = hipEventRecord(ev[1], h->stream)) != hipSuccess || (e = hipEventRecord(ev[2], h->stream)) != hipSuccess)) return e;
+            if ((e = rcw_launch_step_spec(d, actions_dev, nullptr, cur, next, true, h->stream)) != hipSuccess) return e;
+            h->spec_cur ^= 1;
+            if (prof) { if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e; h->prof_count++; }
+            return hipSuccess;
+        }
+        // reset! / set_state (no action, maybe a mask) or a first step: the casting workgroups alone — dynamics if any, the current frame's
+        // descriptors, and the (masked) agents' slots in place —, then the camera fill as a launch of its own
+        if ((e = rcw_launch_step_spec(d, actions_dev, mask_dev, nullptr, cur, false, h->stream)) != hipSuccess) return e;
+        if (!mask_dev) h->spec_primed = true;
+        if (prof && ((e = hipEventRecord(ev[1], h->stream)) != hipSuccess || (e = hipEventRecord(ev[2], h->stream)) != hipSuccess)) return e;
+        if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
+        if (prof) { if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e; h->prof_count++; }
+        return hipSuccess;
+    }
 #ifdef RCW_DEV_SWITCHES
     if (h->step_pieces == 2 && !d.top_view && h->top_stream && d.B >= 2) {
         // Development experiment (RCW_STEP_PIECES=2, docs/experiments.md): the batch in two halves, the second half's cast kernel on
@@ -291,7 +325,7 @@ void free_all(rcw_handle* h)
     }
     for (int k = 0; k < 4; ++k) { if (h->d_rays[k]) (void)hipFree(h->d_rays[k]); h->d_rays[k] = nullptr; h->rays_cap[k] = 0; }
     if (h->top_stream) (void)hipStreamSynchronize(h->top_stream);          // (a draw kernel of a failed step may still run)
-    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_top_flags, &h->d_step_flags, &h->d_step_hc}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_top_flags, &h->d_step_flags, &h->d_step_hc, &h->d_spec[0], &h->d_spec[1]}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (h->ev_top_fork) (void)hipEventDestroy(h->ev_top_fork);
     for (hipEvent_t& q : h->ev_top_join) { if (q) (void)hipEventDestroy(q); q = nullptr; }
     if (h->top_stream) (void)hipStreamDestroy(h->top_stream);
@@ -553,6 +587,30 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     }
     hipError_t e = rcw_prepare_top_view(d, h->device);
     if (e != hipSuccess) return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e));
+    return RCW_OK;
+}
+
+// Which form a step takes (rcw_set_step_form; want = 0: the rule — one launch wherever the geometry allows, unless a step of the handle
+// was captured into a graph).  Allocates the two slot buffers the first time the one-launch form is taken; the caller primes them
+// (launch_step without an action).
+int plan_step_form(rcw_handle* h, int want)
+{
+    RcwDev& d = h->dev;
+    const bool eligible = rcw_step_spec_eligible(d) != 0;
+    if (want == RCW_STEP_ONE_LAUNCH && !eligible)
+        return fail(RCW_ERR_UNSUPPORTED, "this handle does not take the one-launch step (a 256-row camera view without a top view, fewer than 2^29 view columns)");
+    const bool on = want == RCW_STEP_TWO_LAUNCHES ? false : (want == RCW_STEP_ONE_LAUNCH ? true : eligible && !h->step_captured);
+    if (on) {
+        for (int k = 0; k < 2; ++k) {
+            if (h->d_spec[k]) continue;
+            const hipError_t e = hipMalloc(&h->d_spec[k], rcw_step_spec_slot_bytes(d));
+            if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "one-launch step, slot buffers: %s", hipGetErrorString(e));
+        }
+        if (want == RCW_STEP_ONE_LAUNCH) h->step_captured = false;
+    }
+    if (on && !h->spec_on) h->spec_primed = false;
+    h->spec_on = on ? 1 : 0;
+    h->step_form_want = want;
     return RCW_OK;
 }
 
@@ -944,6 +1002,13 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     if (rcw_step_lds_bytes(d) > 64 * 1024) {
         free_all(h); delete h;
         return fail(RCW_ERR_UNSUPPORTED, "tile map + column buffer need %zu B of LDS (> 64 KiB)", rcw_step_lds_bytes(d));
+    }
+    {
+        int want = 0;
+        if (const char* v = RCW_DEV_ENV("RCW_STEP_FORM")) { const int f = std::atoi(v); if (f == RCW_STEP_TWO_LAUNCHES) want = f; }
+        if (d.step_fused || h->step_pieces == 2) want = RCW_STEP_TWO_LAUNCHES;          // (development experiments on the two-launch step)
+        rc = plan_step_form(h, want);
+        if (rc != RCW_OK) { free_all(h); delete h; return rc; }
     }
 
     try {
@@ -1558,10 +1623,28 @@ int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs)
     return RCW_OK;
 }
 
+int rcw_step_form(rcw_handle* h, int32_t* form)
+{
+    if (!h || !form) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    *form = h->spec_on ? RCW_STEP_ONE_LAUNCH : RCW_STEP_TWO_LAUNCHES;
+    return RCW_OK;
+}
+
+int rcw_set_step_form(rcw_handle* h, int32_t form)
+{
+    int rc = check_handle(h); if (rc) return rc;
+    if (form != 0 && form != RCW_STEP_TWO_LAUNCHES && form != RCW_STEP_ONE_LAUNCH)
+        return fail(RCW_ERR_INVALID_ARGUMENT, "form must be 0 (automatic) or RCW_STEP_TWO_LAUNCHES / RCW_STEP_ONE_LAUNCH (got %d)", form);
+    const bool was_on = h->spec_on != 0;
+    rc = plan_step_form(h, form); if (rc) return rc;
+    if (h->spec_on && !was_on) RCW_HIP(launch_step(h, nullptr, nullptr));   // prime the slots (re-renders the current frames: the same pixels)
+    return RCW_OK;
+}
+
 int rcw_fill_kernel_name(rcw_handle* h, char* buf, int32_t buflen)
 {
     if (!h || !buf || buflen < 1) return fail(RCW_ERR_INVALID_ARGUMENT, "bad argument");
-    std::snprintf(buf, (size_t)buflen, "%s", rcw_fill_kernel_name(h->dev, (long long)h->dev.B * h->dev.N));
+    std::snprintf(buf, (size_t)buflen, "%s", h->spec_on ? "rcw_fill256_cast_kernel" : rcw_fill_kernel_name(h->dev, (long long)h->dev.B * h->dev.N));
     return RCW_OK;
 }
 

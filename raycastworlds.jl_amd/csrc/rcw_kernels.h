@@ -131,6 +131,11 @@ int rcw_top_draw_per_cu(const RcwDev& p, int draw_block);   // draw workgroups r
 int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int cus);   // draw + store (+ camera fill) workgroups resident on one CU together
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block = 0);    // agents [first, first + count); block: threads a workgroup, 0 = p.top_draw_block
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
+// the one-launch step (round 6): eligibility of a geometry, the bytes of one of its two slot buffers ([5][B][N] packed column words), the launch
+int rcw_step_spec_eligible(const RcwDev& p);
+size_t rcw_step_spec_slot_bytes(const RcwDev& p);
+hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, const uint16_t* slots_in,
+                                uint16_t* slots_out, bool with_fill, hipStream_t s);
 #ifdef RCW_DEV_SWITCHES
 bool rcw_step_fusable(const RcwDev& p);       // development experiment (RCW_STEP_FUSED): cast + camera fill in one launch
 hipError_t rcw_launch_step256(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, uint32_t epoch, hipStream_t s);

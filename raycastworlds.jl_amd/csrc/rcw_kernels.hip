@@ -620,6 +620,90 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
     return r.oob;
 }
 
+// ---- the one-launch step's successors (rcw_fill256_cast_kernel) ----------------------------------------------------------
+// The word the fill reads for a column of a 256-row camera view: its padding (SR:436, 0..256) | colour id << 9.
+__device__ __forceinline__ uint32_t spec_word(int h, int cid) { return (uint32_t)column_padding(256, h) | ((uint32_t)cid << 9); }
+
+// a heading's table entries of this lane's first kCastCols view columns (as cast_body's batch 2)
+template <typename T>
+__device__ __forceinline__ void spec_load_rows(const T* tab, int tid, int nthr, int N, T* r_dx, T* r_dy, T* r_ddx, T* r_ddy, T* r_dot)
+{
+#pragma unroll
+    for (int k = 0; k < kCastCols; ++k) {
+        const int i = tid + k * nthr;
+        const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);
+        r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o);
+        r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+    }
+}
+
+// One state's whole fan (cast_rays! SR:195-231 + the column of update_camera_view! SR:401-429) from pose (x, y) with the table entries
+// of its heading: the packed word of every column into the slots `slots` names (bit s: slot s of [5][B][N]); COLS: also the
+// (height_line_pu, colour id) descriptors of the current frame, as cast_column.  Returns whether a ray left the map.
+template <typename T, bool TIE_LE, bool DIST_PRE, bool COLS>
+__device__ __forceinline__ bool spec_fan(const RcwDev& p, const uint8_t* tb, int tid, int nthr, T x, T y,
+                                         const T* r_dx, const T* r_dy, const T* r_ddx, const T* r_ddy, const T* r_dot, const T* tab,
+                                         int32_t* col_h_a, uint8_t* col_c_a, uint16_t* slot_a, size_t stride, uint32_t slots)
+{
+    const int N = p.N;
+    bool left = false;
+    auto column = [&](int i, T dx, T dy, T ddx, T ddy, T dot) {
+        const RayHit<T> r = cast_ray_guarded<T, TIE_LE, DIST_PRE>(tb, p.H, p.W, x, y, dx, dy, ddx, ddy);
+        const int hl = height_line_pu<T>(p, r.dist, dot);
+        const int h = r.oob ? p.Hc : hl;
+        const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);     // SR:417-429
+        const uint32_t k = (uint32_t)(N - 1 - i);                           // SR:431 (0-based)
+        if (COLS) {
+            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(col_h_a) + k * 4u) = h;
+            *(col_c_a + k) = (uint8_t)cid;
+        }
+        const uint16_t w = (uint16_t)spec_word(h, cid);
+        uint16_t* const q = slot_a + k;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) if (slots & (1u << s)) q[(size_t)s * stride] = w;   // (wave-uniform)
+        left |= r.oob;
+    };
+#pragma unroll
+    for (int k = 0; k < kCastCols; ++k) {
+        const int i = tid + k * nthr;
+        if (i < N) column(i, r_dx[k], r_dy[k], r_ddx[k], r_ddy[k], r_dot[k]);
+    }
+    if (N > kCastCols * nthr) {                                             // more than kCastCols columns a lane
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int i = tid + kCastCols * nthr; i < N; i += nthr) column(i, tab[i], tab[N + i], tab[2 * N + i], tab[3 * N + i], tab[4 * N + i]);
+    }
+    return left;
+}
+
+// reset!(world) SR:110-137 for an agent that is done, WITHOUT committing it: the draws reset_agent will make when the next launch
+// re-samples the agent (the generator is a pure function of seed, global agent id, episode and draw index), on the agent's tile BYTES in
+// LDS — which it leaves as the re-sampled world's: the goal bit moved (SR:118-122).  The caller casts the new pose against them.
+template <typename T>
+__device__ __forceinline__ Pose<T> reset_preview(const RcwDev& p, int a, uint8_t* tb)
+{
+    const int H = p.H, W = p.W;
+    const uint64_t key = rcw_episode_key(p.seed, (uint64_t)(p.agent_id_offset + a), (uint64_t)p.episode[a]);
+    uint64_t n = 0;
+    const int2 old = p.goal[a];
+    tb[(old.x - 1) + H * (old.y - 1)] &= (uint8_t)~2u;                      // SR:118
+    const int gi = 2 + (int)rcw_below(rcw_draw(key, n++), (uint64_t)(H - 2));  // SR:120
+    const int gj = 2 + (int)rcw_below(rcw_draw(key, n++), (uint64_t)(W - 2));
+    tb[(gi - 1) + H * (gj - 1)] |= 2u;                                      // SR:122
+    const uint64_t HW = (uint64_t)H * (uint64_t)W;
+    const uint64_t max_tries = 1024ull * HW;
+    uint64_t lin = rcw_below(rcw_draw(key, n++), HW);                        // UT:24
+    for (uint64_t t = 0; t < max_tries; ++t) {                               // UT:26 (tile (i, j) is byte (i-1) + H (j-1) = lin)
+        if (tb[lin]) lin = rcw_below(rcw_draw(key, n++), HW);                // UT:27-28
+        else break;
+    }
+    const int pi = (int)(lin % (uint64_t)H) + 1, pj = (int)(lin / (uint64_t)H) + 1;
+    Pose<T> o;
+    o.x = (T)((double)pi - 0.5);                                            // SR:125
+    o.y = (T)((double)pj - 0.5);
+    o.d = (int)rcw_below(rcw_draw(key, n++), (uint64_t)p.nd);                // SR:128
+    return o;
+}
+
 // The lanes of ONE agent wait for each other's LDS writes: a workgroup barrier — or, where the agent is a single wavefront
 // (WAVE), nothing but the wavefront's own LDS counter: its LDS operations execute in order.
 template <bool WAVE>
@@ -632,9 +716,10 @@ __device__ __forceinline__ void agent_sync()
 // WAVE = false: the workgroup is one agent (tid = its thread, nthr = blockDim).  WAVE = true (development build only, measured and
 // rejected): 64 lanes are an agent and the workgroup's wavefronts are DIFFERENT agents (rcw_cast_waves_kernel): the same code with
 // tid = the lane, nthr = 64, the wavefront's own slice of LDS, and no workgroup barrier.
-template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE, bool PUBLISH = false>
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE, bool PUBLISH = false, bool SPEC = false>
 __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
-                                          const int a, const int tid, const int nthr, uint32_t* const lds, const int trace_slot)
+                                          const int a, const int tid, const int nthr, uint32_t* const lds, const int trace_slot,
+                                          uint16_t* __restrict__ spec_out = nullptr)
 {
     typedef typename Real<T>::vec2 vec2;
     const int H = p.H, HW = p.H * p.W, N = p.N;
@@ -673,6 +758,8 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
     // ---- batch 2: what depends on the heading ---------------------------------------------------------------
     // (with a re-sampled heading — rare — the row of the OLD heading is fetched for nothing and the right one again below)
     const vec2 dv = Real<T>::dir_table(p)[d];                               // SR:153
+    vec2 dvn = dv;                                                          // (SPEC: the heading AFTER the action — the successors move along it)
+    if (SPEC) dvn = Real<T>::dir_table(p)[d_new];
     T r_dx[kCastCols], r_dy[kCastCols], r_ddx[kCastCols], r_ddy[kCastCols], r_dot[kCastCols];
     {
         const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
@@ -709,7 +796,9 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
 
     // ---- phase 0: dynamics, computed redundantly by every lane (no broadcast needed) --------
     T x = pos.x, y = pos.y;
+    int done_now = was_done;                                                // world.done once this call's dynamics are through (SPEC)
     if (resample) {                                                         // wave-uniform, rare
+        done_now = 0;
         if (tid == 0) {
             const Pose<T> np = reset_agent<T>(p, a, tm_hbm, nullptr);
             s_pose[0] = np.x; s_pose[1] = np.y; s_pose_d = np.d;
@@ -719,6 +808,7 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
         agent_sync<WAVE>();
         x = s_pose[0]; y = s_pose[1];
         d_new = __builtin_amdgcn_readfirstlane(s_pose_d);
+        if (SPEC) dvn = Real<T>::dir_table(p)[d_new];
         const T* tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
 #pragma unroll
         for (int k = 0; k < kCastCols; ++k) {
@@ -740,6 +830,7 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
             else if (c.wall) { }                                            // SR:170-171
             else { x = nx; y = ny; }                                        // SR:174
         }
+        if (!oob) done_now = done;
         if (tid == 0) {
             if (oob) {
                 p.err[0] = RCW_ERR_OUT_OF_BOUNDS;
@@ -763,6 +854,53 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
     uint8_t* const col_c_a = p.col_c + (size_t)a * N;
     uint32_t* const hc_a = PUBLISH ? p.step_hc + (size_t)a * N : nullptr;
     bool left_the_map = false;
+    if (SPEC) {
+        // The one-launch step (rcw_fill256_cast_kernel): besides the frame of the state just committed — descriptors as below, and the
+        // fill's packed word in slot 0 — the frames of its FOUR SUCCESSORS, one per action of the next act!(world, a) SR:139-191, so
+        // that the next launch's fill workgroups only pick the slot the action names.  A move that would be blocked, reach the goal or
+        // raise (SR:162-176: the pose stays) has the current frame: its slot gets the current fan's words.  An agent that is done
+        // under auto_reset is re-sampled by ANY next action: reset_preview draws the pose the next launch's commit will draw.
+        const T* const tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
+        uint16_t* const slot_a = spec_out + (size_t)a * N;
+        const size_t stride = (size_t)p.B * N;
+        const bool reborn = p.auto_reset != 0 && done_now != 0;
+        bool f_free = false, b_free = false;
+        const T ix = Real<T>::inc(p) * dvn.x, iy = Real<T>::inc(p) * dvn.y;
+        const T xf = x + ix, yf = y + iy, xb = x - ix, yb = y - iy;        // UT:16-17
+        if (!reborn) {
+            const Collide cf = player_colliding<T>(tb, p.H, p.W, xf, yf, Real<T>::radius_sq(p), p.oob_empty);
+            const Collide cb = player_colliding<T>(tb, p.H, p.W, xb, yb, Real<T>::radius_sq(p), p.oob_empty);
+            f_free = cf.wall == 0 && cf.goal == 0;
+            b_free = cb.wall == 0 && cb.goal == 0;
+        }
+        const uint32_t stay = 1u | (!reborn && !f_free ? 2u : 0u) | (!reborn && !b_free ? 4u : 0u);
+        left_the_map = spec_fan<T, TIE_LE, DIST_PRE, true>(p, tb, tid, nthr, x, y, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, col_h_a, col_c_a, slot_a, stride, stay);
+        if (!reborn) {
+            if (f_free) (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xf, yf, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, nullptr, nullptr, slot_a, stride, 2u);
+            if (b_free) (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xb, yb, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, nullptr, nullptr, slot_a, stride, 4u);
+#pragma unroll
+            for (int turn = 0; turn < 2; ++turn) {
+                const int dt = turn == 0 ? (d_new + 1 >= p.nd ? 0 : d_new + 1) : (d_new - 1 < 0 ? p.nd - 1 : d_new - 1);   // UT:13-14
+                const T* const tt = Real<T>::ray_table(p) + (size_t)dt * RCW_TABLE_ROWS * N;
+                spec_load_rows<T>(tt, tid, nthr, N, r_dx, r_dy, r_ddx, r_ddy, r_dot);
+                (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, x, y, r_dx, r_dy, r_ddx, r_ddy, r_dot, tt, nullptr, nullptr, slot_a, stride, turn == 0 ? 8u : 16u);
+            }
+        } else {
+            agent_sync<WAVE>();                                             // (every lane has read the tile bytes of the done state)
+            if (tid == 0) {
+                const Pose<T> np = reset_preview<T>(p, a, tb);
+                s_pose[0] = np.x; s_pose[1] = np.y; s_pose_d = np.d;
+            }
+            agent_sync<WAVE>();
+            const T xr = s_pose[0], yr = s_pose[1];
+            const int dr = __builtin_amdgcn_readfirstlane(s_pose_d);
+            const T* const tt = Real<T>::ray_table(p) + (size_t)dr * RCW_TABLE_ROWS * N;
+            spec_load_rows<T>(tt, tid, nthr, N, r_dx, r_dy, r_ddx, r_ddy, r_dot);
+            (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xr, yr, r_dx, r_dy, r_ddx, r_ddy, r_dot, tt, nullptr, nullptr, slot_a, stride, 30u);
+        }
+        if (left_the_map) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }   // (Julia: BoundsError in cast_ray)
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kCastCols; ++k) {
         const int i = tid + k * nthr;
@@ -1048,6 +1186,77 @@ __global__ __launch_bounds__(kBlock) void rcw_step256_kernel(const RcwDev p, con
     if ((threadIdx.x & 63u) == 0) __hip_atomic_store(p.step_flags + a, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif   // RCW_DEV_SWITCHES (rcw_step256_kernel)
+
+// ---- the WHOLE step in one launch, without a dependency inside it (round 6) ------------------------------------------------
+// act!(env, a) SR:333-340 orders dynamics -> cast_rays! -> update_camera_view!; as two kernels the cast (11 us at 4096 agents x
+// 256 columns, latency / issue bound) and a launch boundary sit in front of every fill.  But the frame of step t + 1 depends only on
+// (state_t, action_{t+1}) and there are four actions: the casting workgroups of launch t, once they have committed act!(world, a_t),
+// also cast the four successors of the new state into five slots of packed column words [5][B][N] (slot 0: the state itself — an
+// invalid action leaves the agent where it is; slots 1..4: the actions), and the fill workgroups of launch t + 1 only read the action
+// and pick the slot: action -> word -> colour, three dependent round trips a group like rcw_fill256_kernel's height -> colour id ->
+// colour (its pace: DESIGN.md §4.2).  Nothing in a launch waits for anything else in it — unlike rcw_step256_kernel above, whose
+// fill workgroups waited for the cast's flags and gained nothing.  Two slot buffers alternate: launch t reads the one launch t - 1
+// wrote and writes the other.  Workgroups 0 .. fill_blocks - 1 are the fill's (dispatched first, one per CU as in a launch of their
+// own); the casting workgroups — VALU / LDS work — run beside them under the HBM-bound sweep.  With fill_blocks = 0 the same kernel
+// PRIMES the slots behind a reset / set_state (or a first step) and the camera fill follows as a launch of its own.
+template <bool PLAIN>
+__device__ __forceinline__ void fill256_spec_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint16_t* __restrict__ slots,
+                                                  u32x4* __restrict__ out, long long total_cols, int block, int blocks, int n_shift)
+{
+    const int lane = threadIdx.x & 63;
+    const long long G = (long long)blocks * (kBlock / 64);
+    const long long g = (long long)block * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    const int r0 = lane * 4;
+    for (long long base = g; base < total_cols; base += G * 64) {
+        // lane l holds the word of this wavefront's l-th next chunk
+        const long long mine = base + (long long)lane * G;
+        int pad_l = -1;                       // -1: nothing to write (past the end)
+        uint32_t colour_l = 0u;
+        if (mine < total_cols) {
+            // the chunk's agent (the launcher takes this form below 2^29 columns), its action, the slot the action names
+            const uint32_t a = n_shift >= 0 ? (uint32_t)mine >> n_shift : (uint32_t)mine / (uint32_t)p.N;   // (n_shift: log2(N) where N is a power of two, else -1)
+            const uint32_t act = actions[a];
+            asm volatile("" :: "v"(act) : "memory");
+            const uint32_t sel = act - 1u < (uint32_t)RCW_NUM_ACTIONS ? act : 0u;   // (an action outside 1..4: the agent is not stepped, SR:140)
+            const uint32_t w = slots[(size_t)sel * (size_t)total_cols + (size_t)mine];
+            asm volatile("" :: "v"(w) : "memory");
+            pad_l = (int)(w & 0x1ffu);
+            colour_l = p.colour[(w >> 9) & 3u];
+        }
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+            const int pad = __builtin_amdgcn_readlane(pad_l, l);
+            if (pad < 0) continue;            // wave-uniform
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)colour_l, l);
+            u32x4 v;
+            v.x = pixel(r0 + 0, pad, 256, c, ceil_c, floor_c);
+            v.y = pixel(r0 + 1, pad, 256, c, ceil_c, floor_c);
+            v.z = pixel(r0 + 2, pad, 256, c, ceil_c, floor_c);
+            v.w = pixel(r0 + 3, pad, 256, c, ceil_c, floor_c);
+            store16<PLAIN>(out + (base + (long long)l * G) * 64 + lane, v);
+        }
+    }
+}
+
+// WAVE: a wavefront per agent, four agents a casting workgroup (at most 256 view columns: four a lane); else a workgroup per agent.
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
+__global__ __launch_bounds__(kBlock) void rcw_fill256_cast_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
+                                                                  u32x4* __restrict__ out, long long total_cols, int fill_blocks,
+                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if ((int)blockIdx.x < fill_blocks) { fill256_spec_body<false>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift); return; }
+    if (WAVE) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int a = ((int)blockIdx.x - fill_blocks) * (kBlock / 64) + wave;
+        if (a >= p.B) return;                                               // (wave-uniform: the batch's last workgroup may be short)
+        cast_body<T, TIE_LE, DIST_PRE, true, false, true>(p, actions, mask, a, (int)(threadIdx.x & 63u), 64, lds + (size_t)wave * lds_words, a, slots_out);
+    } else {
+        const int a = (int)blockIdx.x - fill_blocks;
+        cast_body<T, TIE_LE, DIST_PRE, false, false, true>(p, actions, mask, a, (int)threadIdx.x, kBlock, lds, a, slots_out);
+    }
+}
 
 // The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of
 // the k row blocks of a column: M = 1) and H_cam = 128 or 64 (a chunk holds M = 2 or 4 whole columns; lane l of a
@@ -2542,9 +2751,9 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         int lp = 0;
         { const int mpad = (M + 63) & ~63, g64 = group >> 6; while ((mpad << (lp + 1)) <= group && (g64 & ((2 << lp) - 1)) == 0) ++lp; }
         const int rpp = group >> lp;                                         // lines per pass, a multiple of 64: the part is wave-uniform
-        int part = 0;
-        { const int wpp = rpp >> 6, wv = tid >> 6; for (int t = wpp; t <= wv; t += wpp) ++part; }
-        const int pin = tid - part * rpp;
+        int seg = 0;
+        { const int wpp = rpp >> 6, wv = tid >> 6; for (int t = wpp; t <= wv; t += wpp) ++seg; }
+        const int pin = tid - seg * rpp;
         const uint32_t plane_bits = lds_address(b.line) * 8u;
         const uint32_t dummy_A = lds_address(bcount + lane) * 8u;              // (the 64 words of the class counters and starts: used up by now)
         const uint32_t frac0 = 0x80000000u + (1u << 14);
@@ -2563,8 +2772,8 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
                 sboth = si + sj;
                 A0 = plane_bits + (uint32_t)((jp - 1) * cb_ + (ip - 1));
                 slope = g.b >= g.a ? 0xFFFFFFFFu : line_slope(g.b, g.a);      // floor(2^32 · b / a)
-                ks = first + ((part * n) >> lp);                             // this lane's pixels of the line: ks .. ke - 1
-                len = first + (((part + 1) * n) >> lp) - ks;
+                ks = first + ((seg * n) >> lp);                             // this lane's pixels of the line: ks .. ke - 1
+                len = first + (((seg + 1) * n) >> lp) - ks;
                 if (len == 0) { A0 = dummy_A; smaj = sboth = 0; slope = 0u; }
             }
             const int ke = ks + len;
@@ -2629,7 +2838,9 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         }
     }
     RCW_DRAW_STAMP(3);
-    __syncthreads();
+    // (the walk's ds_or_b32 sit in asm statements, which the compiler's wait-count pass does not see: without the explicit
+    // lgkmcnt(0) a wavefront could pass the barrier with plane ORs still in flight while others read b.line[] below)
+    lds_barrier();
     RCW_DRAW_STAMP(4);
     if (tid == 0 && part == 0) RCW_PLANE_STORE(reinterpret_cast<uint2*>(p.top_hdr + a), make_uint2((uint32_t)ip, (uint32_t)jp));
     if (p.top_flat) {
@@ -2671,9 +2882,7 @@ __device__ __forceinline__ void top_draw_body(const RcwDev& p, const uint8_t* __
         RCW_DRAW_STAMP(5);
 #endif
 #ifdef RCW_DEV_SWITCHES
-    #ifdef RCW_DEV_SWITCHES
     if (p.top_signal) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) top_publish(p, a); }   // (the write-through stores above: written by name, awaited by name)
-#endif
 #endif
         return;
     }
@@ -3682,6 +3891,51 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
     }
 #endif
     RCW_DISPATCH(rcw_cast_kernel, dim3(count), dim3(p.cast_block), rcw_cast_lds_bytes(p), p, actions_dev, mask_dev, first);
+    return hipGetLastError();
+}
+
+// Same dispatch for a kernel template with a fourth (bool) parameter.
+#define RCW_DISPATCH_W(KERNEL, WFLAG, GRID, BLOCK, LDS, ...)                                                 \
+    do {                                                                                                     \
+        if (p.real64) {                                                                                      \
+            if (p.tie_le) { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<double, true, true, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__);   \
+                            else            hipLaunchKernelGGL((KERNEL<double, true, false, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__); } \
+            else          { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<double, false, true, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__);  \
+                            else            hipLaunchKernelGGL((KERNEL<double, false, false, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__); } \
+        } else {                                                                                             \
+            if (p.tie_le) { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<float, true, true, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__);    \
+                            else            hipLaunchKernelGGL((KERNEL<float, true, false, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__); }  \
+            else          { if (p.dist_pre) hipLaunchKernelGGL((KERNEL<float, false, true, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__);   \
+                            else            hipLaunchKernelGGL((KERNEL<float, false, false, WFLAG>), GRID, BLOCK, LDS, s, __VA_ARGS__); } \
+        }                                                                                                    \
+    } while (0)
+
+// The one-launch step (rcw_fill256_cast_kernel): the geometries that take it — a 256-row camera view filled by rcw_fill256_kernel's
+// window, no top view (its drawing needs the state the same launch commits), a batch of fewer than 2^29 view columns — the bytes of ONE
+// of its two slot buffers, and the launch: with_fill = the fill workgroups in front (a step); without, the casting workgroups alone
+// (they prime the slots behind a reset / set_state, or for a first step: the camera fill then follows as a launch of its own).
+int rcw_step_spec_eligible(const RcwDev& p)
+{
+    return p.top_view == nullptr && !p.fill_plain && (long long)p.B * p.N < (1ll << 29) && fill_choice(p, (long long)p.B * p.N) == kFill256 ? 1 : 0;
+}
+size_t rcw_step_spec_slot_bytes(const RcwDev& p) { return (size_t)5 * (size_t)p.B * (size_t)p.N * sizeof(uint16_t); }
+hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, const uint16_t* slots_in,
+                                uint16_t* slots_out, bool with_fill, hipStream_t s)
+{
+    const size_t per_agent = (rcw_cast_lds_bytes(p) + 15) & ~(size_t)15;
+    const int fill_blocks = with_fill ? p.fill_grid : 0;
+    const long long total_cols = (long long)p.B * p.N;
+    u32x4* const out = reinterpret_cast<u32x4*>(p.obs);
+    int n_shift = -1;
+    for (int k = 0; k < 31; ++k) if (p.N == (1 << k)) n_shift = k;
+    if (p.N <= 64 * kCastCols) {                                            // a wavefront per agent
+        const int cast_blocks = (p.B + kBlock / 64 - 1) / (kBlock / 64);
+        RCW_DISPATCH_W(rcw_fill256_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), (kBlock / 64) * per_agent, p, actions_dev, mask_dev,
+                       out, total_cols, fill_blocks, slots_in, slots_out, (int)(per_agent / 4), n_shift);
+    } else {
+        RCW_DISPATCH_W(rcw_fill256_cast_kernel, false, dim3(fill_blocks + p.B), dim3(kBlock), per_agent, p, actions_dev, mask_dev,
+                       out, total_cols, fill_blocks, slots_in, slots_out, (int)(per_agent / 4), n_shift);
+    }
     return hipGetLastError();
 }
 

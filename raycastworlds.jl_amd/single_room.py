@@ -727,6 +727,22 @@ class SingleRoom:
             raise ValueError(f"unknown top view form {form!r}")
         self._check(self._lib.rcw_set_top_view_form(self._h, forms[form], int(runs)))
 
+    def step_form(self) -> str:
+        """How many launches a step of this handle takes (rcw_step_form): "two-launches" (cast kernel, then fill kernel) or
+        "one-launch" (the fill picks each frame among the successors the previous launch cast: rcw_fill256_cast_kernel)."""
+        f = C.c_int32()
+        self._check(self._lib.rcw_step_form(self._h, C.byref(f)))
+        return {_capi.RCW_STEP_TWO_LAUNCHES: "two-launches", _capi.RCW_STEP_ONE_LAUNCH: "one-launch"}[f.value]
+
+    def set_step_form(self, form: Optional[str] = None) -> None:
+        """Choose the step's form instead of the library's rule (rcw_set_step_form): None = automatic, "two-launches" or
+        "one-launch".  Both leave the same state and the same pixels.  Raises RcwError (unsupported) when the geometry cannot
+        take the one-launch form (a 256-row camera view without a top view)."""
+        forms = {None: 0, "auto": 0, "two-launches": _capi.RCW_STEP_TWO_LAUNCHES, "one-launch": _capi.RCW_STEP_ONE_LAUNCH}
+        if form not in forms:
+            raise ValueError(f"unknown step form {form!r}")
+        self._check(self._lib.rcw_set_step_form(self._h, forms[form]))
+
     def fill_kernel_name(self) -> str:
         """The kernel update_camera_view! takes for this camera height (rcw_fill_kernel_name)."""
         buf = C.create_string_buffer(64)
