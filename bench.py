@@ -89,6 +89,7 @@ def cpu_baseline(kw, batch_hint, target_seconds=10.0):
     from oracle import oracle as O
 
     threads = usable_cores()
+    frame_kib = 4 * 256 * kw["num_rays"] // 1024
     one, steps1, dt1 = _time_oracle(O, kw, min(batch_hint, 32), 1, 0.6 * target_seconds)
     agents = min(batch_hint, 32 * threads)
     allc, steps, dt = _time_oracle(O, kw, agents, threads, target_seconds)
@@ -101,7 +102,8 @@ def cpu_baseline(kw, batch_hint, target_seconds=10.0):
         "all_cores": allc,
         "sample": f"all cores: {agents} agents x {steps} steps ({dt:.1f} s, OpenMP over agents, {threads} threads); "
                   f"single thread: {min(batch_hint, 32)} agents x {steps1} steps ({dt1:.1f} s); same workload, C restatement "
-                  f"of the reference camera path incl. the frame fill",
+                  f"of the reference camera path incl. the frame fill; the sample's frames ({agents * frame_kib // 1024} MiB, {frame_kib} KiB an agent) "
+                  f"stay in the host's caches where the GPU's batch does not fit any: a baseline that flatters the CPU",
     }
 
 
@@ -235,7 +237,66 @@ def make_watchdog(rank, emit, headline_ready, pending, seconds, exit_fn=os._exit
     return watchdog
 
 
-def main():
+class Runtime:
+    """What main() needs from torch, torch.distributed and the engine, in one place — so that tests/test_bench_logic.py can run main()'s
+    whole control flow (warm-up collective, timed region, gather of the ranks' clocks, the gather block, the line) on a CPU with doubles
+    for the three: a `dist` whose all_gather_into_tensor enforces the flat-shape rule RCCL and gloo share, a recording engine."""
+    device = "cuda"
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.dist = None
+
+    def gpu_available(self):
+        return self.torch.cuda.is_available()
+
+    def set_device(self, local_rank):
+        self.torch.cuda.set_device(local_rank)
+
+    def init_dist(self, backend, local_rank):
+        import torch.distributed as dist
+
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=self.torch.device("cuda", local_rank))
+        self.dist = dist
+
+    def engine(self):
+        import raycastworlds_jl_amd as RCW
+
+        return RCW
+
+    def ensure_built(self, rank):
+        from raycastworlds_jl_amd import _capi
+
+        if not os.path.exists(_capi.LIB_PATH):       # a checkout without the (git-ignored) build artefact
+            if rank == 0:
+                from raycastworlds_jl_amd import build as _build
+
+                _build.build()
+            if self.dist is not None:
+                self.dist.barrier()
+
+    def make_actions(self, total, B, rank):
+        gen = self.torch.Generator(device="cuda")
+        gen.manual_seed(1234 + rank)
+        return self.torch.randint(1, 5, (total, B), dtype=self.torch.uint8, device="cuda", generator=gen)
+
+    def share_stream(self, env):
+        # engine and torch share ONE stream (the deployment shape: policy kernels and env kernels in order on
+        # a single queue, no cross-stream waits)
+        stream = self.torch.cuda.Stream()
+        env.set_stream(stream.cuda_stream)
+        self.torch.cuda.set_stream(stream)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+
+def main(argv=None, rt=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -243,11 +304,15 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="agents per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0, help="about how long the all-cores leg of the CPU baseline runs")
     ap.add_argument("--traffic", default="live", choices=["live", "committed", "off"],
                     help="roofline.traffic (HBM bytes per launch of the dominant kernel, PMC counters): live = measured by this run (rank 0 "
                          "at N = 1: two short rocprofv3 --pmc passes of this script as child processes, after the timed region; falls back to "
                          "the committed figure if the profiler is not available), committed = profiles/pmc_traffic.json, off = null")
     ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--step-form", default="auto", choices=["auto", "one-launch", "two-launches"],
+                    help="rcw_set_step_form: auto = the library's rule (one launch a step wherever the geometry allows: every BASELINE "
+                         "configuration), two-launches = the cast kernel followed by the fill kernel (rounds 1-5), for the comparison")
     ap.add_argument("--top-view", action="store_true",
                     help="also render the reference's top view every step (update_top_view! SR:446-483, opt-in in the "
                          "engine) and report that kernel's own roofline block; NOT the headline workload")
@@ -266,7 +331,7 @@ def main():
                     help="how long the optional gather may take before every rank gives up with exit code 3")
     ap.add_argument("--hang-rank", type=int, default=-1,
                     help="test only: this rank never enters the gather's first collective (tests/test_gpu_rccl.py drives the watchdog with it)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     # Rank 0 must print ONE JSON line on stdout and nothing else.  Libraries do not know that (RCCL prints a version
     # banner on stdout when a communicator is created): from here on file descriptor 1 is stderr, and the JSON line is
@@ -275,7 +340,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
+    rt = rt or Runtime()
+    torch = rt.torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -284,53 +350,38 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
+    if not rt.gpu_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     if args.rehearse_on_one_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
+    rt.set_device(local_rank)
     if world > 1 or args.gather:
-        import torch.distributed as dist
-
         if world == 1:                               # --gather on one GPU: a process group of one rank
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        rt.init_dist("gloo" if args.rehearse_on_one_gpu else "nccl", local_rank)
+    dist = rt.dist
+    dev = rt.device
 
-    import raycastworlds_jl_amd as RCW
-    from raycastworlds_jl_amd import _capi
-
-    if not os.path.exists(_capi.LIB_PATH):       # a checkout without the (git-ignored) build artefact
-        if rank == 0:
-            from raycastworlds_jl_amd import build as _build
-
-            _build.build()
-        if dist is not None:
-            dist.barrier()
+    RCW = rt.engine()
+    rt.ensure_built(rank)
 
     kw, per_gpu = WORKLOADS[args.workload]
     B = args.batch or per_gpu
     N, Hc = kw["num_rays"], 256
     env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=0, device=local_rank, auto_reset=not args.no_auto_reset,
                                           agent_id_offset=rank * B, render_top_view=args.top_view, **kw)
+    if args.step_form != "auto":
+        env.set_step_form(args.step_form)
+    step_form = env.step_form()
     # U{1..4} actions per agent per step (test/runtests.jl:28), pre-generated on the device
     total = args.warmup + args.steps
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    actions = torch.randint(1, 5, (total, B), dtype=torch.uint8, device="cuda", generator=gen)
-    torch.cuda.synchronize()
-    # engine and torch share ONE stream (the deployment shape: policy kernels and env kernels in order on
-    # a single queue, no cross-stream waits)
-    stream = torch.cuda.Stream()
-    env.set_stream(stream.cuda_stream)
-    torch.cuda.set_stream(stream)
+    actions = rt.make_actions(total, B, rank)
+    rt.synchronize()
+    rt.share_stream(env)
 
     def barrier():
         if dist is not None:
@@ -351,14 +402,14 @@ def main():
     cpu_coll = args.rehearse_on_one_gpu              # gloo moves host tensors only
 
     def gather_rows(values):
-        return gather_rank_rows(dist, world, values, "cpu" if cpu_coll else "cuda")
+        return gather_rank_rows(dist, world, values, "cpu" if cpu_coll else dev)
 
     for s in range(args.warmup):
         RCW.act_(env, actions[s])
     sync_counting_bounds_errors()
-    torch.cuda.synchronize()
+    rt.synchronize()
     gather_rows([0.0])                               # one warm-up collective: the communicator is up before the clock starts
-    torch.cuda.synchronize()
+    rt.synchronize()
     barrier()
     t0 = time.perf_counter()
     env.timer_start()
@@ -366,7 +417,7 @@ def main():
         RCW.act_(env, actions[s])
     kernel_ms = env.timer_stop()   # HIP events on the stream the kernels run on
     bounds_errors = sync_counting_bounds_errors()
-    torch.cuda.synchronize()
+    rt.synchronize()
     dt = time.perf_counter() - t0  # this rank's own clock, stopped behind its own synchronisation: NO collective inside dt
     barrier()
     # Outside the timed region: the same steps again with HIP events around each kernel, to
@@ -389,8 +440,8 @@ def main():
     if args.api == "rlbase":
         RLBase = RCW.RLBase
         rl = RCW.RLBaseEnv(env)
-        returns = torch.zeros(B, dtype=torch.float32, device="cuda")
-        episodes = torch.zeros(B, dtype=torch.int32, device="cuda")
+        returns = torch.zeros(B, dtype=torch.float32, device=dev)
+        episodes = torch.zeros(B, dtype=torch.int32, device=dev)
         def api_step(s):
             state = RLBase.state(rl)                                  # runtests.jl:27 (aliased, device-resident)
             rl(actions[s])                                            # runtests.jl:29
@@ -403,7 +454,7 @@ def main():
         for s in range(args.warmup):                                  # (the whole loop body: torch loads its kernels on first use)
             api_step(s)
         sync_counting_bounds_errors()
-        torch.cuda.synchronize()
+        rt.synchronize()
         barrier()
         returns.zero_(); episodes.zero_()
         syncs0 = env.host_syncs
@@ -412,7 +463,7 @@ def main():
             state = api_step(s)
         syncs = env.host_syncs - syncs0                               # (before the closing synchronisation below)
         bounds_api = sync_counting_bounds_errors()
-        torch.cuda.synchronize()
+        rt.synchronize()
         dta = time.perf_counter() - t0a                               # (this rank's own clock, as above)
         barrier()
         dta = max(r[0] for r in gather_rows([dta]))
@@ -456,10 +507,11 @@ def main():
                 try:
                     with open(tpath) as f:
                         t = json.load(f)
-                    if t.get("workload") == args.workload and t.get("batch") == B:
+                    if t.get("workload") == args.workload and t.get("batch") == B and t.get("kernel", "rcw_fill256_kernel") == fill_kernel:
                         traffic = t.get("traffic_bytes_per_launch")
-                        traffic_source = ("profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE of the fill kernel from separate rocprofv3 --pmc "
-                                          "passes of this command, committed; not re-measured in this run")
+                        traffic_source = (f"profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE of {fill_kernel} from separate rocprofv3 --pmc "
+                                          "passes of this command at N = 1, committed; not re-measured in this run"
+                                          + (f" ({world} ranks: each rank runs the same per-GPU workload)" if world > 1 else ""))
                 except Exception:
                     traffic = None
         out = {
@@ -487,6 +539,7 @@ def main():
                 "agents_that_hit_reference_BoundsError": bounds_errors,
                 "actions": "uniform 1..4 per agent per step, device resident",
                 "sharding": f"agents by rank x{world}, no data-path collective",
+                "step_form": step_form,
             },
             "frames_per_s": world * B * args.steps / dt,
             "roofline": {
@@ -503,7 +556,9 @@ def main():
                 "launches_timed": nrec,
                 "per_rank": ranks["per_rank"],
                 "whole_step": {
-                    "kernels": "rcw_cast_kernel + fill kernel",
+                    "kernels": ("rcw_fill256_cast_kernel alone: the fill workgroups write the frames the actions select among the successors the "
+                                "previous launch cast, the casting workgroups commit the actions and cast the next successors beside them"
+                                if step_form == "one-launch" else "rcw_cast_kernel + fill kernel"),
                     "launch_ms": step_s * 1e3,
                     "cast_ms": cast_ms,
                     "achieved": step_achieved,
@@ -570,7 +625,7 @@ def main():
 
         def all_reduce_max(values, what):
             pending["what"] = f"all_reduce(MAX) of {what}, world {world}"
-            t = torch.tensor(values, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            t = torch.tensor(values, dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return [float(v) for v in t]
 
@@ -581,18 +636,18 @@ def main():
             h_loc, c_loc = env.columns_device()
             h_loc, c_loc = h_loc.torch(sync=False), c_loc.torch(sync=False)
             obs_loc = env.camera_view.torch(sync=False).view(torch.int32)[:Bf]
-            gh = torch.empty((world * B, N), dtype=torch.int32, device="cuda")
-            gc = torch.empty((world * B, N), dtype=torch.uint8, device="cuda")
-            frames_all = torch.empty((world * B, N, Hc), dtype=torch.uint32, device="cuda")
+            gh = torch.empty((world * B, N), dtype=torch.int32, device=dev)
+            gc = torch.empty((world * B, N), dtype=torch.uint8, device=dev)
+            frames_all = torch.empty((world * B, N, Hc), dtype=torch.uint32, device=dev)
             frames_part = frames_all.view(torch.int32)[:world * Bf]
 
             def timed(fn, reps):
                 fn()
-                torch.cuda.synchronize(); pending["what"] = "barrier inside the gather timing"; barrier()
+                rt.synchronize(); pending["what"] = "barrier inside the gather timing"; barrier()
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     fn()
-                torch.cuda.synchronize(); pending["what"] = "barrier inside the gather timing"; barrier()
+                rt.synchronize(); pending["what"] = "barrier inside the gather timing"; barrier()
                 return (time.perf_counter() - t0) / reps * 1e6
 
             def cols():
@@ -607,7 +662,7 @@ def main():
             t_frames = timed(lambda: all_gather(frames_part, obs_loc, "frames (uint32 as int32)"), 1 if rehearsal else 3)
             if rehearsal:
                 # what a rehearsal CAN check: the gathered global batch is this rank's own shard in the right place
-                torch.cuda.synchronize()
+                rt.synchronize()
                 assert torch.equal(gh[rank * B:(rank + 1) * B], h_loc) and torch.equal(gc[rank * B:(rank + 1) * B], c_loc)
                 assert torch.equal(frames_part[rank * Bf:(rank + 1) * Bf], obs_loc)
         except Exception as e:   # noqa: BLE001 — a reported extra must never cost the bench line
@@ -635,10 +690,11 @@ def main():
 
     if rank == 0:
         if world == 1 and args.traffic == "live":
-            traffic_live = live_traffic(args.workload, B, fill_kernel, extra_args=["--top-view"] if args.top_view else [])
+            traffic_live = live_traffic(args.workload, B, fill_kernel, extra_args=(["--top-view"] if args.top_view else []) + ["--step-form", args.step_form])
         out = build_line(gather)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kw, B)
+        if not args.no_cpu_baseline:
+            # rank 0's own host cores, outside every timed region, at any N (the other ranks wait at the closing barrier)
+            out["cpu_baseline"] = cpu_baseline(kw, B, args.cpu_baseline_seconds)
         emit(out)
     env.close()
     if dist is not None:

@@ -295,7 +295,11 @@ RCW_API int rcw_rays(rcw_handle* h, int32_t first, int32_t count,
              float* distance_wu /* (N, count) */, float* directions_wu /* (2, N, count) */);
 /* Compact per-column descriptor of the current frames, indexed by image column k
  * (k = N - i + 1, SR:431): height_line_pu SR:408-411 (Int32, saturated) and colour id.
- */
+ * In the two-launch step these arrays are what the cast kernel hands to the fill kernel, refreshed by every step.  The one-launch
+ * step (RCW_STEP_ONE_LAUNCH below) does not need them and every store of its casting workgroups costs the launch more than its bytes:
+ * it refreshes them only for a caller that holds the device pointers — from the first rcw_columns_device_ptr call on, every step of
+ * the handle does —; otherwise rcw_columns, the gathers and rcw_update_camera_view recast the current state (the cast kernel,
+ * no action, ~10 us at 4096 agents x 256 columns) in front of their read, on demand. */
 RCW_API int rcw_columns(rcw_handle* h, int32_t first, int32_t count,
                 int32_t* height_line_pu /* (N, count) */, uint8_t* colour_id /* (N, count) */);
 RCW_API int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** colour_id);
@@ -394,8 +398,8 @@ RCW_API int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs);
  *   RCW_STEP_ONE_LAUNCH    the frame of the NEXT step depends only on this step's state and the next action, and there are four
  *                          actions: the casting workgroups of a launch commit the dynamics and also cast the four successor states
  *                          (a blocked / goal / raising move keeps the current frame; an agent that is done under cfg.auto_reset gets
- *                          the re-sampled world's, drawn ahead without being committed) into slots in HBM (10 bytes a view column, two
- *                          buffers), and the fill workgroups of the NEXT launch, in the same launch as that step's casting, write the
+ *                          the re-sampled world's, drawn ahead without being committed) into slots in HBM (two buffers of 10 bytes a
+ *                          view column), and the fill workgroups of the NEXT launch, in the same launch as that step's casting, write the
  *                          frames the actions select.  Nothing inside a launch waits for anything else in it; the cast kernel and a
  *                          launch boundary leave the step's critical path.  rcw_reset / rcw_set_state (and a first step) cast as a
  *                          launch of their own, which leaves the slots of the agents it touches ready.

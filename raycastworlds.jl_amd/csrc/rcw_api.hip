@@ -90,10 +90,16 @@ struct rcw_handle {
     bool profiling = false;
     int step_pieces = 1;               // development experiment only (RCW_STEP_PIECES)
     void* d_step_flags = nullptr; void* d_step_hc = nullptr; uint32_t step_epoch = 0;   // development experiment only (RCW_STEP_FUSED)
-    // the one-launch step (rcw_fill256_cast_kernel): two buffers of [5][B][N] packed column words — d_spec[spec_cur] holds the frames of the
+    // the one-launch step (rcw_fill256_cast_kernel): two buffers of [B][5][N] packed column words — d_spec[spec_cur] holds the frames of the
     // CURRENT state (slot 0) and of its four successors (slots 1..4), written by the last casting launch; spec_primed: for every agent
     void* d_spec[2] = {nullptr, nullptr}; int spec_cur = 0; bool spec_primed = false;
     int spec_on = 0;                   // a step is ONE launch (rcw_fill256_cast_kernel)
+    // The (height_line_pu, colour id) descriptors of the current frames (d_col_h / d_col_c) are what the two-launch step hands from its cast
+    // kernel to its fill kernel; the one-launch step's fill reads the slots instead, and every store of the casting workgroups costs the
+    // launch more than its bytes (profiles/r06_step_forms.txt) — so it writes the descriptors only for a caller that holds their device
+    // pointers (cols_live: rcw_columns_device_ptr was called), and otherwise leaves them stale: ensure_columns recasts the current state
+    // (the cast kernel, no action) in front of whatever reads them (rcw_columns, the gathers, rcw_update_camera_view).
+    bool cols_live = false, cols_stale = false;
     int step_form_want = 0;            // rcw_set_step_form: 0 = the rule, or RCW_STEP_TWO_LAUNCHES / RCW_STEP_ONE_LAUNCH
     bool step_captured = false;        // a step of this handle was captured into a graph: it keeps the two-launch form from then on
     int prof_count = 0;
@@ -237,14 +243,16 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
             // casting launch left in `cur`; the casting workgroups commit the actions and cast the new states' successors into the other buffer
             uint16_t* const next = (uint16_t*)h->d_spec[h->spec_cur ^ 1];
             if (prof && ((e = hipEventRecord(ev[1], h->stream)) != hipSuccess || (e = hipEventRecord(ev[2], h->stream)) != hipSuccess)) return e;
-            if ((e = rcw_launch_step_spec(d, actions_dev, nullptr, cur, next, true, h->stream)) != hipSuccess) return e;
+            if ((e = rcw_launch_step_spec(d, actions_dev, nullptr, cur, next, true, h->cols_live, h->stream)) != hipSuccess) return e;
             h->spec_cur ^= 1;
+            if (!h->cols_live) h->cols_stale = true;
             if (prof) { if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e; h->prof_count++; }
             return hipSuccess;
         }
         // reset! / set_state (no action, maybe a mask) or a first step: the casting workgroups alone — dynamics if any, the current frame's
         // descriptors, and the (masked) agents' slots in place —, then the camera fill as a launch of its own
-        if ((e = rcw_launch_step_spec(d, actions_dev, mask_dev, nullptr, cur, false, h->stream)) != hipSuccess) return e;
+        if ((e = rcw_launch_step_spec(d, actions_dev, mask_dev, nullptr, cur, false, true, h->stream)) != hipSuccess) return e;
+        if (!mask_dev) h->cols_stale = false;                 // (with a mask: the masked agents' descriptors are fresh — the fill below reads only those —, the others' as stale as before)
         if (!mask_dev) h->spec_primed = true;
         if (prof && ((e = hipEventRecord(ev[1], h->stream)) != hipSuccess || (e = hipEventRecord(ev[2], h->stream)) != hipSuccess)) return e;
         if ((e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, (long long)d.B * d.N, mask_dev, h->stream)) != hipSuccess) return e;
@@ -666,6 +674,16 @@ int validate_config(const rcw_config* c, int32_t batch)
     return RCW_OK;
 }
 
+// The descriptors of the current frames, where the one-launch step left them stale (rcw_handle::cols_live): cast_rays! SR:195-231 on the
+// current state, no action — the cast kernel, stream-ordered in front of the reader.
+int ensure_columns(rcw_handle* h)
+{
+    if (!h->cols_stale) return RCW_OK;
+    RCW_HIP(rcw_launch_cast(h->dev, nullptr, nullptr, h->stream));
+    h->cols_stale = false;
+    return RCW_OK;
+}
+
 // Wait for the stream, then surface the sticky device error word.
 int sync_and_check(rcw_handle* h)
 {
@@ -1003,6 +1021,10 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
         free_all(h); delete h;
         return fail(RCW_ERR_UNSUPPORTED, "tile map + column buffer need %zu B of LDS (> 64 KiB)", rcw_step_lds_bytes(d));
     }
+#ifdef RCW_DEV_SWITCHES
+    d.spec_debug = 0;
+    if (const char* v = RCW_DEV_ENV("RCW_SPEC_DEBUG")) d.spec_debug = std::atoi(v);
+#endif
     {
         int want = 0;
         if (const char* v = RCW_DEV_ENV("RCW_STEP_FORM")) { const int f = std::atoi(v); if (f == RCW_STEP_TWO_LAUNCHES) want = f; }
@@ -1189,12 +1211,14 @@ int rcw_cast_rays(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
     RCW_HIP(rcw_launch_cast(h->dev, nullptr, nullptr, h->stream));   // no action: rays + descriptors only
+    h->cols_stale = false;
     return RCW_OK;
 }
 
 int rcw_update_camera_view(rcw_handle* h)
 {
     int rc = check_handle(h); if (rc) return rc;
+    rc = ensure_columns(h); if (rc) return rc;
     RCW_HIP(rcw_launch_fill(h->dev, h->dev.col_h, h->dev.col_c, h->dev.obs, (long long)h->dev.B * h->dev.N, nullptr, h->stream));
     return RCW_OK;
 }
@@ -1374,6 +1398,7 @@ int rcw_columns(rcw_handle* h, int32_t first, int32_t count, int32_t* height_lin
     int rc = check_handle(h); if (rc) return rc;
     if (first < 0 || count < 0 || first + (int64_t)count > h->B)
         return fail(RCW_ERR_INVALID_ARGUMENT, "bad agent range [%d, %d)", first, first + count);
+    rc = ensure_columns(h); if (rc) return rc;
     rc = sync_and_check(h);
     const size_t N = (size_t)h->cfg.num_rays;
     if (height_line_pu)
@@ -1386,6 +1411,11 @@ int rcw_columns(rcw_handle* h, int32_t first, int32_t count, int32_t* height_lin
 int rcw_columns_device_ptr(rcw_handle* h, void** height_line_pu, void** colour_id)
 {
     if (!h) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL handle");
+    {   // from now on every step refreshes the descriptors (the caller reads them through the pointers, behind the library's back)
+        int rc = check_handle(h); if (rc) return rc;
+        h->cols_live = true;
+        rc = ensure_columns(h); if (rc) return rc;
+    }
     if (height_line_pu) *height_line_pu = h->d_col_h;
     if (colour_id) *colour_id = h->d_col_c;
     return RCW_OK;
@@ -1455,6 +1485,7 @@ int rcw_gather_columns(rcw_handle* h, int32_t* height_all, uint8_t* colour_all)
     int rc = check_handle(h); if (rc) return rc;
     rc = need_comm(h, "rcw_gather_columns"); if (rc) return rc;
     if (!height_all || !colour_all) return fail(RCW_ERR_INVALID_ARGUMENT, "NULL argument");
+    rc = ensure_columns(h); if (rc) return rc;
     const size_t n = (size_t)h->B * h->cfg.num_rays;
     // one fused group: the two all-gathers progress together on the handle's stream, behind the step
     RCW_NCCL(g_rccl.GroupStart());

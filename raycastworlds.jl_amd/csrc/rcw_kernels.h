@@ -96,6 +96,9 @@ struct RcwDev {
     int32_t fill_pairs;      // development only (RCW_FILL_FLAT_PAIRS=1): rcw_fill_flat_kernel with two wavefronts to a slot of the window
     int32_t* err;            // sticky error word of the handle (0 = ok); never blocks a step
     int32_t* status;         // per-agent sticky status
+#ifdef RCW_DEV_SWITCHES
+    int32_t spec_debug;      // development only (RCW_SPEC_DEBUG): timing probes of the one-launch step — bit 0 the casting workgroups return at once, bit 1 the fill's (wrong frames)
+#endif
 };
 
 struct RcwRayOut {           // rcw_rays(): SR:29-31,39 for agents [first, first+count)
@@ -131,11 +134,11 @@ int rcw_top_draw_per_cu(const RcwDev& p, int draw_block);   // draw workgroups r
 int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int cus);   // draw + store (+ camera fill) workgroups resident on one CU together
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block = 0);    // agents [first, first + count); block: threads a workgroup, 0 = p.top_draw_block
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);
-// the one-launch step (round 6): eligibility of a geometry, the bytes of one of its two slot buffers ([5][B][N] packed column words), the launch
+// the one-launch step (round 6): eligibility of a geometry, the bytes of one of its two slot buffers ([B][5][N] packed column words), the launch
 int rcw_step_spec_eligible(const RcwDev& p);
 size_t rcw_step_spec_slot_bytes(const RcwDev& p);
 hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, const uint16_t* slots_in,
-                                uint16_t* slots_out, bool with_fill, hipStream_t s);
+                                uint16_t* slots_out, bool with_fill, bool cols, hipStream_t s);   // cols: the step also leaves the current frame's (height, colour id) descriptors
 #ifdef RCW_DEV_SWITCHES
 bool rcw_step_fusable(const RcwDev& p);       // development experiment (RCW_STEP_FUSED): cast + camera fill in one launch
 hipError_t rcw_launch_step256(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, uint32_t epoch, hipStream_t s);

@@ -95,6 +95,8 @@ template <> struct Real<double> {
     static __device__ __forceinline__ double two_fov(const RcwDev& p) { return p.two_fov64; }
     static __device__ __forceinline__ vec2 make(double x, double y) { return make_double2(x, y); }
 };
+__device__ __forceinline__ float rabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double rabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float rfloor(float x) { return floorf(x); }
 __device__ __forceinline__ double rfloor(double x) { return floor(x); }
 // floor(Int, x) saturated to Int32 (the reference raises InexactError only beyond Int64)
@@ -624,26 +626,47 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
 // The word the fill reads for a column of a 256-row camera view: its padding (SR:436, 0..256) | colour id << 9.
 __device__ __forceinline__ uint32_t spec_word(int h, int cid) { return (uint32_t)column_padding(256, h) | ((uint32_t)cid << 9); }
 
-// a heading's table entries of this lane's first kCastCols view columns (as cast_body's batch 2)
+// Under the HBM-bound fill every vector-memory operation of the casting workgroups costs the launch several times what it costs alone,
+// every vector instruction next to nothing (profiles/r06_step_forms.txt): the casting half therefore LOADS only the ray's direction
+// (rows 0, 1 of the heading's table slice) and recomputes the other three entries exactly as the host's table builder made them
+// (rcw_api.hip, build_ray_table): |1 / dx|, |1 / dy| — IEEE division, correctly rounded on both sides — and sum(dir .* ray) SR:404 =
+// fl(fl(d1 r1) + fl(d2 r2)), one rounding an operation (this file is compiled without contraction).
 template <typename T>
-__device__ __forceinline__ void spec_load_rows(const T* tab, int tid, int nthr, int N, T* r_dx, T* r_dy, T* r_ddx, T* r_ddy, T* r_dot)
+__device__ __forceinline__ void spec_derive(T dx, T dy, T hx, T hy, T& ddx, T& ddy, T& dot)
+{
+    ddx = rabs((T)1 / dx);
+    ddy = rabs((T)1 / dy);
+    const T m1 = hx * dx, m2 = hy * dy;
+    dot = m1 + m2;
+}
+// a heading's ray directions of this lane's first kCastCols view columns: the loads ...
+template <typename T>
+__device__ __forceinline__ void spec_load_rows(const T* tab, int tid, int nthr, int N, T* r_dx, T* r_dy)
 {
 #pragma unroll
     for (int k = 0; k < kCastCols; ++k) {
         const int i = tid + k * nthr;
         const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);
-        r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o);
-        r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+        r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o);
     }
+}
+// ... and the entries derived from them (hx, hy: the heading's direction vector, directions_wu[d] SR:65-69)
+template <typename T>
+__device__ __forceinline__ void spec_derive_rows(T hx, T hy, const T* r_dx, const T* r_dy, T* r_ddx, T* r_ddy, T* r_dot)
+{
+#pragma unroll
+    for (int k = 0; k < kCastCols; ++k) spec_derive<T>(r_dx[k], r_dy[k], hx, hy, r_ddx[k], r_ddy[k], r_dot[k]);
 }
 
 // One state's whole fan (cast_rays! SR:195-231 + the column of update_camera_view! SR:401-429) from pose (x, y) with the table entries
-// of its heading: the packed word of every column into the slots `slots` names (bit s: slot s of [5][B][N]); COLS: also the
-// (height_line_pu, colour id) descriptors of the current frame, as cast_column.  Returns whether a ray left the map.
+// of its heading: the packed word of every column into the slots `slots` names (bit s: slot s of the agent's [5][N] words — the five
+// slots of an agent lie together, [B][5][N]: what the casting workgroups write is ONE stream through memory beside the fill's);
+// COLS && col_h_a: also the (height_line_pu, colour id) descriptors of the current frame, as cast_column.  hx, hy: the heading's
+// direction vector (for the columns beyond kCastCols a lane, whose entries are loaded and derived here).  Returns whether a ray left the map.
 template <typename T, bool TIE_LE, bool DIST_PRE, bool COLS>
 __device__ __forceinline__ bool spec_fan(const RcwDev& p, const uint8_t* tb, int tid, int nthr, T x, T y,
-                                         const T* r_dx, const T* r_dy, const T* r_ddx, const T* r_ddy, const T* r_dot, const T* tab,
-                                         int32_t* col_h_a, uint8_t* col_c_a, uint16_t* slot_a, size_t stride, uint32_t slots)
+                                         const T* r_dx, const T* r_dy, const T* r_ddx, const T* r_ddy, const T* r_dot, const T* tab, T hx, T hy,
+                                         int32_t* col_h_a, uint8_t* col_c_a, uint16_t* slot_a, uint32_t stride, uint32_t slots)
 {
     const int N = p.N;
     bool left = false;
@@ -653,14 +676,21 @@ __device__ __forceinline__ bool spec_fan(const RcwDev& p, const uint8_t* tb, int
         const int h = r.oob ? p.Hc : hl;
         const int cid = ((r.bits & 1u) ? 0 : 2) + (r.dim == 1 ? 0 : 1);     // SR:417-429
         const uint32_t k = (uint32_t)(N - 1 - i);                           // SR:431 (0-based)
-        if (COLS) {
+#ifdef RCW_DEV_SWITCHES
+        if (COLS && col_h_a != nullptr && !(p.spec_debug & 4)) {
+#else
+        if (COLS && col_h_a != nullptr) {                                    // (wave-uniform)
+#endif
             *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(col_h_a) + k * 4u) = h;
             *(col_c_a + k) = (uint8_t)cid;
         }
         const uint16_t w = (uint16_t)spec_word(h, cid);
         uint16_t* const q = slot_a + k;
+#ifdef RCW_DEV_SWITCHES
+        if (p.spec_debug & 4) { asm volatile("" :: "v"(w)); left |= r.oob; return; }   // (timing probe: no slot stores)
+#endif
 #pragma unroll
-        for (int s = 0; s < 5; ++s) if (slots & (1u << s)) q[(size_t)s * stride] = w;   // (wave-uniform)
+        for (int s = 0; s < 5; ++s) if (slots & (1u << s)) q[(uint32_t)s * stride] = w;   // (wave-uniform)
         left |= r.oob;
     };
 #pragma unroll
@@ -670,7 +700,12 @@ __device__ __forceinline__ bool spec_fan(const RcwDev& p, const uint8_t* tb, int
     }
     if (N > kCastCols * nthr) {                                             // more than kCastCols columns a lane
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (int i = tid + kCastCols * nthr; i < N; i += nthr) column(i, tab[i], tab[N + i], tab[2 * N + i], tab[3 * N + i], tab[4 * N + i]);
+        for (int i = tid + kCastCols * nthr; i < N; i += nthr) {
+            const T dx = tab[i], dy = tab[N + i];
+            T ddx, ddy, dot;
+            spec_derive<T>(dx, dy, hx, hy, ddx, ddy, dot);
+            column(i, dx, dy, ddx, ddy, dot);
+        }
     }
     return left;
 }
@@ -719,7 +754,7 @@ __device__ __forceinline__ void agent_sync()
 template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE, bool PUBLISH = false, bool SPEC = false>
 __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
                                           const int a, const int tid, const int nthr, uint32_t* const lds, const int trace_slot,
-                                          uint16_t* __restrict__ spec_out = nullptr)
+                                          uint16_t* __restrict__ spec_out = nullptr, const int spec_cols = 1)
 {
     typedef typename Real<T>::vec2 vec2;
     const int H = p.H, HW = p.H * p.W, N = p.N;
@@ -767,8 +802,11 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
         for (int k = 0; k < kCastCols; ++k) {                               // (five uniform row bases, one lane offset per column)
             const int i = tid + k * nthr;
             const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);   // (lanes past the last column re-read it)
-            r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o);
-            r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+            r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o);
+            if (!SPEC) {                                                    // (SPEC derives the other three: spec_derive)
+                r_ddx[k] = load_at(tab + 2 * N, o);
+                r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+            }
         }
     }
 
@@ -814,8 +852,11 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
         for (int k = 0; k < kCastCols; ++k) {
             const int i = tid + k * nthr;
             const uint32_t o = (uint32_t)(i < N ? i : N - 1) * (uint32_t)sizeof(T);
-            r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o); r_ddx[k] = load_at(tab + 2 * N, o);
-            r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+            r_dx[k] = load_at(tab, o); r_dy[k] = load_at(tab + N, o);
+            if (!SPEC) {
+                r_ddx[k] = load_at(tab + 2 * N, o);
+                r_ddy[k] = load_at(tab + 3 * N, o); r_dot[k] = load_at(tab + 4 * N, o);
+            }
         }
     } else if (act != 0) {
         int done = 0;                                                       // reward = done ? goal_reward : zero(R)
@@ -861,8 +902,10 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
         // raise (SR:162-176: the pose stays) has the current frame: its slot gets the current fan's words.  An agent that is done
         // under auto_reset is re-sampled by ANY next action: reset_preview draws the pose the next launch's commit will draw.
         const T* const tab = Real<T>::ray_table(p) + (size_t)d_new * RCW_TABLE_ROWS * N;
-        uint16_t* const slot_a = spec_out + (size_t)a * N;
-        const size_t stride = (size_t)p.B * N;
+        uint16_t* const slot_a = spec_out + (size_t)a * 5u * (size_t)N;     // [B][5][N]
+        const uint32_t stride = (uint32_t)N;
+        int32_t* const ch = spec_cols ? col_h_a : nullptr;                  // the descriptors of the current frame: only where somebody reads them (rcw_api.hip, ensure_columns)
+        spec_derive_rows<T>(dvn.x, dvn.y, r_dx, r_dy, r_ddx, r_ddy, r_dot);
         const bool reborn = p.auto_reset != 0 && done_now != 0;
         bool f_free = false, b_free = false;
         const T ix = Real<T>::inc(p) * dvn.x, iy = Real<T>::inc(p) * dvn.y;
@@ -874,16 +917,24 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
             b_free = cb.wall == 0 && cb.goal == 0;
         }
         const uint32_t stay = 1u | (!reborn && !f_free ? 2u : 0u) | (!reborn && !b_free ? 4u : 0u);
-        left_the_map = spec_fan<T, TIE_LE, DIST_PRE, true>(p, tb, tid, nthr, x, y, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, col_h_a, col_c_a, slot_a, stride, stay);
+        left_the_map = spec_fan<T, TIE_LE, DIST_PRE, true>(p, tb, tid, nthr, x, y, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, dvn.x, dvn.y, ch, col_c_a, slot_a, stride, stay);
+#ifdef RCW_DEV_SWITCHES
+        if (p.spec_debug & 16) return;                                      // (timing probe: the current state's fan only)
+#endif
         if (!reborn) {
-            if (f_free) (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xf, yf, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, nullptr, nullptr, slot_a, stride, 2u);
-            if (b_free) (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xb, yb, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, nullptr, nullptr, slot_a, stride, 4u);
+            if (f_free) (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xf, yf, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, dvn.x, dvn.y, nullptr, nullptr, slot_a, stride, 2u);
+            if (b_free) (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xb, yb, r_dx, r_dy, r_ddx, r_ddy, r_dot, tab, dvn.x, dvn.y, nullptr, nullptr, slot_a, stride, 4u);
 #pragma unroll
             for (int turn = 0; turn < 2; ++turn) {
                 const int dt = turn == 0 ? (d_new + 1 >= p.nd ? 0 : d_new + 1) : (d_new - 1 < 0 ? p.nd - 1 : d_new - 1);   // UT:13-14
                 const T* const tt = Real<T>::ray_table(p) + (size_t)dt * RCW_TABLE_ROWS * N;
-                spec_load_rows<T>(tt, tid, nthr, N, r_dx, r_dy, r_ddx, r_ddy, r_dot);
-                (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, x, y, r_dx, r_dy, r_ddx, r_ddy, r_dot, tt, nullptr, nullptr, slot_a, stride, turn == 0 ? 8u : 16u);
+                const vec2 dvt = Real<T>::dir_table(p)[dt];
+#ifdef RCW_DEV_SWITCHES
+                if (!(p.spec_debug & 8))                                    // (timing probe: the turns with the current heading's rows, no further table loads)
+#endif
+                spec_load_rows<T>(tt, tid, nthr, N, r_dx, r_dy);
+                spec_derive_rows<T>(dvt.x, dvt.y, r_dx, r_dy, r_ddx, r_ddy, r_dot);
+                (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, x, y, r_dx, r_dy, r_ddx, r_ddy, r_dot, tt, dvt.x, dvt.y, nullptr, nullptr, slot_a, stride, turn == 0 ? 8u : 16u);
             }
         } else {
             agent_sync<WAVE>();                                             // (every lane has read the tile bytes of the done state)
@@ -895,8 +946,10 @@ __device__ __forceinline__ void cast_body(const RcwDev& p, const uint8_t* __rest
             const T xr = s_pose[0], yr = s_pose[1];
             const int dr = __builtin_amdgcn_readfirstlane(s_pose_d);
             const T* const tt = Real<T>::ray_table(p) + (size_t)dr * RCW_TABLE_ROWS * N;
-            spec_load_rows<T>(tt, tid, nthr, N, r_dx, r_dy, r_ddx, r_ddy, r_dot);
-            (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xr, yr, r_dx, r_dy, r_ddx, r_ddy, r_dot, tt, nullptr, nullptr, slot_a, stride, 30u);
+            const vec2 dvr = Real<T>::dir_table(p)[dr];
+            spec_load_rows<T>(tt, tid, nthr, N, r_dx, r_dy);
+            spec_derive_rows<T>(dvr.x, dvr.y, r_dx, r_dy, r_ddx, r_ddy, r_dot);
+            (void)spec_fan<T, TIE_LE, DIST_PRE, false>(p, tb, tid, nthr, xr, yr, r_dx, r_dy, r_ddx, r_ddy, r_dot, tt, dvr.x, dvr.y, nullptr, nullptr, slot_a, stride, 30u);
         }
         if (left_the_map) { p.err[0] = RCW_ERR_OUT_OF_BOUNDS; p.status[a] = RCW_ERR_OUT_OF_BOUNDS; }   // (Julia: BoundsError in cast_ray)
         return;
@@ -1191,18 +1244,20 @@ __global__ __launch_bounds__(kBlock) void rcw_step256_kernel(const RcwDev p, con
 // act!(env, a) SR:333-340 orders dynamics -> cast_rays! -> update_camera_view!; as two kernels the cast (11 us at 4096 agents x
 // 256 columns, latency / issue bound) and a launch boundary sit in front of every fill.  But the frame of step t + 1 depends only on
 // (state_t, action_{t+1}) and there are four actions: the casting workgroups of launch t, once they have committed act!(world, a_t),
-// also cast the four successors of the new state into five slots of packed column words [5][B][N] (slot 0: the state itself — an
+// also cast the four successors of the new state into five slots of packed column words [B][5][N] (slot 0: the state itself — an
 // invalid action leaves the agent where it is; slots 1..4: the actions), and the fill workgroups of launch t + 1 only read the action
 // and pick the slot: action -> word -> colour, three dependent round trips a group like rcw_fill256_kernel's height -> colour id ->
 // colour (its pace: DESIGN.md §4.2).  Nothing in a launch waits for anything else in it — unlike rcw_step256_kernel above, whose
 // fill workgroups waited for the cast's flags and gained nothing.  Two slot buffers alternate: launch t reads the one launch t - 1
 // wrote and writes the other.  Workgroups 0 .. fill_blocks - 1 are the fill's (dispatched first, one per CU as in a launch of their
-// own); the casting workgroups — VALU / LDS work — run beside them under the HBM-bound sweep.  With fill_blocks = 0 the same kernel
-// PRIMES the slots behind a reset / set_state (or a first step) and the camera fill follows as a launch of its own.
+// own); the casting workgroups — VALU / LDS work — run beside them under the HBM-bound sweep.  rcw_cast_successors_kernel is the
+// casting half alone: it PRIMES the slots behind a reset / set_state (or a first step), the camera fill following as a launch of its own.
 template <bool PLAIN>
 __device__ __forceinline__ void fill256_spec_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint16_t* __restrict__ slots,
                                                   u32x4* __restrict__ out, long long total_cols, int block, int blocks, int n_shift)
 {
+    // (Raising the fill wavefronts' priority over the casting ones — s_setprio 3 — changes nothing: what the casting half costs this
+    // launch is its memory operations, not its issue slots: profiles/r06_step_forms.txt.)
     const int lane = threadIdx.x & 63;
     const long long G = (long long)blocks * (kBlock / 64);
     const long long g = (long long)block * (kBlock / 64) + (threadIdx.x >> 6);
@@ -1219,7 +1274,7 @@ __device__ __forceinline__ void fill256_spec_body(const RcwDev& p, const uint8_t
             const uint32_t act = actions[a];
             asm volatile("" :: "v"(act) : "memory");
             const uint32_t sel = act - 1u < (uint32_t)RCW_NUM_ACTIONS ? act : 0u;   // (an action outside 1..4: the agent is not stepped, SR:140)
-            const uint32_t w = slots[(size_t)sel * (size_t)total_cols + (size_t)mine];
+            const uint32_t w = slots[(size_t)mine + (size_t)(4u * a + sel) * (size_t)p.N];   // [B][5][N]: (5 a + sel) N + (mine - a N)
             asm volatile("" :: "v"(w) : "memory");
             pad_l = (int)(w & 0x1ffu);
             colour_l = p.colour[(w >> 9) & 3u];
@@ -1239,23 +1294,44 @@ __device__ __forceinline__ void fill256_spec_body(const RcwDev& p, const uint8_t
     }
 }
 
-// WAVE: a wavefront per agent, four agents a casting workgroup (at most 256 view columns: four a lane); else a workgroup per agent.
+// casting workgroup `block` of the launch.  WAVE: a wavefront per agent, four agents a casting workgroup (at most 256 view columns:
+// four a lane); else a workgroup per agent.
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
+__device__ __forceinline__ void cast_successors(const RcwDev& p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask, int block,
+                                                uint16_t* __restrict__ slots_out, uint32_t* lds, int lds_words, int cols)
+{
+    if (WAVE) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int a = block * (kBlock / 64) + wave;
+        if (a >= p.B) return;                                               // (wave-uniform: the batch's last workgroup may be short)
+        cast_body<T, TIE_LE, DIST_PRE, true, false, true>(p, actions, mask, a, (int)(threadIdx.x & 63u), 64, lds + (size_t)wave * lds_words, a, slots_out, cols);
+    } else {
+        cast_body<T, TIE_LE, DIST_PRE, false, false, true>(p, actions, mask, block, (int)threadIdx.x, kBlock, lds, block, slots_out, cols);
+    }
+}
+
 template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
 __global__ __launch_bounds__(kBlock) void rcw_fill256_cast_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
                                                                   u32x4* __restrict__ out, long long total_cols, int fill_blocks,
-                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift)
+                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift, int cols)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+#ifdef RCW_DEV_SWITCHES
+    if (p.spec_debug & ((int)blockIdx.x < fill_blocks ? 2 : 1)) return;     // (timing probes: one half of the launch alone)
+#endif
     if ((int)blockIdx.x < fill_blocks) { fill256_spec_body<false>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift); return; }
-    if (WAVE) {
-        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int a = ((int)blockIdx.x - fill_blocks) * (kBlock / 64) + wave;
-        if (a >= p.B) return;                                               // (wave-uniform: the batch's last workgroup may be short)
-        cast_body<T, TIE_LE, DIST_PRE, true, false, true>(p, actions, mask, a, (int)(threadIdx.x & 63u), 64, lds + (size_t)wave * lds_words, a, slots_out);
-    } else {
-        const int a = (int)blockIdx.x - fill_blocks;
-        cast_body<T, TIE_LE, DIST_PRE, false, false, true>(p, actions, mask, a, (int)threadIdx.x, kBlock, lds, a, slots_out);
-    }
+    cast_successors<T, TIE_LE, DIST_PRE, WAVE>(p, actions, mask, (int)blockIdx.x - fill_blocks, slots_out, lds, lds_words, cols);
+}
+
+// The casting workgroups alone, under a name of their own (profiles tell a step from what primes its slots): behind rcw_reset /
+// rcw_set_state — no action, maybe a mask: masked-out agents keep their slots — or for a first step; the camera fill follows as a launch
+// of its own, from the descriptors.
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
+__global__ __launch_bounds__(kBlock) void rcw_cast_successors_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
+                                                                     uint16_t* __restrict__ slots_out, int lds_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    cast_successors<T, TIE_LE, DIST_PRE, WAVE>(p, actions, mask, (int)blockIdx.x, slots_out, lds, lds_words, 1);
 }
 
 // The same moving window for the camera heights that tile a 1 KiB chunk evenly: H_cam = 256·k (a chunk is one of
@@ -3920,21 +3996,27 @@ int rcw_step_spec_eligible(const RcwDev& p)
 }
 size_t rcw_step_spec_slot_bytes(const RcwDev& p) { return (size_t)5 * (size_t)p.B * (size_t)p.N * sizeof(uint16_t); }
 hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, const uint16_t* slots_in,
-                                uint16_t* slots_out, bool with_fill, hipStream_t s)
+                                uint16_t* slots_out, bool with_fill, bool cols, hipStream_t s)
 {
+    const int icols = cols ? 1 : 0;
     const size_t per_agent = (rcw_cast_lds_bytes(p) + 15) & ~(size_t)15;
     const int fill_blocks = with_fill ? p.fill_grid : 0;
     const long long total_cols = (long long)p.B * p.N;
     u32x4* const out = reinterpret_cast<u32x4*>(p.obs);
     int n_shift = -1;
     for (int k = 0; k < 31; ++k) if (p.N == (1 << k)) n_shift = k;
-    if (p.N <= 64 * kCastCols) {                                            // a wavefront per agent
-        const int cast_blocks = (p.B + kBlock / 64 - 1) / (kBlock / 64);
-        RCW_DISPATCH_W(rcw_fill256_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), (kBlock / 64) * per_agent, p, actions_dev, mask_dev,
-                       out, total_cols, fill_blocks, slots_in, slots_out, (int)(per_agent / 4), n_shift);
+    const bool wave = p.N <= 64 * kCastCols;                                // a wavefront per agent
+    const int cast_blocks = wave ? (p.B + kBlock / 64 - 1) / (kBlock / 64) : p.B;
+    const size_t lds = wave ? (kBlock / 64) * per_agent : per_agent;
+    const int lds_words = (int)(per_agent / 4);
+    if (with_fill) {
+        if (wave) RCW_DISPATCH_W(rcw_fill256_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
+                                 out, total_cols, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols);
+        else      RCW_DISPATCH_W(rcw_fill256_cast_kernel, false, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
+                                 out, total_cols, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols);
     } else {
-        RCW_DISPATCH_W(rcw_fill256_cast_kernel, false, dim3(fill_blocks + p.B), dim3(kBlock), per_agent, p, actions_dev, mask_dev,
-                       out, total_cols, fill_blocks, slots_in, slots_out, (int)(per_agent / 4), n_shift);
+        if (wave) RCW_DISPATCH_W(rcw_cast_successors_kernel, true, dim3(cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev, slots_out, lds_words);
+        else      RCW_DISPATCH_W(rcw_cast_successors_kernel, false, dim3(cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev, slots_out, lds_words);
     }
     return hipGetLastError();
 }

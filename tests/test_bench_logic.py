@@ -94,7 +94,7 @@ def test_no_collective_inside_the_timed_regions():
         region = src[a:b]
         for word in ("barrier(", "all_reduce", "all_gather", "gather_rows", "dist."):
             assert word not in region, (word, start)
-        assert "torch.cuda.synchronize()" in region                  # the rank's own synchronisation is inside
+        assert "rt.synchronize()" in region                          # the rank's own synchronisation is inside (Runtime.synchronize = torch.cuda.synchronize)
         assert "barrier()" in src[b:b + 400]                          # ... and the barrier right behind the stop
     warm = src.index("gather_rows([0.0])")
     assert warm < src.index("t0 = time.perf_counter()", warm) < src.index("dt = time.perf_counter() - t0  # this rank's own clock")
@@ -106,3 +106,34 @@ def test_top_view_scratch_bytes_of_the_fused_launch():
     bench = _bench()
     assert bench.top_view_scratch_bytes(8, 8, 32, 4096) == 4096 * (8192 + 8 + 64)
     assert bench.top_view_scratch_bytes(8, 16, 32, 1) == 256 * 512 // 8 + 8 + 8 * 16
+
+
+def test_the_multi_rank_control_flow_runs_on_doubles(tmp_path):
+    """bench.py's N > 1 path has only ever run over gloo and a stand-in; its first run over RCCL is the
+    driver's.  tests/bench_double.py runs main() itself — rank 0 of a world of 2 — with doubles for torch.distributed and the engine:
+    the `dist` refuses any all_gather_into_tensor whose output is not the concatenation of `world` inputs along dim 0 with the same
+    dtype, device and contiguity (the rule RCCL and gloo share; round 5's first gather_rows broke it and only a GPU rehearsal caught
+    it), counts barriers, and the engine records its calls.  The line must come out whole: n_gpus 2, the slowest rank's clock, both
+    ranks in per_rank, the gather block without an error, and — new in round 6 — rank 0's cpu_baseline at N > 1 and a traffic figure
+    that is either null or says it was not re-measured at this N."""
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK",)}
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", BENCH_DOUBLE_LOG=str(tmp_path / "calls.json"))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_double.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--batch", "8", "--cpu-baseline-seconds", "0.3", "--api", "rlbase"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6 / 1e3)) < 1e-6 * d["value"]
+    assert d["ms_per_step"] == d["ms_per_step_max"] >= d["ms_per_step_min"] > 0
+    assert [r["rank"] for r in d["roofline"]["per_rank"]] == [0, 1]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "caches" in d["cpu_baseline"]["sample"]
+    assert d["roofline"]["traffic"] is None or "not re-measured" in d["roofline"]["traffic_source"]
+    assert "error" not in d["gather"], d["gather"]
+    assert d["gather"]["ranks"] == 2 and d["api_loop"]["host_syncs_per_step"] == 0
+    calls = json.load(open(tmp_path / "calls.json"))
+    assert calls["all_gather"] >= 4 and calls["barrier"] >= 4 and calls["destroyed"] == 1
+    assert calls["steps"] == 2 + 6 + 6 + 2 + 6                       # warm-up + timed + per-kernel events + the API loop's two
+    assert calls["collectives_inside_timed_regions"] == 0

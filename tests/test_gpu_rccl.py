@@ -129,13 +129,15 @@ def test_bench_rehearsal_with_four_ranks(rcw, tmp_path):
         env.pop(k, None)
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2",
-                          "--rehearse-on-one-gpu"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "--rehearse-on-one-gpu", "--cpu-baseline-seconds", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + "\n" + res.stderr[-6000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout[-3000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 4 * 4096 and out["steps"] == 5 and out["scaling"] == "weak"
-    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out          # rank 0 at N = 1 only
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0               # rank 0's, at any N (round 6)
+    assert out["roofline"]["traffic"] is None or "not re-measured" in out["roofline"]["traffic_source"]
     # every rank's own clock, reduced afterwards: the slowest rank is the job's time, the spread and every rank's fill-kernel
     # launch time are in the line
     assert out["ms_per_step"] == out["ms_per_step_max"] >= out["ms_per_step_min"] > 0 and "no collective inside the timed region" in out["timing"]

@@ -63,6 +63,9 @@ def test_the_case_lists_cover_every_shipped_instantiation_of_the_flat_kernels():
     assert not [n for n in names if re.match(r"rcw_(fill256|top_store|top_store_units)_kernel<true", n)], names
     assert "rcw_top_store_units_kernel<false, 2>" not in names
     assert not [n for n in names if re.match(r"rcw_fill_flat_kernel<\w+, \d+, true>", n)], names
+    # the step's kernels: <T, TIE, DIST> of the cast kernel, <T, TIE, DIST, WAVE> of the one-launch step and of what primes its slots
+    for family, count in (("rcw_cast_kernel<", 8), ("rcw_fill256_cast_kernel<", 16), ("rcw_cast_successors_kernel<", 16)):
+        assert len([n for n in names if n.startswith(family)]) == count, (family, sorted(n for n in names if n.startswith(family)))
 
 
 def _steps(rcw, env, orc, rng, n, top):
@@ -150,6 +153,28 @@ def test_top_view_forms_under_every_unpinned_switch(rcw, oracle, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", ["Float32", "Float64"])
+def test_step_kernels_under_every_unpinned_switch(rcw, oracle, T):
+    """<T, TIE, DIST> of rcw_cast_kernel (the two-launch step) and <T, TIE, DIST, WAVE> of rcw_fill256_cast_kernel / rcw_cast_successors_kernel
+    (the one-launch step and what primes its slots; WAVE: a wavefront per agent up to 256 view columns, a workgroup per agent beyond): all four
+    settings of the two unpinned cast_ray switches, both casting shapes, both forms, a masked reset in between, auto_reset on."""
+    rng = np.random.default_rng(12)
+    for tie in (0, 1):
+        for dist in (0, 1):
+            for N in (96, 300):
+                for form in ("one-launch", "two-launches"):
+                    env, orc = _make(rcw, oracle, 7, 18, T=T, auto_reset=True, out_of_bounds=1, dda_tie_break=tie, dda_distance=dist,
+                                     height_tile_map_tu=7, width_tile_map_tu=9, num_rays=N)
+                    env.set_step_form(form)
+                    assert env.step_form() == form
+                    _steps(rcw, env, orc, rng, 5, False)
+                    mask = np.array([1, 0, 1, 1, 0, 0, 1], dtype=np.uint8)
+                    rcw.reset_(env, mask=mask, seed=8); orc.reset(mask=mask, seed=8)
+                    _steps(rcw, env, orc, rng, 4, False)
+                    env.close()
+
+
+@pytest.mark.gpu
 def test_top_view_planner_sweep(rcw, oracle):
     """Every pixel scale from 8 to 40 on maps of 3, 4, 5, 7, 8 and 10 tile rows (198 geometries; whatever form the library's rule picks for each —
     in-place, one kernel, units, flat, 256-row chunks — and the fused or side-stream drawing): two steps and a stand-alone redraw
@@ -182,7 +207,7 @@ def test_camera_height_sweep(rcw, oracle):
         rcw.reset_(env, mask=mask, seed=6); orc.reset(mask=mask, seed=6)
         _steps(rcw, env, orc, rng, 1, False)
         env.close()
-    assert set(names) == {"rcw_fill_frame_kernel", "rcw_fill_flat_kernel", "rcw_fill_window_kernel", "rcw_fill256_kernel"}, names
+    assert set(names) == {"rcw_fill_frame_kernel", "rcw_fill_flat_kernel", "rcw_fill_window_kernel", "rcw_fill256_cast_kernel"}, names   # (256 rows: the one-launch step)
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): stateful fuzzing of the host API.  Random SEQUENCES of calls — steps with host / device / scalar
 actions, masked and full resets, injected states, rejected actions, another stream, another output buffer
-(rcw_bind_obs), another top-view form, stand-alone re-renders, ray materialisation, descriptor expansion, profiling
+(rcw_bind_obs), another top-view form, another form of the step (one launch / two launches), stand-alone re-renders, ray materialisation, descriptor expansion, profiling
 on / off — against the CPU oracle driven by the same sequence; every observable is compared after every call.
 
     python tools/api_fuzz.py [runs] [seed] [ops per run] [sharded|pairs]
@@ -53,10 +53,15 @@ GEOMETRIES = (
     dict(height_tile_map_tu=9, width_tile_map_tu=11, num_rays=150, height_camera_view_pu=250),
     dict(height_tile_map_tu=4, width_tile_map_tu=20, num_rays=64, height_camera_view_pu=24, player_radius_wu=0.3, position_increment_wu=0.2),
     dict(height_tile_map_tu=32, width_tile_map_tu=32, num_rays=64, height_camera_view_pu=128),
+    # 256-row camera views: without a top view these take the one-launch step (a wavefront per agent / a workgroup per agent / the table's tail)
+    dict(height_tile_map_tu=7, width_tile_map_tu=9, num_rays=300),
+    dict(height_tile_map_tu=16, width_tile_map_tu=16, num_rays=512),
+    dict(height_tile_map_tu=6, width_tile_map_tu=6, num_rays=1100, num_directions=32),
+    dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=200, num_directions=96),
 )
 counts = {}
 OPS = ["act_host", "act_host", "act_device", "act_device", "act_scalar", "reset_mask", "reset_all", "reset_rng", "set_state", "bad_action", "stream",
-       "bind_obs", "form", "rerender", "rays", "expand", "profile"] + (["gather_columns", "gather_columns_abi", "gather_obs", "gather_obs_abi"] * 2 if SHARDED else [])
+       "bind_obs", "form", "step_form", "step_form", "rerender", "rays", "expand", "profile"] + (["gather_columns", "gather_columns_abi", "gather_obs", "gather_obs_abi"] * 2 if SHARDED else [])
 
 
 class Ctx:
@@ -146,7 +151,7 @@ class Ctx:
             same = (tile == goal).all(axis=1)                # the player never starts on the goal tile (SR:124)
             tile[same, 0] = np.where(goal[same, 0] > 2, goal[same, 0] - 1, goal[same, 0] + 1)
             pos = (tile - 0.5).astype(np.float64 if kw.get("T") == "Float64" else np.float32)
-            d = rng.integers(0, 128, B).astype(np.int32)
+            d = rng.integers(0, kw.get("num_directions", 128), B).astype(np.int32)
             mask = (rng.random(B) < 0.6).astype(np.uint8) if rng.integers(0, 2) else None
             self.last = dict(op=op, mask=None if mask is None else mask.tolist())
             env.set_state(goal, pos, d, mask=mask)
@@ -185,6 +190,12 @@ class Ctx:
             except (RuntimeError, ValueError, AssertionError, NotImplementedError):
                 pass                                         # (a form this geometry cannot take is refused, nothing changes)
             RCW.update_top_view_(env)
+        elif op == "step_form":
+            form = [None, "one-launch", "two-launches"][int(rng.integers(0, 3))]
+            try:
+                env.set_step_form(form)
+            except RuntimeError:
+                assert form == "one-launch" and (top or Hc != 256), (form, top, Hc)   # (refused where the geometry cannot take it: nothing changes)
         elif op == "rerender":
             RCW.update_camera_view_(env)
             if top:
