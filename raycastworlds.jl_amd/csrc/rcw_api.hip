@@ -137,29 +137,7 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         return between(h->stream);
     }
 #ifdef RCW_DEV_SWITCHES
-    // Development experiment (RCW_TOP_FOLLOW = 1 inside a step | 2 alone; measured slower, docs/experiments.md): the store kernel FOLLOWS
-    // the draw kernel where that is safe (rcw_kernels.hip, top_publish): an unmasked whole batch, the two
-    // kernels' workgroups fitting on a CU together (d.top_follow_ok), and no stream capture (a graph would replay this call's number,
-    // and promises no concurrency between its branches).  The draw kernel goes to the side stream, the store kernel to the handle's
-    // WITHOUT waiting for it — agent by agent it waits in memory —, and the handle's stream joins the side stream behind it.
-    bool follow = mask_dev == nullptr && (d.top_follow_ok & (beside ? 1 : 2)) != 0 && !(beside && d.top_fused);
-    if (follow) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) follow = false;
-    }
-    if (follow) {
-        RcwDev dd = d;
-        dd.top_epoch = ++h->top_epoch;                       // (the counters wrap with it: the comparison is modulo 2^32)
-        dd.top_signal = 1; dd.top_follow = 1;
-        if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
-        e = rcw_launch_top_draw(dd, nullptr, 0, d.B, h->top_stream, beside ? 0 : d.top_draw_block_alone);
-        const hipError_t rec = hipEventRecord(h->ev_top_join[0], h->top_stream);
-        if (e == hipSuccess) e = between(h->stream);
-        if (e == hipSuccess) e = rcw_launch_top_store(dd, nullptr, 0, d.B, h->stream);
-        if (rec == hipSuccess) { const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[0], 0); if (e == hipSuccess) e = w; }
-        return e == hipSuccess ? rec : e;
-    }
+#include "dev/api_top_follow.inc"   // RCW_TOP_FOLLOW, the launch order in which the store kernel follows the draw kernel
 #endif
     if (!beside) {                                           // stand-alone, two kernels back to back on the handle's stream
         if ((e = rcw_launch_top_draw(d, mask_dev, 0, d.B, h->stream, d.top_draw_block_alone)) != hipSuccess) return e;
@@ -260,27 +238,7 @@ hipError_t launch_step(rcw_handle* h, const uint8_t* actions_dev, const uint8_t*
         return hipSuccess;
     }
 #ifdef RCW_DEV_SWITCHES
-    if (h->step_pieces == 2 && !d.top_view && h->top_stream && d.B >= 2) {
-        // Development experiment (RCW_STEP_PIECES=2, docs/experiments.md): the batch in two halves, the second half's cast kernel on
-        // the side stream BESIDE the first half's fill: cast(1) | fork | fill(1) ∥ cast(2) | join | fill(2).
-        const int B1 = d.B / 2, B2 = d.B - B1;
-        const long long cols1 = (long long)B1 * d.N;
-        if ((e = rcw_launch_cast(d, actions_dev, mask_dev, h->stream, 0, B1)) != hipSuccess) return e;
-        if ((e = hipEventRecord(h->ev_top_fork, h->stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(h->top_stream, h->ev_top_fork, 0)) != hipSuccess) return e;
-        e = rcw_launch_cast(d, actions_dev, mask_dev, h->top_stream, B1, B2);
-        const hipError_t rec = hipEventRecord(h->ev_top_join[0], h->top_stream);
-        if (prof && e == hipSuccess) e = hipEventRecord(ev[1], h->stream);
-        if (prof && e == hipSuccess) e = hipEventRecord(ev[2], h->stream);
-        if (e == hipSuccess) e = rcw_launch_fill(d, d.col_h, d.col_c, d.obs, cols1, mask_dev, h->stream);
-        if (rec == hipSuccess) { const hipError_t w = hipStreamWaitEvent(h->stream, h->ev_top_join[0], 0); if (e == hipSuccess) e = w; }
-        if (e == hipSuccess) e = rec;
-        if (e == hipSuccess)
-            e = rcw_launch_fill(d, d.col_h + cols1, d.col_c + cols1, d.obs + cols1 * d.Hc, (long long)B2 * d.N, mask_dev ? mask_dev + B1 : nullptr, h->stream);
-        if (e != hipSuccess) return e;
-        if (prof) { if ((e = hipEventRecord(ev[3], h->stream)) != hipSuccess) return e; h->prof_count++; }
-        return hipSuccess;
-    }
+#include "dev/api_step_pieces.inc"   // RCW_STEP_PIECES=2, the batch in two halves with the second cast beside the first fill
 #endif
 #ifdef RCW_DEV_SWITCHES
     if (d.step_fused && rcw_step_fusable(d)) {

@@ -128,6 +128,7 @@ int rcw_top_flat_cols(const RcwDev& p);    // rcw_top_store_flat_kernel: columns
 int32_t rcw_top_plane_words(const RcwDev& p);
 int rcw_fill_flat_cols(const RcwDev& p);   // rcw_fill_flat_kernel: columns a chunk may touch at this camera height, 0: not taken
 const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // the kernel rcw_launch_fill takes
+int rcw_fill_takes_256(const RcwDev& p, long long total_cols);              // ... is rcw_fill256_kernel (what the fused launches build on)
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
 int rcw_top_draw_per_cu(const RcwDev& p, int draw_block);   // draw workgroups resident on a CU together

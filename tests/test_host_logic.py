@@ -100,7 +100,7 @@ def test_frame_dump_matches_the_reference_blit(rcw, oracle, tmp_path):
 
 
 def test_line_closed_form_equals_the_error_term_walk():
-    """The write-once top view kernel (rcw_kernels.hip, top_draw) steps a line with the remainder of
+    """The write-once top view kernel (rcw_top_draw.hip, top_draw) steps a line with the remainder of
     floor((2 b k + a) / (2 a)) instead of the error term of SD.Line as the oracle restates it (sd_line in
     oracle/rcw_oracle.c).  Exhaustive check that both visit the same pixels, for every end point within +-48 px."""
     def error_term_walk(i2, j2):
@@ -189,7 +189,7 @@ def test_frame_buffer_blit_is_the_reference_transpose(rcw):
 
 
 def _fast_div(n, d):
-    """rcw_kernels.hip `fast_div`, operation for operation in Float32 / int32 (numpy, vectorised over n)."""
+    """rcw_device.h `fast_div`, operation for operation in Float32 / int32 (numpy, vectorised over n)."""
     inv = np.float32(1.0) / np.float32(d)
     q = (n.astype(np.float32) * inv).astype(np.int64)          # v_cvt_f32_i32, v_mul_f32, v_cvt_i32_f32 (truncation)
     q = q - (q * d > n)
@@ -248,10 +248,10 @@ def test_flat_plane_layout_makes_chunks_whole_words():
 
 
 def test_flat_store_kernel_reads_stay_inside_their_allocations():
-    """rcw_top_store_flat_kernel's loads are CLAMPED into their arrays, not predicated (rcw_kernels.hip, `issue`), and two of
+    """rcw_top_store_flat_kernel's loads are CLAMPED into their arrays, not predicated (rcw_top_store.hip, `issue`), and two of
     them reach past the element they name: three tile_map words from any word of a map (12-byte load), eight plane words
     from a chunk's first word (two 16-byte loads).  Restated here with the allocation sizes of rcw_api.hip /
-    rcw_kernels.hip — tile_map: B * nwords words + 16 bytes; top_plane: B * PW words + 64 bytes, PW = ((Ht Wt + 510) div
+    rcw_api.hip — tile_map: B * nwords words + 16 bytes; top_plane: B * PW words + 64 bytes, PW = ((Ht Wt + 510) div
     256) * 8 — and checked for the EXTREME addresses over geometries whose images are not a whole number of chunks
     (profiles/r04_exp5_fault.txt: one of the three candidate causes of round 3's unexplained memory access fault)."""
     rng = np.random.default_rng(4)
@@ -600,7 +600,7 @@ print("ok")
 def test_turning_chunk_assignment_replayed_against_plain_division():
     """rcw_top_store_flat_kernel's wavefront -> chunk assignment TURNS from group to group (slot (g + k R) mod G of
     group k) and carries every lane's (agent, image column, row) from group to group with two step sets — (dq, dr) and, where the
-    slot wraps past G, (dq_w, dr_w) — instead of dividing.  Replayed here statement by statement (rcw_kernels.hip, `issue` and the
+    slot wraps past G, (dq_w, dr_w) — instead of dividing.  Replayed here statement by statement (rcw_top_store.hip, `issue` and the
     main loop) for random grids, turns, image shapes and chunk ranges, including a short last group and turns >= G: every carried
     value equals the plain division of the chunk's first pixel, every chunk of the range is taken exactly once, and everything
     stays inside 32 bits."""
@@ -675,7 +675,7 @@ def _line_geom(key, ip, jp):
 
 
 def _covered_prefix(key, key_lo, key_hi, ip, jp, exact=False):
-    """rcw_kernels.hip::top_covered_prefix, statement by statement (`exact`: the last division exactly instead of its low estimate)."""
+    """rcw_top_draw.hip::top_covered_prefix, statement by statement (`exact`: the last division exactly instead of its low estimate)."""
     NO = 0xFFFFFFFF
     if key_lo == NO or key_hi == NO:
         return 0
@@ -716,7 +716,7 @@ def _line_pixels(ip, jp, key, first=0):
 
 def test_draw_kernel_leaves_out_only_pixels_that_other_lines_draw(oracle):
     """Round 5: the top view's draw kernel does not walk the leading pixels of a ray's line that the rays 2^t before and behind it
-    in the fan draw anyway (rcw_kernels.hip::top_covered_prefix, and the class-by-class list in top_draw_body) — EXACTLY: the union
+    in the fan draw anyway (rcw_top_draw.hip::top_covered_prefix, and the class-by-class list in top_draw_body) — EXACTLY: the union
     of what is still walked equals the union of all lines.  Replayed here on the rays of real agents (the oracle's end points, several
     map / pixel-scale / ray-count shapes, incl. fans across an axis and rays that end in the same pixel), with the kernel's low
     Float32 estimate of the one division and with the exact quotient; and the estimate never exceeds the exact quotient."""

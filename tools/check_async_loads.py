@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build check for the store kernels' descriptor prefetch (flat_load_* / flat_wait_loads in rcw_kernels.hip).
+"""Build check for the store kernels' descriptor prefetch (flat_load_* / flat_wait_loads in rcw_top_store.hip).
 
 Those global loads are issued in inline asm so that the compiler does not track their completion; the price is that
 nothing but the hardware may touch a destination register between the load and the `s_waitcnt vmcnt` that awaits it.

@@ -41,7 +41,7 @@ for rep in range(reps):
     for _ in range(4):
         RCW.act_(env, a)
     env.sync()
-    assert env._lib.rcw_wave_trace_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert (env._lib.rcw_top_store_trace_read if TOP else env._lib.rcw_wave_trace_read)(buf.ctypes.data_as(ctypes.c_void_p)) == 0   # (each translation unit has its own trace array)
     t = buf.reshape(1024, 20, 2).astype(np.int64)
     ng = int(min(16, (t[:, :18, 0] > 0).sum(axis=1).min()))      # groups every wavefront traced (16 at 1 GiB; fewer for smaller batches)
     t0, t1, tend, hw = t[:, :ng, 0], t[:, :ng, 1], t[:, 19, 0], t[:, 18, 0]
