@@ -8,7 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    cmd = ["make", "-C", os.path.join(_PKG, "csrc")]
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), f"-j{min(8, os.cpu_count() or 1)}"]   # (a translation unit per group of kernels: they compile side by side)
     if force:
         cmd.append("-B")
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -65,6 +65,7 @@ extern "C" __attribute__((visibility("default"))) int rcw_dev_fail_sites(unsigne
 struct rcw_handle {
     rcw_config cfg{};
     int32_t B = 0, device = 0, nchunks = 0, num_cus = 256;
+    RcwHw hw{256, 160 * 1024, 32};     // the device's CUs, LDS bytes and wavefront slots a CU (hipDeviceProp_t: rcw_create)
     RcwDev dev{};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -387,41 +388,92 @@ int upload_tables(rcw_handle* h)
 #define RCW_DEV_ENV(name) (static_cast<const char*>(nullptr))
 #endif
 
-// Which form update_top_view! (SR:446-483) takes for this handle, and its scratch in HBM.  want_form: 0 = the rule below,
-// or one of RCW_TOP_VIEW_IN_PLACE / ONE_KERNEL / TWO_KERNELS (rcw_set_top_view_form); want_runs: 0 = the rule, or 1..8.
-// `lenient`: a form the geometry cannot take falls back to the rule (development switches) instead of failing.
-int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
+// The geometry of a batch as the kernels' argument block holds it: what the launchers' and the top view's rules read (rcw_create; the
+// development build's rcw_dev_plan_top_view, which runs the rule without a device).
+void set_geometry(RcwDev& d, const rcw_config* cfg, int32_t batch)
 {
-    RcwDev& d = h->dev;
-    const rcw_config* cfg = &h->cfg;
+    d.B = batch; d.H = cfg->height_tile_map_tu; d.W = cfg->width_tile_map_tu; d.N = cfg->num_rays; d.nd = cfg->num_directions; d.Hc = cfg->height_camera_view_pu;
+    d.real64 = cfg->world_unit_bits == 64 ? 1 : 0;
+    d.pu = cfg->pu_per_tu;
+    // player_radius_pu = wu_to_pu(player_radius_wu, pu_per_tu) SR:469 = floor(Int, r * pu) + 1 in T (UT:6)
+    d.top_rp = d.real64 ? (int32_t)std::floor(cfg->player_radius_wu_f64 * (double)cfg->pu_per_tu) + 1
+                        : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
+}
+
+// ---- update_top_view! (SR:446-483): which form a handle takes — the RULES AS DATA ------------------------------------------------------
+// Every threshold the choice of a form rests on, with the measurement that put it there.  The rule itself (top_view_rule below) is a pure
+// function of the configuration, the batch and three numbers of the device (CUs, LDS and wavefronts a CU: rcw_create reads them from
+// hipDeviceProp_t); tests/test_top_view_plan.py runs it on the CPU (development build: rcw_dev_plan_top_view) for every shape of the
+// committed profile table and compares with tests/golden/top_view_plan_cases.json — the forms those profiles were taken with.  A retune
+// on another box is an edit of this table, a re-run of tools/top_view_shapes.py and of tools/make_top_view_plan_cases.py; a change of a
+// rule by accident is a red test.
+struct TopRule { const char* name; double value; const char* unit; const char* evidence; };
+enum TopRuleId {
+    kRingThreeBuffersLds, kRingLdsCap, kRingWorkgroupsPerCu, kLineWalkMaxPixels, kAloneTwoKernelsPixels, kAloneTwoKernelsBelowPu,
+    kDrawWideBlockLds, kDrawBlockMin, kDrawBlockMax, kAloneBlock64Agents, kAloneBlock128Agents, kRunsLineToCameraNum, kRunsLineToCameraDen,
+    kRuns4Gib, kRuns2Gib, kSideStreamMinBytes, kPartsMax, kPartsMinRays, kFillGBperMs, kFillLateStartUs, kDrawUsPerGibFewRays,
+    kDrawUsPerGibManyRays, kDrawManyRays, kDrawPartialRound, kDrawLdsCap, kFillWavefrontsPerCu, kTopRuleCount
+};
+constexpr TopRule kTopRules[kTopRuleCount] = {
+    /* kRingThreeBuffersLds   */ {"ring_three_buffers_max_lds", 52 * 1024, "B", "profiles/r02_top_view_summary.txt: three workgroups of 8 wavefronts a CU still fit beside each other up to 52 KiB of ring each"},
+    /* kRingLdsCap            */ {"ring_lds_cap", 156 * 1024, "B", "the CU's 160 KiB less what the kernel's static words and the runtime keep: beyond it the in-place form (profiles/r02_top_draw_lds.txt)"},
+    /* kRingWorkgroupsPerCu   */ {"ring_workgroups_per_cu_max", 3, "", "profiles/r02_top_view_summary.txt: 3 x 8 wavefronts is what the ring kernel's register use admits; 4 measured no faster"},
+    /* kLineWalkMaxPixels     */ {"line_walk_max_pixels", 16384, "px", "exactness, not tuning: the bit-plane kernels step a line on the carry of a 32-bit fraction, exact for lines of up to 2^14 pixels (tests/test_host_logic.py)"},
+    /* kAloneTwoKernelsPixels */ {"stand_alone_two_kernels_from_pixels", 65536, "px", "profiles/r05_top_view_shapes.txt (b): draw -> store back to back 217 / 224 / 198 / 210 / 218 us/GiB against 214 / 231 / 228 / 253 / 360 for the ring from 256^2 px up"},
+    /* kAloneTwoKernelsBelowPu*/ {"stand_alone_two_kernels_below_pu", 16, "px/tile", "profiles/r05_top_view_shapes.txt (b): 10 / 13 px a tile 360 / 302 against 507 / 450, 12 px 310 against 347; the ring keeps 16, 20, 24 ... px below 256^2 (264 / 228 / 229 against 268 / 246 / 233)"},
+    /* kDrawWideBlockLds      */ {"draw_wide_block_from_plane_lds", 64 * 1024, "B", "profiles/r04_top_view_small_batches.txt, r03_top_view_shapes.txt: planes beyond 64 KiB leave one or two workgroups a CU: 512^2 px 180 / 182 / 200, 768^2 212 / 200 / 203, 1024^2 357 / 265 / 216 us with 256 / 512 / 1024 threads"},
+    /* kDrawBlockMin          */ {"draw_wide_block_min_threads", 512, "threads", "same measurement"},
+    /* kDrawBlockMax          */ {"draw_wide_block_max_threads", 1024, "threads", "same measurement (a lane per ray up to 1024 rays)"},
+    /* kAloneBlock64Agents    */ {"stand_alone_64_threads_from_agents", 24576, "agents", "profiles/r05_draw_kernel.txt: 41,943 images of 80^2 px 175 us with 64 threads against 193 with 256"},
+    /* kAloneBlock128Agents   */ {"stand_alone_128_threads_from_agents", 12288, "agents", "profiles/r05_draw_kernel.txt: 16,384 images of 128^2 px 103 us with 128 threads against 109"},
+    /* kRunsLineToCameraNum   */ {"runs_when_lines_to_camera_num", 7, "", "profiles/r03_top_view_shapes.txt: (H + W) pu / 2 >= 1.75 H_cam, i.e. 2 (H + W) pu >= 7 H_cam: the drawing no longer fits beside the camera fill"},
+    /* kRunsLineToCameraDen   */ {"runs_when_lines_to_camera_den", 2, "", "same rule's left-hand factor"},
+    /* kRuns4Gib              */ {"four_runs_from_gib", 4, "GiB", "profiles/r03_top_view_shapes.txt: 16 GiB of top view 4516 / 4409 / 4332 / 4294 us with 1 / 2 / 4 / 8 runs, 32 GiB 8586 / 8459 / 7658 / 8068"},
+    /* kRuns2Gib              */ {"two_runs_from_gib", 2, "GiB", "same table; runs of 256 MiB do not pay (205 vs 181 us at 1 GiB of 512^2 px images)"},
+    /* kSideStreamMinBytes    */ {"side_stream_form_from_bytes", 256.0 * 1048576.0, "B", "profiles/r04_top_view_small_batches.txt: the fork / join and the extra launch cost ~13 us a step (39 / 51 / 53 / 60 / 102 / 341 us against the ring's 36 / 38 / 41 / 47 / 103 / 387 at 1 .. 4096 agents)"},
+    /* kPartsMax              */ {"draw_parts_max", 4, "workgroups", "profiles/r05_draw_kernel.txt (tools/r05_draw_parts.sh): 1024^2 px x 64 agents 53.6 / 38.6 / 30.5 us with 1 / 2 / 4 parts"},
+    /* kPartsMinRays          */ {"draw_part_min_rays", 128, "rays", "same table: a part's fixed costs (plane cleared, every end point, plane scanned) are most of a workgroup's life; x 256 agents 61.4 / 78.7 / 110"},
+    /* kFillGBperMs           */ {"camera_fill_rate", 6.5e6, "B/us", "profiles/r05_kernel_stats.csv: rcw_fill256_kernel 156 us a GiB = 6.88 TB/s; 6.5 with its smaller siblings"},
+    /* kFillLateStartUs       */ {"side_stream_late_start", 12, "us", "profiles/r05_top_view_shapes.txt / tools/step_timeline.sh: a kernel behind an event of the other stream starts ~13 us later than behind a kernel of its own (19 against 6 us after the cast kernel's end)"},
+    /* kDrawUsPerGibFewRays   */ {"draw_floor_few_rays", 34, "us/GiB", "profiles/r05_draw_kernel.txt, r05_top_view_shapes.txt (a): the draw kernel's floor per GiB of top view with up to 256 rays (768^2 px x 455: 37 us)"},
+    /* kDrawUsPerGibManyRays  */ {"draw_floor_many_rays", 55, "us/GiB", "same: beyond 256 rays (1024^2 px x 256, 1024 rays: 58-61 us)"},
+    /* kDrawManyRays          */ {"draw_many_rays_from", 257, "rays", "the boundary between the two floors above"},
+    /* kDrawPartialRound      */ {"draw_partial_round", 0.7, "", "profiles/r05_draw_kernel.txt (tools/r05_draw_first.sh): a partial round of draw workgroups takes about as long as a full one (768^2 px x 114 / 228 / 341 agents 90 -> 75, 129 -> 115, 169 -> 155 us)"},
+    /* kDrawLdsCap            */ {"draw_kernel_lds_cap", 159 * 1024, "B", "rcw_top_split_unit / rcw_top_flat_cols: the draw kernel's plane + ray lists within the CU's LDS less 1 KiB"},
+    /* kFillWavefrontsPerCu   */ {"fill_wavefronts_per_cu", 4, "wavefronts", "one workgroup of the camera fill (four wavefronts) sits on every CU: what is left of the CU's wavefront slots is the drawing's"},
+};
+constexpr double top_rule(TopRuleId id) { return kTopRules[id].value; }
+
+// what the rule decides (fields of RcwDev), from the configuration, the batch, the device's numbers and the caller's wishes; no HIP call.
+// want_form: 0 = the rule, or one of RCW_TOP_VIEW_IN_PLACE / ONE_KERNEL / TWO_KERNELS (rcw_set_top_view_form); want_runs: 0 = the rule, or 1..8.
+// `lenient`: a form the geometry cannot take falls back to the rule (development switches) instead of failing.
+int top_view_rule(RcwDev& d, const rcw_config* cfg, size_t B, const RcwHw& hw, int want_form, int want_runs, bool lenient)
+{
     const int H = cfg->height_tile_map_tu, W = cfg->width_tile_map_tu, N = cfg->num_rays, Hc = cfg->height_camera_view_pu;
-    const size_t B = (size_t)h->B;
-    if (h->top_stream) RCW_HIP(hipStreamSynchronize(h->top_stream));
-    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_top_flags}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-    d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr; d.top_flags = nullptr; h->top_epoch = 0;
     d.top_blk_shift = 0; d.top_epoch = 0; d.top_signal = 0; d.top_follow = 0; d.top_follow_ok = 0;
     d.top_lds = 0; d.top_split = 0; d.top_flat = 0; d.top_plane_words = 0; d.top_unit_px = 256; d.top_runs = 1;
-    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = h->num_cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256; d.top_draw_first = 0; d.top_parts = 1;
+    d.top_alone_split = 0; d.top_fused = 0; d.top_grid = hw.cus; d.top_store_grid = d.fill_grid; d.top_store_plain = 0; d.top_draw_block = 256; d.top_draw_block_alone = 256; d.top_draw_first = 0; d.top_parts = 1;
     if (!cfg->render_top_view) {
         if (want_form != 0 && !lenient) return fail(RCW_ERR_UNSUPPORTED, "handle was created with render_top_view = 0");
         return RCW_OK;
     }
-    // the write-once kernel keeps a ring of 1..3 agents' bit planes in LDS (160 KiB per CU): three where three
-    // workgroups per CU still fit beside each other, else two, else one; larger images take the in-place kernel
+    const size_t ring_cap = (size_t)top_rule(kRingLdsCap);
+    // the write-once kernel keeps a ring of 1..3 agents' bit planes in LDS: three where three workgroups per CU still fit beside
+    // each other, else two, else one; larger images take the in-place kernel
     d.top_lds = 3;
-    if (rcw_top_view_lds_bytes(d) > 52 * 1024) d.top_lds = 2;
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1;
-    if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 0;             // (the size depends on top_lds)
-    if ((long long)H * cfg->pu_per_tu > 16384 || (long long)W * cfg->pu_per_tu > 16384) d.top_lds = 0;   // the bit-plane kernels' line walk is exact for lines of up to 2^14 pixels
-    if (const char* v = RCW_DEV_ENV("RCW_TOP_RING")) { const int k = std::atoi(v); if (k >= 1 && k <= 3 && d.top_lds > 0) { d.top_lds = k; if (rcw_top_view_lds_bytes(d) > 156 * 1024) d.top_lds = 1; } }
+    if (rcw_top_view_lds_bytes(d) > (size_t)top_rule(kRingThreeBuffersLds)) d.top_lds = 2;
+    if (rcw_top_view_lds_bytes(d) > ring_cap) d.top_lds = 1;
+    if (rcw_top_view_lds_bytes(d) > ring_cap) d.top_lds = 0;             // (the size depends on top_lds)
+    if ((long long)H * cfg->pu_per_tu > (long long)top_rule(kLineWalkMaxPixels) || (long long)W * cfg->pu_per_tu > (long long)top_rule(kLineWalkMaxPixels)) d.top_lds = 0;
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_RING")) { const int k = std::atoi(v); if (k >= 1 && k <= 3 && d.top_lds > 0) { d.top_lds = k; if (rcw_top_view_lds_bytes(d) > ring_cap) d.top_lds = 1; } }
     if (want_form == RCW_TOP_VIEW_IN_PLACE) d.top_lds = 0;
     if (want_form == RCW_TOP_VIEW_ONE_KERNEL && !d.top_lds && !lenient)
         return fail(RCW_ERR_UNSUPPORTED, "the image's bit planes do not fit in LDS: this geometry takes the in-place form only");
     {   // persistent grid: as many 8-wavefront workgroups per CU as registers and LDS allow
         const size_t lds = rcw_top_view_lds_bytes(d);
-        int per_cu = lds ? (int)((160 * 1024) / lds) : 4;
-        per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);   // 3 x 8 wavefronts: what the kernel's register use admits (4 measured no faster)
-        d.top_grid = per_cu * h->num_cus;
+        int per_cu = lds ? (int)((size_t)hw.lds_per_cu / lds) : 4;
+        per_cu = per_cu < 1 ? 1 : (per_cu > (int)top_rule(kRingWorkgroupsPerCu) ? (int)top_rule(kRingWorkgroupsPerCu) : per_cu);
+        d.top_grid = per_cu * hw.cus;
     }
     if (const char* v = RCW_DEV_ENV("RCW_TOP_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_grid = g; }
     if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_GRID")) { const int g = std::atoi(v); if (g >= 1 && g <= 65536) d.top_store_grid = g; }
@@ -437,11 +489,9 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     d.top_unit_px = unit ? unit : 256;
     d.top_flat = unit ? 0 : flat;
     d.top_plane_words = d.top_flat ? rcw_top_plane_words(d) : 0;
-    // ... at every batch size where a step's camera fill and the drawing go in ONE launch (rcw_fill256_draw_kernel: 8×8 tiles of
-    // 32 px, 1 / 16 / 64 / 256 / 1024 / 4096 agents: 21 / 28 / 30 / 38 / 91 / 330 µs a step against 36 / 38 / 41 / 47 / 103 / 387 in the
-    // one-kernel form); where the drawing needs the side stream (another camera height, planes beyond 64 KiB, runs of agents), only
-    // where the batch is big enough to pay for the fork / join and the extra launch (≈ 13 µs a step: 39 / 51 / 53 / 60 / 102 / 341 µs):
-    // from 256 MiB of top view a step.  (Decided below, when the draw kernel's block and the runs are known.)
+    // ... at every batch size where a step's camera fill and the drawing go in ONE launch (rcw_fill256_draw_kernel); where the drawing
+    // needs the side stream (another camera height, planes beyond 64 KiB, runs of agents), only where the batch is big enough to pay for
+    // the fork / join and the extra launch (kSideStreamMinBytes).  (Decided below, when the draw kernel's block and the runs are known.)
     d.top_split = eligible ? 1 : 0;
     if (want_form == RCW_TOP_VIEW_ONE_KERNEL || want_form == RCW_TOP_VIEW_IN_PLACE) d.top_split = 0;
     if (want_form == RCW_TOP_VIEW_TWO_KERNELS) {
@@ -449,76 +499,78 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         else if (!lenient) return fail(RCW_ERR_UNSUPPORTED, "this geometry does not take the two-kernel form (pu_per_tu >= 8, image height a multiple of 4 and of at least 42 rows, bit plane within LDS)");
     }
     if (!d.top_split) { d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; }
-    // rcw_update_top_view alone has no camera fill to hide the drawing behind.  Measured, round 5 (draw -> store back to back against
-    // the one-kernel form, us per GiB of top view, profiles/r05_top_view_shapes.txt): images from 256 x 256 px 217 / 224 / 198 / 210 /
-    // 218 against 214 / 231 / 228 / 253 / 360 (256^2, 256 x 512, 512^2, 768^2, 1024^2 px); pixel scales that are no multiple of 4,
-    // where the one-kernel form has only its generic paths, 360 / 302 against 507 / 450 (10, 13 px a tile), and 12 px a tile 310
-    // against 347; the one-kernel form keeps what is left of the two-kernel form's geometries: images below 256^2 px at 16, 20, 24,
-    // 28 ... px a tile (264 / 228 / 229 against 268 / 246 / 233) — and every geometry the two-kernel form cannot take.
+    // rcw_update_top_view alone has no camera fill to hide the drawing behind (kAloneTwoKernelsPixels, kAloneTwoKernelsBelowPu): draw ->
+    // store back to back for images from 256 x 256 px, pixel scales that are no multiple of 4 and tiles below 16 px; the one-kernel form
+    // keeps what is left of the two-kernel form's geometries — and every geometry the two-kernel form cannot take.
     {
         const long long px = (long long)H * cfg->pu_per_tu * W * cfg->pu_per_tu;
-        d.top_alone_split = d.top_split && (px >= 65536 || (cfg->pu_per_tu & 3) != 0 || cfg->pu_per_tu < 16) ? 1 : 0;
+        d.top_alone_split = d.top_split && (px >= (long long)top_rule(kAloneTwoKernelsPixels) || (cfg->pu_per_tu & 3) != 0 || cfg->pu_per_tu < (int)top_rule(kAloneTwoKernelsBelowPu)) ? 1 : 0;
     }
     if (const char* v = RCW_DEV_ENV("RCW_TOP_ALONE_SPLIT")) d.top_alone_split = d.top_split && std::atoi(v) ? 1 : 0;
-    // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on
-    // a CU (> 64 KiB), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer (measured, µs of the top
-    // view in a step with 256 / 512 / 1024 threads: 512² px, 256 rays 180 / 182 / 200; 768² px 212 / 200 / 203; 1024² px, 1024 rays 357 / 265 / 216)
-    if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > 64 * 1024) { const int b = ((N + 255) / 256) * 256; d.top_draw_block = b < 512 ? 512 : (b > 1024 ? 1024 : b); }
-    // ... and alone, with tens of thousands of small images, one or two wavefronts an agent (the set-up per wavefront is what such a
-    // batch costs; 41,943 images of 80^2 px: 175 us with 64 threads against 193 with 256, 16,384 of 128^2 px: 103 with 128 against 109)
-    d.top_draw_block_alone = d.top_draw_block;
-    if (d.top_draw_block == 256) d.top_draw_block_alone = h->B >= 24576 ? 64 : (h->B >= 12288 ? 128 : 256);
-    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = d.top_draw_block_alone = b; }
-    // runs of agents: where the lines are long against the camera image's columns ((Ht + Wt) / 2 >= 1.75 H_cam) the drawing
-    // does not fit beside the camera fill; with several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside
-    // the storing of earlier runs.  Measured (µs a step with 1 / 2 / 4 / 8 runs): 16×16 map, 512 rays, 16,384 agents (16 GiB of
-    // top view) 4516 / 4409 / 4332 / 4294; 32×32 map, 1024 rays, 8192 agents (32 GiB) 8586 / 8459 / 7658 / 8068.  Runs of
-    // 256 MiB do NOT pay (four short store launches and their joins: 205 vs 181 µs at 1 GiB of 512² px images).
-    if (2ll * ((long long)H + W) * cfg->pu_per_tu >= 7ll * Hc) {
-        const size_t gib = (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)) >> 30;
-        d.top_runs = gib >= 4 ? 4 : (gib >= 2 ? 2 : 1);
+    // draw kernel: one workgroup of 4 wavefronts per agent; where the bit plane leaves room for one or two workgroups on a CU
+    // (kDrawWideBlockLds), 8 to 16 wavefronts: a lane per ray for N > 256, two lanes a ray for fewer
+    if (rcw_top_view_lds_bytes(d) / (d.top_lds > 0 ? d.top_lds : 1) > (size_t)top_rule(kDrawWideBlockLds)) {
+        const int b = ((N + 255) / 256) * 256;
+        d.top_draw_block = b < (int)top_rule(kDrawBlockMin) ? (int)top_rule(kDrawBlockMin) : (b > (int)top_rule(kDrawBlockMax) ? (int)top_rule(kDrawBlockMax) : b);
     }
-    if (want_runs >= 1) d.top_runs = want_runs <= 8 ? (want_runs <= h->B ? want_runs : h->B) : 8;
+    // ... and alone, with tens of thousands of small images, one or two wavefronts an agent (the set-up per wavefront is what such a batch costs)
+    d.top_draw_block_alone = d.top_draw_block;
+    if (d.top_draw_block == 256) d.top_draw_block_alone = B >= (size_t)top_rule(kAloneBlock64Agents) ? 64 : (B >= (size_t)top_rule(kAloneBlock128Agents) ? 128 : 256);
+    if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_BLOCK")) { const int b = std::atoi(v); if (b == 64 || b == 128 || b == 256 || b == 512 || b == 768 || b == 1024) d.top_draw_block = d.top_draw_block_alone = b; }
+    // runs of agents: where the lines are long against the camera image's columns the drawing does not fit beside the camera fill; with
+    // several GiB of top view a step, runs of >= 1 GiB let the rest of it hide beside the storing of earlier runs
+    if ((long long)top_rule(kRunsLineToCameraDen) * ((long long)H + W) * cfg->pu_per_tu >= (long long)top_rule(kRunsLineToCameraNum) * Hc) {
+        const size_t gib = (B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)) >> 30;
+        d.top_runs = gib >= (size_t)top_rule(kRuns4Gib) ? 4 : (gib >= (size_t)top_rule(kRuns2Gib) ? 2 : 1);
+    }
+    if (want_runs >= 1) d.top_runs = want_runs <= 8 ? (want_runs <= (int)B ? want_runs : (int)B) : 8;
     // a step's camera fill and the drawing in one launch where the geometry allows (256-row camera view, one run, planes of a
     // 256-thread draw workgroup): no side stream in the step
     d.top_fused = rcw_fill_draw_fusable(d) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_FUSED")) d.top_fused = d.top_fused && std::atoi(v) ? 1 : 0;
     if (d.top_split && !d.top_fused && want_form != RCW_TOP_VIEW_TWO_KERNELS &&
-        B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t) < ((size_t)256 << 20)) {
+        (double)(B * (size_t)H * W * cfg->pu_per_tu * cfg->pu_per_tu * sizeof(uint32_t)) < top_rule(kSideStreamMinBytes)) {
         d.top_split = 0; d.top_unit_px = 256; d.top_flat = 0; d.top_plane_words = 0; d.top_alone_split = 0;
     }
     // Several draw workgroups an agent (rcw_top_draw_kernel: each walks a part of the fan and ORs its plane into the agent's) where a batch
-    // of big images leaves draw slots empty: as many parts as fill them, at most four, at least 128 rays each.  Only with
-    // rcw_top_store_kernel, which reads every plane word exactly once and leaves the zero the next drawing needs.  Measured (tools/
-    // r05_draw_parts.sh; draw kernel, us, 1 / 2 / 4 parts): 1024^2 px, 1024 rays x 64 agents 53.6 / 38.6 / 30.5, x 128: 58.8 / 40.4 / 59.0,
-    // x 256 (every CU has its agent): 61.4 / 78.7 / 110 — a part's fixed costs (the plane cleared, every ray's end point, the plane
-    // scanned) are most of a workgroup's life, so parts only pay where they fill empty CUs; 768^2 px, 256 rays x 114: 24.7 / 19.4 / 21.2.
+    // of big images leaves draw slots empty: as many parts as fill them (kPartsMax, kPartsMinRays).  Only with rcw_top_store_kernel, which
+    // reads every plane word exactly once and leaves the zero the next drawing needs.
+    const int draw_per_cu = rcw_top_draw_per_cu(d, d.top_draw_block, hw.lds_per_cu, hw.waves_per_cu - (int)top_rule(kFillWavefrontsPerCu));
     d.top_parts = 1;
     if (d.top_split && !d.top_flat && d.top_unit_px == 256 && !d.top_fused && !d.top_draw_r4) {
-        const long long slots = (long long)h->num_cus * rcw_top_draw_per_cu(d, d.top_draw_block);
-        int parts = (int)std::min<long long>(4, slots / (long long)B);
-        while (parts > 1 && N / parts < 128) --parts;
+        const long long slots = (long long)hw.cus * draw_per_cu;
+        int parts = (int)std::min<long long>((long long)top_rule(kPartsMax), slots / (long long)B);
+        while (parts > 1 && N / parts < (int)top_rule(kPartsMinRays)) --parts;
         d.top_parts = parts < 1 ? 1 : parts;
         if (const char* v = RCW_DEV_ENV("RCW_TOP_PARTS")) { const int q = std::atoi(v); if (q >= 1 && q <= 4 && N / q >= 16) d.top_parts = q; }
     }
     // The drawing first on the handle's stream and the camera fill on the side stream (launch_top_view) where the fill is the SHORTER of the
-    // two: it then ends before the store kernel starts.  Where it is the longer one it runs into the store kernel — two moving windows on one
-    // HBM — and the step takes up to 60 % longer (measured, us a step, drawing on the side stream -> drawing first; tools/r05_draw_first.sh:
-    // 768^2 px 226 -> 211, 1024^2 250 -> 239, 704^2 251 -> 236, 512^2 px beside a 128-row camera view 231 -> 216 — and 256^2 px beside 128 /
-    // 300 / 512 rows 267 -> 376, 374 -> 563, 495 -> 801, 256 x 512 px beside 128 rows 265 -> 328).  Both are estimated from the sizes: the
-    // fill at 6.5 TB/s plus its late start, the drawing at its measured floor per GiB of top view (34 us with up to 256 rays, 55 beyond) —
-    // of the batch or, for a small one, of most of one round of workgroups (a partial round takes about as long as a full one: 768^2 px x
-    // 114 / 228 / 341 agents 90 -> 75, 129 -> 115, 169 -> 155 us; 1024^2 x 64 / 128 / 192: 113 -> 99, 147 -> 133, 178 -> 164).
+    // two: it then ends before the store kernel starts (where it is the longer one it runs into the store kernel — two moving windows on one
+    // HBM — and the step takes up to 60 % longer).  Both are estimated from the sizes: the fill at kFillGBperMs plus its late start, the
+    // drawing at its measured floor per GiB of top view — of the batch or, for a small one, of most of one round of workgroups.
     {
-        const double fill_us = (double)B * N * Hc * 4.0 / 6.5e6 + 12.0;
+        const double fill_us = (double)B * N * Hc * 4.0 / top_rule(kFillGBperMs) + top_rule(kFillLateStartUs);
         const double image_gib = (double)H * W * cfg->pu_per_tu * cfg->pu_per_tu * 4.0 / (double)(1u << 30);
-        const double round_gib = (double)h->num_cus * rcw_top_draw_per_cu(d, d.top_draw_block) * image_gib;
-        const double top_gib = std::max((double)B * image_gib, 0.7 * round_gib);
-        const double draw_us = top_gib * (N > 256 ? 55.0 : 34.0);
+        const double round_gib = (double)hw.cus * draw_per_cu * image_gib;
+        const double top_gib = std::max((double)B * image_gib, top_rule(kDrawPartialRound) * round_gib);
+        const double draw_us = top_gib * (N >= (int)top_rule(kDrawManyRays) ? top_rule(kDrawUsPerGibManyRays) : top_rule(kDrawUsPerGibFewRays));
         d.top_draw_first = d.top_split && !d.top_fused && d.top_runs <= 1 && fill_us <= draw_us ? 1 : 0;
     }
     if (const char* v = RCW_DEV_ENV("RCW_TOP_DRAW_FIRST")) d.top_draw_first = d.top_split && !d.top_fused && std::atoi(v) ? 1 : 0;
     if (const char* v = RCW_DEV_ENV("RCW_TOP_STORE_PLAIN")) d.top_store_plain = std::atoi(v) ? 1 : 0;
+    return RCW_OK;
+}
+
+// Which form update_top_view! (SR:446-483) takes for this handle (top_view_rule), and its scratch in HBM.
+int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
+{
+    RcwDev& d = h->dev;
+    const size_t B = (size_t)h->B;
+    if (h->top_stream) RCW_HIP(hipStreamSynchronize(h->top_stream));
+    for (void** q : {&h->d_top_plane, &h->d_top_hdr, &h->d_top_codes, &h->d_top_flags}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    d.top_plane = nullptr; d.top_hdr = nullptr; d.top_codes = nullptr; d.top_flags = nullptr; h->top_epoch = 0;
+    int rc = top_view_rule(d, &h->cfg, B, h->hw, want_form, want_runs, lenient);
+    if (rc != RCW_OK || !h->cfg.render_top_view) return rc;
     if (d.top_split) {
         hipError_t e = hipMalloc(&h->d_top_plane, rcw_top_plane_bytes(d));
         // The planes start out ZERO.  The flat store kernel ORs the plane words of two neighbouring agents' regions in a chunk
@@ -541,20 +593,17 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RCW_ERR_OUT_OF_MEMORY : RCW_ERR_HIP, "top view planes: %s", hipGetErrorString(e));
         d.top_plane = (uint32_t*)h->d_top_plane; d.top_hdr = (int2*)h->d_top_hdr; d.top_codes = (uint2*)h->d_top_codes;
 #ifdef RCW_DEV_SWITCHES
-        d.top_flags = (uint32_t*)h->d_top_flags;
-        while ((((size_t)h->B + ((size_t)1 << d.top_blk_shift) - 1) >> d.top_blk_shift) > 1024) ++d.top_blk_shift;   // at most 1024 blocks: sixteen looks of a wavefront see them all
-        // the store kernel follows the draw kernel (no event between them) where their workgroups fit on a CU together:
-        // bit 0 inside a step (side-stream form, one run), bit 1 in rcw_update_top_view alone
-        d.top_follow_ok = (!d.top_fused && d.top_runs <= 1 && rcw_top_follow_fits(d, d.top_draw_block, true, h->num_cus) ? 1 : 0) |
-                          (d.top_alone_split && rcw_top_follow_fits(d, d.top_draw_block_alone, false, h->num_cus) ? 2 : 0);
-        { const char* v = RCW_DEV_ENV("RCW_TOP_FOLLOW"); d.top_follow_ok &= v ? std::atoi(v) : 0; }   // (off unless asked for)
-        if (d.top_draw_r4 || d.top_parts > 1) d.top_follow_ok = 0;
+#include "dev/api_top_follow_plan.inc"   // RCW_TOP_FOLLOW: the counters' block size and where the store kernel may follow the draw kernel
 #endif
     }
     hipError_t e = rcw_prepare_top_view(d, h->device);
     if (e != hipSuccess) return fail(RCW_ERR_HIP, "top view kernel attribute: %s", hipGetErrorString(e));
     return RCW_OK;
 }
+
+#ifdef RCW_DEV_SWITCHES
+#include "dev/api_plan_export.inc"   // rcw_dev_plan_top_view / rcw_dev_top_view_rules: the rule and its table without a device (tests/test_top_view_plan.py)
+#endif
 
 // Which form a step takes (rcw_set_step_form; want = 0: the rule — one launch wherever the geometry allows, unless a step of the handle
 // was captured into a graph).  Allocates the two slot buffers the first time the one-launch form is taken; the caller primes them
@@ -879,7 +928,7 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
 #undef RCW_TRY
 
     RcwDev& d = h->dev;
-    d.B = batch; d.H = H; d.W = W; d.N = N; d.nd = nd; d.Hc = Hc;
+    set_geometry(d, cfg, batch);
     d.nwords = h->nchunks * 2;
     d.radius = cfg->player_radius_wu;
     d.radius_sq = cfg->player_radius_wu * cfg->player_radius_wu;        // radius * radius CD:18
@@ -889,7 +938,6 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.reward_type = cfg->reward_type;
     d.num = cfg->camera_height_tile_wu * (float)N;                      // SR:406 numerator
     d.two_fov = 2.0f * cfg->semi_field_of_view_wu;                      // 2 * fov
-    d.real64 = h->real64 ? 1 : 0;
     d.radius64 = cfg->player_radius_wu_f64;
     d.radius_sq64 = cfg->player_radius_wu_f64 * cfg->player_radius_wu_f64;
     d.inc64 = cfg->position_increment_wu_f64;
@@ -912,13 +960,13 @@ int rcw_create(const rcw_config* cfg, int32_t batch, int32_t device, uint64_t se
     d.dir_table64 = (const double2*)h->d_dir_table; d.ray_table64 = (const double*)h->d_ray_table;
     d.obs = (uint32_t*)h->d_obs; d.col_h = (int32_t*)h->d_col_h; d.col_c = (uint8_t*)h->d_col_c;
     d.err = (int32_t*)h->d_err;
-    d.top_view = (uint32_t*)h->d_top_view; d.pu = cfg->pu_per_tu;
-    // player_radius_pu = wu_to_pu(player_radius_wu, pu_per_tu) SR:469 = floor(Int, r * pu) + 1 in T (UT:6)
-    d.top_rp = h->real64 ? (int32_t)std::floor(cfg->player_radius_wu_f64 * (double)cfg->pu_per_tu) + 1
-                         : (int32_t)std::floor(cfg->player_radius_wu * (float)cfg->pu_per_tu) + 1;
+    d.top_view = (uint32_t*)h->d_top_view;
     d.status = (int32_t*)h->d_status;
     d.oob_empty = cfg->out_of_bounds == RCW_OOB_TREAT_EMPTY;
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->hw.cus = h->num_cus;
+    if (prop.sharedMemPerBlock >= 64 * 1024) h->hw.lds_per_cu = (int)prop.sharedMemPerBlock;           // (gfx950: 160 KiB, the whole CU's)
+    if (prop.maxThreadsPerMultiProcessor >= 64) h->hw.waves_per_cu = prop.maxThreadsPerMultiProcessor / 64;
     // fill kernel: one workgroup per CU (256 on an MI355X in SPX mode; a partitioned device reports fewer)
     d.fill_grid = h->num_cus; d.fill_plain = 0; d.fill_flat = 0;
     // lanes per agent in the cast kernel: four rays a lane once the batch fills the chip (measured, µs: 512 columns 45.6 vs 51.4

@@ -131,7 +131,8 @@ const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // th
 int rcw_fill_takes_256(const RcwDev& p, long long total_cols);              // ... is rcw_fill256_kernel (what the fused launches build on)
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
-int rcw_top_draw_per_cu(const RcwDev& p, int draw_block);   // draw workgroups resident on a CU together
+struct RcwHw { int cus, lds_per_cu, waves_per_cu; };       // what the top view's rule needs of the device (hipDeviceProp_t: multiProcessorCount, sharedMemPerBlock, maxThreadsPerMultiProcessor / 64)
+int rcw_top_draw_per_cu(const RcwDev& p, int draw_block, int lds_per_cu = 160 * 1024, int waves = 28);   // draw workgroups resident on a CU together: by LDS, by the wavefront slots the camera fill leaves
 int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int cus);   // draw + store (+ camera fill) workgroups resident on one CU together
 hipError_t rcw_launch_top_draw(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s, int block = 0);    // agents [first, first + count); block: threads a workgroup, 0 = p.top_draw_block
 hipError_t rcw_launch_top_store(const RcwDev& p, const uint8_t* mask_dev, int first, int count, hipStream_t s);

@@ -1191,11 +1191,11 @@ hipError_t rcw_launch_fill256_draw(const RcwDev& p, const uint8_t* mask_dev, hip
 // workgroups — resident for the whole launch, and waiting — are already there (and, inside a step, the camera fill's): wavefronts
 // (32 a CU; 28 counted, what the draw kernel was seen to reach) and LDS (160 KiB).
 // draw workgroups that fit on a CU together (LDS, wavefronts): what one "round" of the draw kernel is
-int rcw_top_draw_per_cu(const RcwDev& p, int draw_block)
+int rcw_top_draw_per_cu(const RcwDev& p, int draw_block, int lds_per_cu, int waves)
 {
     const size_t lds = 4 * top_draw_lds_words(p);
-    int n = lds ? (int)((size_t)(160 * 1024) / lds) : 8;
-    const int by_waves = 28 / (draw_block / 64 > 0 ? draw_block / 64 : 1);
+    int n = lds ? (int)((size_t)lds_per_cu / lds) : 8;
+    const int by_waves = waves / (draw_block / 64 > 0 ? draw_block / 64 : 1);
     if (n > by_waves) n = by_waves;
     return n < 1 ? 1 : n;
 }
