@@ -80,7 +80,7 @@ def test_every_rule_names_its_evidence(devlib):
     # the source holds no second copy of a threshold: the rule's function reads the table
     src = open(os.path.join(ROOT, "raycastworlds.jl_amd", "csrc", "rcw_api.hip")).read()
     body = src[src.index("int top_view_rule("):src.index("// Which form update_top_view! (SR:446-483) takes for this handle (top_view_rule)")]
-    for literal in ("52 * 1024", "156 * 1024", "65536", "24576", "12288", "6.5e6", "55.0", "34.0", "0.7 *", "160 * 1024", "<< 20"):
+    for literal in ("52 * 1024", "156 * 1024", ">= 65536", "24576", "12288", "6.5e6", "55.0", "34.0", "0.7 *", "160 * 1024", "<< 20"):
         assert literal not in body, literal
 
 
