@@ -586,7 +586,9 @@ def main(argv=None, rt=None):
                            "planes of 1/32 of the image) " + ("rides in the camera fill's launch (rcw_fill256_draw_kernel, roofline.kernel)"
                                                               if fill_kernel == "rcw_fill256_draw_kernel" else
                                                               "is rcw_top_draw_kernel on a side stream beside the camera fill")
-                           + " and is inside roofline.launch_ms — see profiles/ for its own duration" if form == "two-kernels" else ""),
+                           + " and is inside roofline.launch_ms — see profiles/ for its own duration; where the rule keeps the DRAWING on the handle's stream and sends "
+                             "the camera fill to the side stream (big images: include/rcw.h, rcw_profile), launch_ms here runs from the fill's end to the step's end and "
+                             "may hold the drawing's tail: `achieved` is then a lower bound of the store kernel's own rate" if form == "two-kernels" else ""),
             }
         if api_loop is not None:
             out["api_loop"] = api_loop

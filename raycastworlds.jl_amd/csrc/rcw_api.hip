@@ -78,7 +78,12 @@ struct rcw_handle {
     void* d_top_view = nullptr;
     // two-kernel top view: planes / player pixels / tile codes in HBM, the side stream the draw kernel runs on
     void* d_top_plane = nullptr; void* d_top_hdr = nullptr; void* d_top_codes = nullptr;
-    void* d_top_flags = nullptr; uint32_t top_epoch = 0;   // the store kernel follows the draw kernel (rcw_kernels.hip: top_publish)
+    void* d_top_flags = nullptr; uint32_t top_epoch = 0;   // the store kernel follows the draw kernel (dev/top_follow_publish.inc)
+    // Several draw workgroups an agent (top_parts > 1) OR their bits into the agent's plane in HBM, and only rcw_top_store_kernel — which reads
+    // every plane word exactly once — leaves the zero the next drawing needs: a drawing whose store did not follow (a failed launch in
+    // between, the development build's skip-the-store switch) leaves bits behind that every later frame would carry.  Set in front of such a
+    // drawing, cleared behind its store's launch; a drawing that finds it set clears the planes first.
+    bool top_plane_dirty = false;
     hipStream_t top_stream = nullptr;
     hipEvent_t ev_top_fork = nullptr;
     hipEvent_t ev_top_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per run of agents
@@ -129,6 +134,8 @@ constexpr int kProfileSlots = 256;
 // the draw kernel runs on the side stream: fork after what is already queued (the cast kernel), join before the store.
 // The stand-alone call (`beside` = false) has no camera fill to run beside and takes the one-kernel form.
 template <typename Between>
+hipError_t launch_top_view_ordered(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between, hipEvent_t fused_event);
+template <typename Between>
 hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between, hipEvent_t fused_event = nullptr)   // between(stream): the caller's camera fill
 {
     const RcwDev& d = h->dev;
@@ -137,6 +144,24 @@ hipError_t launch_top_view(rcw_handle* h, const uint8_t* mask_dev, bool beside, 
         if ((e = rcw_launch_top_view(d, mask_dev, h->stream)) != hipSuccess) return e;
         return between(h->stream);
     }
+    if (d.top_parts > 1) {                                   // (see rcw_handle::top_plane_dirty; every order below forks from the handle's stream behind this)
+        if (h->top_plane_dirty && (e = hipMemsetAsync(h->d_top_plane, 0, rcw_top_plane_bytes(d), h->stream)) != hipSuccess) return e;
+        h->top_plane_dirty = true;
+        struct Clean { rcw_handle* h; hipError_t* e; ~Clean() { if (*e == hipSuccess && !(h->dev.top_debug & 2)) h->top_plane_dirty = false; } };
+        hipError_t result = hipErrorUnknown;
+        Clean clean{h, &result};
+        result = launch_top_view_ordered(h, mask_dev, beside, between, fused_event);
+        return result;
+    }
+    return launch_top_view_ordered(h, mask_dev, beside, between, fused_event);
+}
+
+// (the launch orders of the two-kernel form; launch_top_view above decides whether it is taken)
+template <typename Between>
+hipError_t launch_top_view_ordered(rcw_handle* h, const uint8_t* mask_dev, bool beside, Between between, hipEvent_t fused_event)
+{
+    const RcwDev& d = h->dev;
+    hipError_t e;
 #ifdef RCW_DEV_SWITCHES
 #include "dev/api_top_follow.inc"   // RCW_TOP_FOLLOW, the launch order in which the store kernel follows the draw kernel
 #endif

@@ -1213,7 +1213,7 @@ int rcw_top_follow_fits(const RcwDev& p, int draw_block, bool beside_fill, int c
 }
 // Above 64 KiB of dynamic LDS a kernel has to be told so once (the CU has 160 KiB).  The attribute belongs to the
 // FUNCTION, i.e. to every handle on the device: it is set once per device, to the fixed cap the geometry selection
-// works with (16 B + 156 KiB for the ring kernel, 156 KiB for the draw kernel), never to one handle's own need — a
+// works with (16 B + 156 KiB for the ring kernel, 159 KiB for the draw kernel; the attribute itself is set to the CU's 160 KiB), never to one handle's own need — a
 // second handle with a smaller image must not lower the limit under a first one's feet.
 hipError_t rcw_prepare_top_view(const RcwDev& p, int device)
 {

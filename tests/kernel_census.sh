@@ -8,7 +8,7 @@ set -o pipefail
 R=$PWD; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/census; mkdir -p $R/gpurun_out/census
 run() { local tag=$1; shift; (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/census/$tag -- "$@" > $R/gpurun_out/census/$tag.log 2>&1); echo "$tag rc=$?"; tail -1 $R/gpurun_out/census/$tag.log | cut -c1-150; }
-run tests python3 -m pytest $R/tests/test_gpu_parity.py $R/tests/test_gpu_full_size.py $R/tests/test_reference_fixtures.py $R/tests/test_reference_invariants.py $R/tests/test_discriminators.py $R/tests/test_kernel_instantiations.py -m gpu -q -p no:cacheprovider
+run tests python3 -m pytest $R/tests/test_gpu_parity.py $R/tests/test_gpu_full_size.py $R/tests/test_reference_fixtures.py $R/tests/test_reference_invariants.py $R/tests/test_discriminators.py $R/tests/test_kernel_instantiations.py $R/tests/test_gpu_step_form.py -m gpu -q -p no:cacheprovider
 run fuzz1 python3 $R/tools/fuzz_parity.py 120 2025
 run fuzz2 python3 $R/tools/fuzz_parity.py 80 77 flat
 run fuzz3 python3 $R/tools/fuzz_parity.py 80 78 split
