@@ -630,16 +630,31 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
 #include "dev/api_plan_export.inc"   // rcw_dev_plan_top_view / rcw_dev_top_view_rules: the rule and its table without a device (tests/test_top_view_plan.py)
 #endif
 
-// Which form a step takes (rcw_set_step_form; want = 0: the rule — one launch wherever the geometry allows, unless a step of the handle
-// was captured into a graph).  Allocates the two slot buffers the first time the one-launch form is taken; the caller primes them
-// (launch_step without an action).
+// The one-launch step pays where the fill outlasts the casting half's own life: one casting workgroup marches FIVE fans one after the
+// other, so a small batch waits for it (4096 x 256 columns: 17 us of casting life under a 154 us fill; 64 agents: 22 us a step against
+// 12 for cast kernel + fill).  Measured crossovers (profiles/r06_small_batches.txt, frames of a step): 8x8 map, 256 columns ~128 MiB;
+// 16x16, 512 columns ~100 MiB; 32x32, 1024 columns ~350 MiB; 8x8, 64 columns below 64 MiB — the casting life fits
+// kStepCastBaseUs + kStepCastUsPerUnit x (view columns a lane x 5 fans x (H + W) tiles a ray may cross), the fill kFillGBperMs.
+constexpr double kStepCastBaseUs = 4.5, kStepCastUsPerUnit = 0.045;
+bool step_one_launch_pays(const RcwDev& d)
+{
+    const int lanes = d.N <= 256 ? 64 : 256;                                // a wavefront per agent up to 256 view columns, a workgroup beyond
+    const double units = (double)((d.N + lanes - 1) / lanes) * 5.0 * (double)(d.H + d.W);
+    const double cast_us = kStepCastBaseUs + kStepCastUsPerUnit * units;
+    const double fill_us = (double)d.B * d.N * d.Hc * 4.0 / top_rule(kFillGBperMs);
+    return fill_us >= cast_us;
+}
+
+// Which form a step takes (rcw_set_step_form; want = 0: the rule — one launch where the geometry allows AND the batch is large enough
+// for it to pay, unless a step of the handle was captured into a graph).  Allocates the two slot buffers the first time the one-launch
+// form is taken; the caller primes them (launch_step without an action).
 int plan_step_form(rcw_handle* h, int want)
 {
     RcwDev& d = h->dev;
     const bool eligible = rcw_step_spec_eligible(d) != 0;
     if (want == RCW_STEP_ONE_LAUNCH && !eligible)
         return fail(RCW_ERR_UNSUPPORTED, "this handle does not take the one-launch step (a 256-row camera view without a top view, fewer than 2^29 view columns)");
-    const bool on = want == RCW_STEP_TWO_LAUNCHES ? false : (want == RCW_STEP_ONE_LAUNCH ? true : eligible && !h->step_captured);
+    const bool on = want == RCW_STEP_TWO_LAUNCHES ? false : (want == RCW_STEP_ONE_LAUNCH ? true : eligible && !h->step_captured && step_one_launch_pays(d));
     if (on) {
         for (int k = 0; k < 2; ++k) {
             if (h->d_spec[k]) continue;

@@ -42,18 +42,18 @@ int main(int argc, char** argv)
     memset(actions, 1, sizeof actions); actions[7] = 5;
     if (rcw_step(h, actions) != RCW_ERR_INVALID_ACTION) { fprintf(stderr, "invalid action accepted\n"); return 1; }
 
-    /* a step's two forms (rcw_step_form): one launch by the rule here (256-row camera view, no top view); the two-launch form for a
-     * stretch in the middle — the same state and pixels either way (the checksum below is the oracle's) */
+    /* a step's two forms (rcw_step_form): two launches by the rule here (64 agents: too small a batch for the one-launch step to pay); the
+     * one-launch form on request for a stretch in the middle — the same state and pixels either way (the checksum below is the oracle's) */
     int32_t step_form = -1;
     CHECK(rcw_step_form(h, &step_form));
-    if (step_form != RCW_STEP_ONE_LAUNCH) { fprintf(stderr, "rcw_step_form: %d, expected the one-launch step\n", (int)step_form); return 1; }
+    if (step_form != RCW_STEP_TWO_LAUNCHES) { fprintf(stderr, "rcw_step_form: %d, expected the two-launch step at this batch\n", (int)step_form); return 1; }
     printf("step_form=%d\n", (int)step_form);
 
     uint64_t seed = 99;
     float ret[64] = {0};
     int finished = 0;
     for (int s = 0; s < STEPS; ++s) {
-        if (s == STEPS / 3) CHECK(rcw_set_step_form(h, RCW_STEP_TWO_LAUNCHES));
+        if (s == STEPS / 3) { CHECK(rcw_set_step_form(h, RCW_STEP_ONE_LAUNCH)); CHECK(rcw_step_form(h, &step_form)); if (step_form != RCW_STEP_ONE_LAUNCH) return 1; }
         if (s == 2 * STEPS / 3) CHECK(rcw_set_step_form(h, 0));
         for (int a = 0; a < B; ++a) actions[a] = (uint8_t)(1 + lcg(&seed) % 4);
         CHECK(rcw_step(h, actions));

@@ -52,7 +52,7 @@ def test_plain_c_caller(oracle, tmp_path):
     mt = re.search(r"top_view_form=(\d+) top_checksum=([0-9a-f]{16})", res.stdout)
     assert mt, res.stdout
     assert int(mt.group(1)) == 3
-    assert "step_form=2" in res.stdout                                       # RCW_STEP_ONE_LAUNCH by the rule; the harness steps a third of its rollout in the other form
+    assert "step_form=1" in res.stdout                                       # RCW_STEP_TWO_LAUNCHES by the rule at 64 agents; the harness steps a third of its rollout in the one-launch form
     assert "fill_kernel=rcw_fill256_draw_kernel" in res.stdout           # the handle renders the top view: camera fill + drawing in one launch
     assert "top_view_form_alone=3" in res.stdout                         # 256 x 256 px: the stand-alone call takes draw -> store too
     ort = oracle.OracleBatch(64, seed=2024, out_of_bounds=1, render_top_view=1, pu_per_tu=32,

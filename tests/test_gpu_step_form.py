@@ -41,7 +41,7 @@ def test_the_rule_and_the_refusals(rcw):
     from raycastworlds_jl_amd import _capi
 
     SR = rcw.SingleRoomModule.SingleRoom
-    with SR(batch=4, seed=1, **CFG2) as env:
+    with SR(batch=1024, seed=1, **CFG2) as env:                              # 256 MiB of frames a step: the fill outlasts the casting half's five fans
         assert env.step_form() == "one-launch" and env.fill_kernel_name() == "rcw_fill256_cast_kernel"
         env.set_step_form("two-launches")
         assert env.step_form() == "two-launches" and env.fill_kernel_name() == "rcw_fill256_kernel"
@@ -49,6 +49,15 @@ def test_the_rule_and_the_refusals(rcw):
         assert env.step_form() == "one-launch"
         with pytest.raises(ValueError):
             env.set_step_form("three")
+    # ... and the batch must be large enough for it to pay (profiles/r06_small_batches.txt): by the rule a small batch keeps the two launches,
+    # on request it takes the one
+    for kw, small, large in ((CFG2, 256, 768), (CFG1, 512, 2048), (CFG3, 128, 512), (CFG5, 256, 512)):
+        with SR(batch=small, seed=1, **kw) as env:
+            assert env.step_form() == "two-launches", (kw, small)
+            env.set_step_form("one-launch"); assert env.step_form() == "one-launch"
+            env.set_step_form(None); assert env.step_form() == "two-launches"
+        with SR(batch=large, seed=1, **kw) as env:
+            assert env.step_form() == "one-launch", (kw, large)
     # what the one-launch form does not take: another camera height (another fill kernel), the top view (its drawing needs the state
     # the same launch commits)
     for kw in (dict(height_camera_view_pu=128, **CFG1), dict(height_camera_view_pu=100, **CFG1), dict(render_top_view=1, **CFG1)):
@@ -132,6 +141,7 @@ def test_episodes_restart_in_the_one_launch_form(rcw, oracle):
     B = 96
     for kw in (dict(out_of_bounds=1, **CFG2), dict(out_of_bounds=1, **CFG3), dict(T="Float64", out_of_bounds=1, **CFG1)):
         env, orc = _make(rcw, oracle, B, seed=3, auto_reset=True, **kw)
+        env.set_step_form("one-launch")
         assert env.step_form() == "one-launch"
         f = np.float64 if kw.get("T") == "Float64" else np.float32
         g = np.tile(np.array([[4, 6]], np.int32), (B, 1)); p = np.tile(np.array([[3.5, 4.5]], f), (B, 1)); d = np.full(B, 32, np.int32)
@@ -151,6 +161,7 @@ def test_episodes_restart_in_the_one_launch_form(rcw, oracle):
 def test_invalid_device_actions_keep_the_frame_in_the_one_launch_form(rcw, oracle):
     torch = pytest.importorskip("torch")
     env, orc = _make(rcw, oracle, 40, seed=4, **CFG2)
+    env.set_step_form("one-launch")
     assert env.step_form() == "one-launch"
     rng = np.random.default_rng(9)
     for s in range(12):
@@ -174,6 +185,7 @@ def test_rebound_observation_buffer_and_separate_renderers(rcw, oracle):
     """rcw_bind_obs alternates two caller buffers between one-launch steps; cast_rays! / update_camera_view! alone leave the slots alone."""
     torch = pytest.importorskip("torch")
     env, orc = _make(rcw, oracle, 24, seed=6, **CFG2)
+    env.set_step_form("one-launch")
     bufs = [torch.zeros((24, 256, 256), dtype=torch.int32, device="cuda") for _ in range(2)]
     rng = np.random.default_rng(1)
     for s in range(10):
@@ -192,6 +204,7 @@ def test_rebound_observation_buffer_and_separate_renderers(rcw, oracle):
 def test_a_captured_step_turns_the_handle_to_two_launches(rcw, oracle):
     torch = pytest.importorskip("torch")
     env, orc = _make(rcw, oracle, 48, seed=31, out_of_bounds=1, auto_reset=True, **CFG2)
+    env.set_step_form("one-launch")
     assert env.step_form() == "one-launch"
     stream = torch.cuda.Stream()
     env.set_stream(stream.cuda_stream)
@@ -231,6 +244,7 @@ def test_descriptors_are_refreshed_on_demand_and_live_once_their_pointers_are_ou
     (include/rcw.h, rcw_columns): rcw_columns recasts on demand; after rcw_columns_device_ptr every step refreshes them in place."""
     torch = pytest.importorskip("torch")
     env, orc = _make(rcw, oracle, 33, seed=12, out_of_bounds=1, **CFG2)
+    env.set_step_form("one-launch")
     assert env.step_form() == "one-launch"
     rng = np.random.default_rng(4)
     for s in range(6):
@@ -255,6 +269,7 @@ def test_descriptors_are_refreshed_on_demand_and_live_once_their_pointers_are_ou
     env.close()
     # ... and a masked reset BEHIND steps that left them stale: the masked agents' are fresh, the others' recast on demand
     env, orc = _make(rcw, oracle, 33, seed=13, out_of_bounds=1, **CFG2)
+    env.set_step_form("one-launch")
     for s in range(4):
         a = rng.integers(1, 5, 33).astype(np.uint8)
         rcw.act_(env, a); assert orc.step(a) == 0

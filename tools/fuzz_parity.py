@@ -24,6 +24,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split", "flat")
 split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the unit store kernels (units of 256 / 128 / 64 / 32 rows)
 flat_geometry = len(sys.argv) > 3 and sys.argv[3] == "flat"     # geometries of the flat store kernel; the two-kernel form is asked for
+one_launch_steps = 0
 two_kernel_forms = 0                                            # (rcw_set_top_view_form: by default it is taken only from 256 MiB a step)
 fails = 0
 O.set_num_threads(8)
@@ -82,6 +83,12 @@ for c in range(n_cfg):
                 two_kernel_forms += 1
             except Exception:                                  # the geometry does not take it: the automatic form stays
                 pass
+        if rng.integers(0, 2):                                 # the one-launch step (these batches are below where the rule takes it by itself)
+            try:
+                env.set_step_form("one-launch")
+                one_launch_steps += 1
+            except Exception:                                  # another camera height / a top view: the two launches stay
+                pass
         if rng.integers(0, 2):
             # arbitrary injected poses: uniform, exactly on tile boundaries, a hair off them, tile centres,
             # possibly inside the goal tile (a ray that starts inside an obstacle)
@@ -125,5 +132,5 @@ for c in range(n_cfg):
         print(f"config {c} FAILED: T64={T64} R={R} B={B} seed={seed} {kw}\n   {type(e).__name__}: {str(e)[:300]}")
         if fails >= 5:
             break
-print(f"{n_cfg} random configurations ({two_kernel_forms} with the two-kernel top view asked for and taken), {fails} mismatches")
+print(f"{n_cfg} random configurations ({two_kernel_forms} with the two-kernel top view asked for and taken, {one_launch_steps} with the one-launch step), {fails} mismatches")
 sys.exit(1 if fails else 0)
