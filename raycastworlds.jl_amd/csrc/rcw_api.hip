@@ -626,10 +626,6 @@ int plan_top_view(rcw_handle* h, int want_form, int want_runs, bool lenient)
     return RCW_OK;
 }
 
-#ifdef RCW_DEV_SWITCHES
-#include "dev/api_plan_export.inc"   // rcw_dev_plan_top_view / rcw_dev_top_view_rules: the rule and its table without a device (tests/test_top_view_plan.py)
-#endif
-
 // The one-launch step pays where the fill outlasts the casting half's own life: one casting workgroup marches FIVE fans one after the
 // other, so a small batch waits for it (4096 x 256 columns: 17 us of casting life under a 154 us fill; 64 agents: 22 us a step against
 // 12 for cast kernel + fill).  Measured crossovers (profiles/r06_small_batches.txt, frames of a step): 8x8 map, 256 columns ~128 MiB;
@@ -668,6 +664,10 @@ int plan_step_form(rcw_handle* h, int want)
     h->step_form_want = want;
     return RCW_OK;
 }
+
+#ifdef RCW_DEV_SWITCHES
+#include "dev/api_plan_export.inc"   // rcw_dev_plan_top_view / rcw_dev_top_view_rules / rcw_dev_step_rule: the rules without a device (tests/test_top_view_plan.py)
+#endif
 
 int validate_config(const rcw_config* c, int32_t batch)
 {

@@ -103,6 +103,36 @@ def test_the_devices_numbers_are_arguments(devlib):
         tool.HW.clear(); tool.HW.update(hw)
 
 
+def test_the_steps_rule_agrees_with_the_measured_crossovers(devlib):
+    """rcw_api.hip, step_one_launch_pays: the one-launch step where the fill outlasts the casting half's five serial fans.  For every line of
+    profiles/r06_small_batches.txt (us per step of both forms, four geometries, 1 .. 8192 agents) the rule picks the form that was measured
+    faster — ties within 6 % (one box's run-to-run spread at these sizes) may go either way."""
+    from raycastworlds_jl_amd import _capi
+
+    geos = {"cfg1": (8, 8, 64), "cfg2": (8, 8, 256), "cfg3": (16, 16, 512), "cfg5": (32, 32, 1024)}
+    devlib.rcw_dev_step_rule.argtypes = [C.POINTER(_capi.RcwConfig), C.c_int32, C.c_int32]
+    text = open(os.path.join(ROOT, "profiles", "r06_small_batches.txt")).read()
+    seen = wins = 0
+    for m in re.finditer(r"^(?:(cfg\d) )?B=\s*(\d+).*?one-launch\s+([\d.]+) us/step \| two-launches\s+([\d.]+) us/step", text, re.M):
+        geo, B, one, two = m.group(1) or "cfg2", int(m.group(2)), float(m.group(3)), float(m.group(4))
+        H, W, N = geos[geo]
+        cfg = _capi.default_config()
+        cfg.height_tile_map_tu, cfg.width_tile_map_tu, cfg.num_rays = H, W, N
+        rule = devlib.rcw_dev_step_rule(C.byref(cfg), B, 256)
+        assert rule in (0, 1)
+        seen += 1
+        if abs(one - two) <= 0.06 * min(one, two):
+            continue
+        assert rule == (1 if one < two else 0), (geo, B, one, two, rule)
+        wins += 1
+    assert seen >= 25 and wins >= 20
+    # what the geometry cannot take stays on two launches at any batch
+    cfg = _capi.default_config(); cfg.height_camera_view_pu = 128
+    assert devlib.rcw_dev_step_rule(C.byref(cfg), 65536, 256) == 0
+    cfg = _capi.default_config(); cfg.render_top_view = 1
+    assert devlib.rcw_dev_step_rule(C.byref(cfg), 65536, 256) == 0
+
+
 @pytest.mark.gpu
 def test_a_handle_takes_the_form_the_rule_gives_for_its_device(devlib, rcw):
     torch = pytest.importorskip("torch")

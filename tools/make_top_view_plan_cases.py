@@ -37,14 +37,15 @@ def plan(lib, H, W, pu, N, B, Hc=256, want_form=0, want_runs=0, **kw):
 
 
 def profile_shapes():
-    """(H, W, pu, N, B, form in a step, form alone) of every line of section (b) of the newest committed shapes table"""
+    """(H, W, pu, N, B, form in a step, form alone) of every shape line of the newest committed shapes table"""
     files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_top_view_shapes\.txt", f))
     text = open(os.path.join(ROOT, "profiles", files[-1])).read()
-    sec = text[text.index("== (b)"):text.index("== (c)")]
     out = []
-    for m in re.finditer(r"^map\s*(\d+)x\s*(\d+) pu\s*(\d+) N\s*(\d+) image\s*\d+x\s*\d+ B\s*(\d+) ([\w-]+): .*?stand-alone \(([\w-]+)\)", sec, re.M):
+    for m in re.finditer(r"^map\s*(\d+)x\s*(\d+) pu\s*(\d+) N\s*(\d+) image\s*\d+x\s*\d+ B\s*(\d+) ([\w-]+): .*?stand-alone \(([\w-]+)\)", text, re.M):
         H, W, pu, N, B = (int(m.group(k)) for k in range(1, 6))
-        out.append((H, W, pu, N, B, m.group(6), m.group(7)))
+        row = (H, W, pu, N, B, m.group(6), m.group(7))
+        if row not in out:                                    # (a table may hold a shape in several sections: with / without the profiler)
+            out.append(row)
     return files[-1], out
 
 
@@ -52,7 +53,7 @@ def cases(lib):
     name, shapes = profile_shapes()
     out = []
     for H, W, pu, N, B, form, alone in shapes:
-        out.append(dict(source=f"profiles/{name} (b)", H=H, W=W, pu=pu, N=N, B=B, Hc=256, recorded_form=form, recorded_form_alone=alone, plan=plan(lib, H, W, pu, N, B)))
+        out.append(dict(source=f"profiles/{name}", H=H, W=W, pu=pu, N=N, B=B, Hc=256, recorded_form=form, recorded_form_alone=alone, plan=plan(lib, H, W, pu, N, B)))
     extra = [
         ("kSideStreamMinBytes, one launch for fill + drawing at every batch size", [dict(H=8, W=8, pu=32, N=256, B=b) for b in (1, 16, 64, 256, 1024, 4096)]),
         ("kSideStreamMinBytes, another camera height: the side stream pays from 256 MiB of top view", [dict(H=8, W=8, pu=32, N=256, B=b, Hc=128) for b in (16, 255, 256, 1024, 4096)]),
