@@ -1172,6 +1172,10 @@ int rcw_reset(rcw_handle* h, const uint8_t* mask_host, uint64_t seed)
     int rc = check_handle(h); if (rc) return rc;
     const uint8_t* mask_dev = nullptr;
     rc = upload_mask(h, mask_host, &mask_dev); if (rc) return rc;
+    // (the seed is the HANDLE's: an agent that is done under auto_reset and NOT in the mask is re-sampled by its next action with the new
+    // seed — but the one-launch step has already cast that agent's successors from a preview drawn with the old one: every agent's slots are
+    // cast again by the next step, as a launch of its own)
+    if (seed != h->dev.seed && h->dev.auto_reset && mask_dev) h->spec_primed = false;
     h->dev.seed = seed;
     RCW_HIP(rcw_launch_reset(h->dev, mask_dev, h->stream));            // SR:110-132
     RCW_HIP(launch_step(h, nullptr, mask_dev));    // SR:134, SR:329

@@ -276,3 +276,31 @@ def test_descriptors_are_refreshed_on_demand_and_live_once_their_pointers_are_ou
     rcw.reset_(env, mask=mask, seed=6); orc.reset(mask=mask, seed=6)
     assert_state_equal(env, orc, where="masked reset behind stale descriptors")
     env.close()
+
+
+def test_a_masked_reset_with_a_new_seed_reaches_the_agents_it_does_not_touch(rcw, oracle):
+    """The reset generator's seed is the handle's (rcw_reset sets it for every agent): an agent that is DONE under auto_reset and is NOT in a
+    masked reset's mask is re-sampled by its next action with the NEW seed.  The one-launch step had cast that agent's successors from a
+    preview drawn with the old seed: rcw_reset must not leave those slots in place.  Every agent one forward move from its goal, one step
+    (all done), a masked reset of half of them with another seed, then steps: frames, poses, tile maps and episode counters against the oracle."""
+    B = 48
+    for kw in (dict(out_of_bounds=1, **CFG2), dict(out_of_bounds=1, **CFG3)):
+        env, orc = _make(rcw, oracle, B, seed=5, auto_reset=True, **kw)
+        env.set_step_form("one-launch")
+        g = np.tile(np.array([[4, 6]], np.int32), (B, 1)); p = np.tile(np.array([[3.5, 4.875]], np.float32), (B, 1)); d = np.full(B, 32, np.int32)
+        env.set_state(g, p, d); orc.set_state(g, p, d)
+        fwd = np.ones(B, np.uint8)
+        rcw.act_(env, fwd); assert orc.step(fwd) == 0
+        assert orc.done.all(), "the set-up did not bring the agents to their goal"
+        assert_state_equal(env, orc, where=f"all done {kw}")
+        mask = np.zeros(B, np.uint8); mask[::2] = 1
+        rcw.reset_(env, mask=mask, seed=4242); orc.reset(mask=mask, seed=4242)
+        assert_state_equal(env, orc, where=f"masked reset with a new seed {kw}")
+        rng = np.random.default_rng(3)
+        for s in range(6):
+            a = rng.integers(1, 5, B).astype(np.uint8)
+            rcw.act_(env, a); assert orc.step(a) == 0
+            assert_state_equal(env, orc, where=f"step {s} behind the masked reset {kw}")
+            np.testing.assert_array_equal(env.world.episode, orc.episode)
+        assert env.step_form() == "one-launch"
+        env.close()

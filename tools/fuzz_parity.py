@@ -24,6 +24,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split", "flat")
 split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the unit store kernels (units of 256 / 128 / 64 / 32 rows)
 flat_geometry = len(sys.argv) > 3 and sys.argv[3] == "flat"     # geometries of the flat store kernel; the two-kernel form is asked for
+step_geometry = len(sys.argv) > 3 and sys.argv[3] == "step"     # what the one-launch step takes (256-row camera view, no top view), asked for in every case:
+                                                                # 1 .. 1,500 view columns (a wavefront per agent, a workgroup per agent, the table's tail), maps of up to 40 x 40 tiles
 one_launch_steps = 0
 two_kernel_forms = 0                                            # (rcw_set_top_view_form: by default it is taken only from 256 MiB a step)
 fails = 0
@@ -46,6 +48,10 @@ for c in range(n_cfg):
               pu_per_tu=int(rng.choice([4, 8, 13, 32, 40, 52] if always_top else [4, 8, 13, 32])))
     R = str(rng.choice(["Float32", "Float64", "Int32", "Int64"]))
     B = int(rng.integers(1, 40))
+    if step_geometry:
+        kw.update(height_camera_view_pu=256, render_top_view=False, num_rays=int(rng.choice([1, 7, 64, 100, 255, 256, 257, 333, 512, 700, 1024, 1100, 1500])),
+                  height_tile_map_tu=int(rng.integers(3, 41)), width_tile_map_tu=int(rng.integers(3, 41)))
+        B = int(rng.choice([1, 3, 4, 5, 17, 64, 130]))
     if split_geometry:
         # image heights of 32 m rows with tiles that divide the store kernel's unit (256, 128, 64 or 32 rows)
         pu = int(rng.choice([8, 16, 32, 32, 64, 128]))
@@ -83,7 +89,7 @@ for c in range(n_cfg):
                 two_kernel_forms += 1
             except Exception:                                  # the geometry does not take it: the automatic form stays
                 pass
-        if rng.integers(0, 2):                                 # the one-launch step (these batches are below where the rule takes it by itself)
+        if step_geometry or rng.integers(0, 2):               # the one-launch step (these batches are below where the rule takes it by itself)
             try:
                 env.set_step_form("one-launch")
                 one_launch_steps += 1

@@ -61,10 +61,12 @@ if [ "$part" = 3 ]; then
   run tools/fuzz_parity.py 600 61002 top
   run tools/fuzz_parity.py 600 61003 split
   run tools/fuzz_parity.py 600 61004 flat
+  run tools/fuzz_parity.py 600 61005 step
   run tools/api_fuzz.py 120 61010 60
   run tools/api_fuzz.py 40 61011 60 sharded
   run tools/api_fuzz.py 30 61012 80 pairs
   echo "== tools/soak.py 100000" >> $out; timeout -k 10 600 python3 tools/soak.py 100000 2>&1 | tail -2 >> $out
+  echo "== tools/soak.py 100000 one" >> $out; timeout -k 10 600 python3 tools/soak.py 100000 one 2>&1 | tail -2 >> $out
   cat $out
   echo "part 3 done"
 fi

@@ -18,11 +18,14 @@ from oracle import oracle as O
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 top = len(sys.argv) > 2 and sys.argv[2] == "top"
+one = len(sys.argv) > 2 and sys.argv[2] == "one"           # the one-launch step (256 agents are below where the rule takes it by itself)
 B = 256
 kw = dict(height_tile_map_tu=8, width_tile_map_tu=8, num_rays=64)
 env = RCW.SingleRoomModule.SingleRoom(batch=B, seed=99, auto_reset=True, out_of_bounds=1, render_top_view=top, **kw)
 if top:
     env.set_top_view_form("two-kernels")                   # (256 agents would take the one-kernel form): side stream fork / join every step
+if one:
+    env.set_step_form("one-launch")
 orc = O.OracleBatch(B, seed=99, auto_reset=1, out_of_bounds=1, render=False, **kw)
 O.set_num_threads(16)
 rng = np.random.default_rng(0)
