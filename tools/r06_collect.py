@@ -71,6 +71,11 @@ halves = open(f"{G}/r06_spec_halves_final.txt").read()
 k1, k2 = kernel(rows, "rcw_fill256_cast_kernel"), kernel(rows2, "rcw_fill256_kernel<")
 kc = kernel(rows2, "rcw_cast_kernel")
 k5 = kernel(rows5, "rcw_fill256_cast_kernel")
+def probe(w, bit):
+    return float(re.search(rf"^{w} RCW_SPEC_DEBUG={bit}\s+([\d.]+) us/step", halves, re.M).group(1))
+alone = " / ".join(f"{probe(w, 2):.0f}" for w in ("cfg2", "cfg3", "cfg5"))
+inside = " / ".join(f"{probe(w, 0) - probe(w, 1):.0f}" for w in ("cfg2", "cfg3", "cfg5"))
+cast = " / ".join(re.search(rf"^{w} two launches.*?cast\s+([\d.]+) us", halves, re.M).group(1).split(".")[0] for w in ("cfg2", "cfg3", "cfg5"))
 earlier = open(f"{P}/r06_step_forms_development.txt").read() if os.path.exists(f"{P}/r06_step_forms_development.txt") else ""
 open(f"{P}/r06_step_forms.txt", "w").write(
     "Round 6 — RCW.act!(env, a) SR:333-340 in ONE launch (rcw_fill256_cast_kernel) against the cast kernel followed by the fill kernel, 1 MI355X,\n"
@@ -84,9 +89,9 @@ open(f"{P}/r06_step_forms.txt", "w").write(
     "\n== (3) what the casting half costs the launch: timing probes (development build, tools/r06_spec_halves.sh; RCW_SPEC_DEBUG bits: 1 = the casting\n"
     "       workgroups return at once (the fill half alone), 2 = the fill's do (the casting half alone), 4 = the casting half stores nothing,\n"
     "       8 = its turns' fans take no table loads, 16 = the current state's fan only; all but 0 give wrong frames)\n" + halves +
-    "\nReading.  The casting half alone is 32 / 207 / 284 us of work at cfg-2 / cfg-3 / cfg-5 (five fans an agent, two divisions a column and heading in\n"
-    "place of three table loads); inside the launch it costs 2 / 20 / 23 us (this table: whole launch - fill half alone), against 13 / 43 / 61 us of cast\n"
-    "kernel + a boundary in the two-launch step.  With its stores off (4) and its turns' loads off (8) — all five fans still marched — the launch is\n"
+    f"\nReading.  The casting half alone is {alone} us of work at cfg-2 / cfg-3 / cfg-5 (five fans an agent, two divisions a column and heading in\n"
+    f"place of three table loads); inside the launch it costs {inside} us (this table: whole launch - fill half alone), against {cast} us of cast\n"
+    "kernel (+ a boundary) in the two-launch step.  With its stores off (4) and its turns' loads off (8) — all five fans still marched — the launch is\n"
     "within a few us of the fill alone: what the casting half costs is its memory operations (1.07 x the frames' bytes by WRITE_SIZE), not its vector work.\n"
     "The shipped library (no probe code in its loops) runs the same launch 1-2 % faster than the development build measured here: block (1).\n" + earlier)
 
