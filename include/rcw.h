@@ -403,8 +403,8 @@ RCW_API int rcw_set_top_view_form(rcw_handle* h, int32_t form, int32_t runs);
  *                          frames the actions select.  Nothing inside a launch waits for anything else in it; the cast kernel and a
  *                          launch boundary leave the step's critical path.  rcw_reset / rcw_set_state (and a first step) cast as a
  *                          launch of their own, which leaves the slots of the agents it touches ready.
- * The rule: one launch where the geometry allows — a 256-row camera view (every BASELINE configuration) without a top view
- * (cfg.render_top_view = 0), fewer than 2^29 view columns in the batch — AND the batch is large enough for it to pay: a casting
+ * The rule: one launch where the geometry allows — a camera view the moving-window fill kernels take (256 rows: every BASELINE configuration;
+ * also 256 k, 128 and 64 rows, up to 8191) without a top view (cfg.render_top_view = 0), fewer than 2^29 view columns in the batch — AND the batch is large enough for it to pay: a casting
  * workgroup marches five fans one after the other, so the launch is no shorter than that, and below ~100-350 MiB of frames a step
  * (by map size and view columns: 512 agents at 8x8 / 256 columns, 400 at 32x32 / 1024 columns) the cast kernel followed by the fill
  * kernel is the faster step (rcw_set_step_form(RCW_STEP_ONE_LAUNCH) takes it at any batch).  A step captured into a HIP graph (hipStreamBeginCapture on

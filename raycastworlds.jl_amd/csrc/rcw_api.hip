@@ -649,7 +649,7 @@ int plan_step_form(rcw_handle* h, int want)
     RcwDev& d = h->dev;
     const bool eligible = rcw_step_spec_eligible(d) != 0;
     if (want == RCW_STEP_ONE_LAUNCH && !eligible)
-        return fail(RCW_ERR_UNSUPPORTED, "this handle does not take the one-launch step (a 256-row camera view without a top view, fewer than 2^29 view columns)");
+        return fail(RCW_ERR_UNSUPPORTED, "this handle does not take the one-launch step (a camera view of 256 k, 128 or 64 rows — up to 8191 — without a top view, fewer than 2^29 view columns)");
     const bool on = want == RCW_STEP_TWO_LAUNCHES ? false : (want == RCW_STEP_ONE_LAUNCH ? true : eligible && !h->step_captured && step_one_launch_pays(d));
     if (on) {
         for (int k = 0; k < 2; ++k) {

@@ -65,8 +65,8 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
 }
 
 // ---- the one-launch step's successors (rcw_fill256_cast_kernel) ----------------------------------------------------------
-// The word the fill reads for a column of a 256-row camera view: its padding (SR:436, 0..256) | colour id << 9.
-__device__ __forceinline__ uint32_t spec_word(int h, int cid) { return (uint32_t)column_padding(256, h) | ((uint32_t)cid << 9); }
+// The word the fill reads for a column: its padding (SR:436, 0..H_cam; H_cam <= 8191 here) | colour id << 13.
+__device__ __forceinline__ uint32_t spec_word(int Hc, int h, int cid) { return (uint32_t)column_padding(Hc, h) | ((uint32_t)cid << 13); }
 
 // Under the HBM-bound fill every vector-memory operation of the casting workgroups costs the launch several times what it costs alone,
 // every vector instruction next to nothing (profiles/r06_step_forms.txt): the casting half therefore LOADS only the ray's direction
@@ -126,7 +126,7 @@ __device__ __forceinline__ bool spec_fan(const RcwDev& p, const uint8_t* tb, int
             *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(col_h_a) + k * 4u) = h;
             *(col_c_a + k) = (uint8_t)cid;
         }
-        const uint16_t w = (uint16_t)spec_word(h, cid);
+        const uint16_t w = (uint16_t)spec_word(p.Hc, h, cid);
         uint16_t* const q = slot_a + k;
 #ifdef RCW_DEV_SWITCHES
         if (p.spec_debug & 4) { asm volatile("" :: "v"(w)); left |= r.oob; return; }   // (timing probe: no slot stores)
@@ -477,8 +477,8 @@ __device__ __forceinline__ void fill256_spec_body(const RcwDev& p, const uint8_t
             const uint32_t sel = act - 1u < (uint32_t)RCW_NUM_ACTIONS ? act : 0u;   // (an action outside 1..4: the agent is not stepped, SR:140)
             const uint32_t w = slots[(size_t)mine + (size_t)(4u * a + sel) * (size_t)p.N];   // [B][5][N]: (5 a + sel) N + (mine - a N)
             asm volatile("" :: "v"(w) : "memory");
-            pad_l = (int)(w & 0x1ffu);
-            colour_l = p.colour[(w >> 9) & 3u];
+            pad_l = (int)(w & 0x1fffu);
+            colour_l = p.colour[(w >> 13) & 3u];
         }
 #pragma unroll 4
         for (int l = 0; l < 64; ++l) {
@@ -491,6 +491,67 @@ __device__ __forceinline__ void fill256_spec_body(const RcwDev& p, const uint8_t
             v.z = pixel(r0 + 2, pad, 256, c, ceil_c, floor_c);
             v.w = pixel(r0 + 3, pad, 256, c, ceil_c, floor_c);
             store16<PLAIN>(out + (base + (long long)l * G) * 64 + lane, v);
+        }
+    }
+}
+
+// The same for the other camera heights the moving window takes (rcw_fill_window_kernel<M>, rcw_fill.hip): H_cam = 256 k (a chunk is one of
+// the k row blocks of a column: M = 1), 128 or 64 (a chunk holds M = 2 or 4 whole columns, which start at a multiple of M: their M words are one
+// 2 M-byte load).  The launcher takes this form below 2^31 chunks.
+template <int M>
+__device__ __forceinline__ void fill_window_spec_body(const RcwDev& p, const uint8_t* __restrict__ actions, const uint16_t* __restrict__ slots,
+                                                      u32x4* __restrict__ out, long long total_chunks, int block, int blocks, int n_shift)
+{
+    const int lane = threadIdx.x & 63;
+    const long long G = (long long)blocks * (kBlock / 64);
+    const long long g = (long long)block * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t ceil_c = p.ceiling_color, floor_c = p.floor_color;
+    const int Hc = p.Hc;
+    const uint32_t k = M == 1 ? (uint32_t)Hc >> 8 : 1u;   // chunks per column (M == 1)
+    const int sub = M == 1 ? 0 : lane / (64 / M);          // this lane's column within a chunk (M > 1)
+    const int r_lane = M == 1 ? lane * 4 : (lane - sub * (64 / M)) * 4;
+    for (long long base = g; base < total_chunks; base += G * 64) {
+        const long long mine = base + (long long)lane * G;
+        int pad_l[M], rb_l = 0;
+        uint32_t colour_l[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) { pad_l[j] = -1; colour_l[j] = 0u; }
+        if (mine < total_chunks) {
+            const uint32_t col0 = M == 1 ? (uint32_t)mine / k : (uint32_t)mine * (uint32_t)M;      // first (only) column of the chunk
+            const uint32_t a = n_shift >= 0 ? col0 >> n_shift : col0 / (uint32_t)p.N;              // (a chunk never spans two agents: N H_cam % 256 == 0 here)
+            rb_l = M == 1 ? (int)((uint32_t)mine - col0 * k) * 256 : 0;
+            const uint32_t act = actions[a];
+            asm volatile("" :: "v"(act) : "memory");
+            const uint32_t sel = act - 1u < (uint32_t)RCW_NUM_ACTIONS ? act : 0u;
+            struct __attribute__((aligned(2 * M))) Words { uint16_t w[M]; };
+            const Words ws = *reinterpret_cast<const Words*>(slots + ((size_t)col0 + (size_t)(4u * a + sel) * (size_t)p.N));   // [B][5][N]
+            asm volatile("" :: "v"(ws.w[0]) : "memory");
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                pad_l[j] = (int)(ws.w[j] & 0x1fffu);
+                colour_l[j] = p.colour[(ws.w[j] >> 13) & 3u];
+            }
+        }
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+            const int pad0 = __builtin_amdgcn_readlane(pad_l[0], l);
+            if (pad0 < 0) continue;            // wave-uniform: past the end
+            int pad = pad0;
+            uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)colour_l[0], l);
+#pragma unroll
+            for (int j = 1; j < M; ++j) {
+                const int pj = __builtin_amdgcn_readlane(pad_l[j], l);
+                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)colour_l[j], l);
+                pad = sub == j ? pj : pad;
+                c = sub == j ? cj : c;
+            }
+            const int r0 = (M == 1 ? __builtin_amdgcn_readlane(rb_l, l) : 0) + r_lane;
+            u32x4 v;
+            v.x = pixel(r0 + 0, pad, Hc, c, ceil_c, floor_c);
+            v.y = pixel(r0 + 1, pad, Hc, c, ceil_c, floor_c);
+            v.z = pixel(r0 + 2, pad, Hc, c, ceil_c, floor_c);
+            v.w = pixel(r0 + 3, pad, Hc, c, ceil_c, floor_c);
+            __builtin_nontemporal_store(v, out + (base + (long long)l * G) * 64 + lane);
         }
     }
 }
@@ -514,13 +575,20 @@ __device__ __forceinline__ void cast_successors(const RcwDev& p, const uint8_t* 
 template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
 __global__ __launch_bounds__(kBlock) void rcw_fill256_cast_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
                                                                   u32x4* __restrict__ out, long long total_cols, int fill_blocks,
-                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift, int cols)
+                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift, int cols,
+                                                                  int window /* 0: 256 rows; else M of rcw_fill_window_kernel<M>, total_cols = its chunks */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 #ifdef RCW_DEV_SWITCHES
     if (p.spec_debug & ((int)blockIdx.x < fill_blocks ? 2 : 1)) return;     // (timing probes: one half of the launch alone)
 #endif
-    if ((int)blockIdx.x < fill_blocks) { fill256_spec_body<false>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift); return; }
+    if ((int)blockIdx.x < fill_blocks) {
+        if (window == 0) fill256_spec_body<false>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
+        else if (window == 1) fill_window_spec_body<1>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
+        else if (window == 2) fill_window_spec_body<2>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
+        else fill_window_spec_body<4>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
+        return;
+    }
     cast_successors<T, TIE_LE, DIST_PRE, WAVE>(p, actions, mask, (int)blockIdx.x - fill_blocks, slots_out, lds, lds_words, cols);
 }
 
@@ -649,13 +717,17 @@ hipError_t rcw_launch_cast(const RcwDev& p, const uint8_t* actions_dev, const ui
     return hipGetLastError();
 }
 
-// The one-launch step (rcw_fill256_cast_kernel): the geometries that take it — a 256-row camera view filled by rcw_fill256_kernel's
-// window, no top view (its drawing needs the state the same launch commits), a batch of fewer than 2^29 view columns — the bytes of ONE
+// The one-launch step (rcw_fill256_cast_kernel): the geometries that take it — a camera view the moving window of rcw_fill256_kernel /
+// rcw_fill_window_kernel fills (256 k, 128 or 64 rows, up to 8191), no top view (its drawing needs the state the same launch commits), a
+// batch of fewer than 2^29 view columns and 2^31 chunks — the bytes of ONE
 // of its two slot buffers, and the launch: with_fill = the fill workgroups in front (a step); without, the casting workgroups alone
 // (they prime the slots behind a reset / set_state, or for a first step: the camera fill then follows as a launch of its own).
 int rcw_step_spec_eligible(const RcwDev& p)
 {
-    return p.top_view == nullptr && !p.fill_plain && (long long)p.B * p.N < (1ll << 29) && rcw_fill_takes_256(p, (long long)p.B * p.N) ? 1 : 0;
+    const long long cols = (long long)p.B * p.N;
+    if (p.top_view != nullptr || p.fill_plain || cols >= (1ll << 29) || p.Hc > 8191) return 0;                  // (the slot word holds a padding of 13 bits)
+    if (rcw_fill_window_columns(p, cols) < 0) return 0;                                                           // another fill kernel's camera height
+    return cols * p.Hc / 256 < (1ll << 31) ? 1 : 0;                                                              // chunk ids in 32 bits
 }
 size_t rcw_step_spec_slot_bytes(const RcwDev& p) { return (size_t)5 * (size_t)p.B * (size_t)p.N * sizeof(uint16_t); }
 hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, const uint8_t* mask_dev, const uint16_t* slots_in,
@@ -673,10 +745,13 @@ hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, con
     const size_t lds = wave ? (kBlock / 64) * per_agent : per_agent;
     const int lds_words = (int)(per_agent / 4);
     if (with_fill) {
+        const int window = rcw_fill_window_columns(p, total_cols);          // 0: the 256-row window; 1, 2, 4: rcw_fill_window_kernel<M>'s
+        const long long units = window == 0 ? total_cols : total_cols * p.Hc / 256;   // view columns / 1 KiB chunks of the batch
+        if (window < 0) return hipErrorInvalidValue;
         if (wave) RCW_DISPATCH_W(rcw_fill256_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
-                                 out, total_cols, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols);
+                                 out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols, window);
         else      RCW_DISPATCH_W(rcw_fill256_cast_kernel, false, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
-                                 out, total_cols, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols);
+                                 out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols, window);
     } else {
         if (wave) RCW_DISPATCH_W(rcw_cast_successors_kernel, true, dim3(cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev, slots_out, lds_words);
         else      RCW_DISPATCH_W(rcw_cast_successors_kernel, false, dim3(cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev, slots_out, lds_words);

@@ -551,6 +551,17 @@ hipError_t rcw_launch_fill(const RcwDev& p, const int32_t* col_h, const uint8_t*
 
 // (for the other translation units: does this geometry take rcw_fill256_kernel's window?)
 int rcw_fill_takes_256(const RcwDev& p, long long total_cols) { return fill_choice(p, total_cols) == kFill256 ? 1 : 0; }
+// ... or the window of rcw_fill_window_kernel<M>: 0 for the 256-row kernel, M = 1 / 2 / 4 for the window kernel's forms, -1 for the other fill kernels
+int rcw_fill_window_columns(const RcwDev& p, long long total_cols)
+{
+    switch (fill_choice(p, total_cols)) {
+    case kFill256: return 0;
+    case kFillWindow1: return 1;
+    case kFillWindow2: return 2;
+    case kFillWindow4: return 4;
+    default: return -1;
+    }
+}
 
 hipError_t rcw_launch_expand(const RcwDev& p, const int32_t* col_h, const uint8_t* col_c,
                              int32_t count, uint32_t* frames, hipStream_t s)

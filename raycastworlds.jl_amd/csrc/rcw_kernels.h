@@ -129,6 +129,7 @@ int32_t rcw_top_plane_words(const RcwDev& p);
 int rcw_fill_flat_cols(const RcwDev& p);   // rcw_fill_flat_kernel: columns a chunk may touch at this camera height, 0: not taken
 const char* rcw_fill_kernel_name(const RcwDev& p, long long total_cols);   // the kernel rcw_launch_fill takes
 int rcw_fill_takes_256(const RcwDev& p, long long total_cols);              // ... is rcw_fill256_kernel (what the fused launches build on)
+int rcw_fill_window_columns(const RcwDev& p, long long total_cols);         // ... 0: rcw_fill256_kernel, 1 / 2 / 4: rcw_fill_window_kernel<M>, -1: another one (the one-launch step takes the first four)
 size_t rcw_top_plane_bytes(const RcwDev& p);
 size_t rcw_top_codes_bytes(const RcwDev& p);
 struct RcwHw { int cus, lds_per_cu, waves_per_cu; };       // what the top view's rule needs of the device (hipDeviceProp_t: multiProcessorCount, sharedMemPerBlock, maxThreadsPerMultiProcessor / 64)

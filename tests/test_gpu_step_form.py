@@ -58,9 +58,15 @@ def test_the_rule_and_the_refusals(rcw):
             env.set_step_form(None); assert env.step_form() == "two-launches"
         with SR(batch=large, seed=1, **kw) as env:
             assert env.step_form() == "one-launch", (kw, large)
-    # what the one-launch form does not take: another camera height (another fill kernel), the top view (its drawing needs the state
-    # the same launch commits)
-    for kw in (dict(height_camera_view_pu=128, **CFG1), dict(height_camera_view_pu=100, **CFG1), dict(render_top_view=1, **CFG1)):
+    # the other camera heights of the moving window (rcw_fill_window_kernel's: 256 k, 128, 64 rows) take it too
+    for hc in (64, 128, 512, 768, 1024):
+        with SR(batch=4, seed=1, height_camera_view_pu=hc, **CFG1) as env:
+            assert env.step_form() == "two-launches"                        # (4 agents: the rule)
+            env.set_step_form("one-launch"); assert env.step_form() == "one-launch" and env.fill_kernel_name() == "rcw_fill256_cast_kernel"
+    # what the one-launch form does not take: a camera height of the flat / frame kernels, a slot word's 13 bits of padding, the top view (its
+    # drawing needs the state the same launch commits)
+    for kw in (dict(height_camera_view_pu=100, **CFG1), dict(height_camera_view_pu=20, **CFG1), dict(height_camera_view_pu=8192, **CFG1),
+               dict(height_camera_view_pu=128, height_tile_map_tu=8, width_tile_map_tu=8, num_rays=33), dict(render_top_view=1, **CFG1)):
         with SR(batch=4, seed=1, **kw) as env:
             assert env.step_form() == "two-launches"
             with pytest.raises(_capi.RcwError) as e:
@@ -83,6 +89,11 @@ SHAPES = [
     ("Float64, 600 columns", dict(T="Float64", height_tile_map_tu=8, width_tile_map_tu=8, num_rays=600), 3),
     ("the other march", dict(dda_tie_break=1, dda_distance=1, normalize_mode=1, **CFG1), 6),
     ("inc > radius", dict(position_increment_wu=0.25, player_radius_wu=0.125, out_of_bounds=0, **CFG1), 12),
+    ("128 rows (two columns a chunk)", dict(height_camera_view_pu=128, **CFG2), 9),
+    ("64 rows (four columns a chunk), 100 columns", dict(height_camera_view_pu=64, height_tile_map_tu=7, width_tile_map_tu=11, num_rays=100), 11),
+    ("512 rows, a workgroup per agent", dict(height_camera_view_pu=512, height_tile_map_tu=9, width_tile_map_tu=9, num_rays=300), 5),
+    ("768 rows (three chunks a column), Float64", dict(T="Float64", height_camera_view_pu=768, **CFG1), 6),
+    ("1024 rows", dict(height_camera_view_pu=1024, height_tile_map_tu=6, width_tile_map_tu=6, num_rays=33), 7),
 ]
 
 

@@ -127,8 +127,10 @@ def test_the_steps_rule_agrees_with_the_measured_crossovers(devlib):
         wins += 1
     assert seen >= 25 and wins >= 20
     # what the geometry cannot take stays on two launches at any batch
-    cfg = _capi.default_config(); cfg.height_camera_view_pu = 128
+    cfg = _capi.default_config(); cfg.height_camera_view_pu = 100          # (a camera height of the flat fill kernel)
     assert devlib.rcw_dev_step_rule(C.byref(cfg), 65536, 256) == 0
+    cfg = _capi.default_config(); cfg.height_camera_view_pu = 128          # (the window kernels' heights take it)
+    assert devlib.rcw_dev_step_rule(C.byref(cfg), 65536, 256) == 1 and devlib.rcw_dev_step_rule(C.byref(cfg), 64, 256) == 0
     cfg = _capi.default_config(); cfg.render_top_view = 1
     assert devlib.rcw_dev_step_rule(C.byref(cfg), 65536, 256) == 0
 

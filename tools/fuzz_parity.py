@@ -24,7 +24,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 always_top = len(sys.argv) > 3 and sys.argv[3] in ("top", "split", "flat")
 split_geometry = len(sys.argv) > 3 and sys.argv[3] == "split"   # geometries of the unit store kernels (units of 256 / 128 / 64 / 32 rows)
 flat_geometry = len(sys.argv) > 3 and sys.argv[3] == "flat"     # geometries of the flat store kernel; the two-kernel form is asked for
-step_geometry = len(sys.argv) > 3 and sys.argv[3] == "step"     # what the one-launch step takes (256-row camera view, no top view), asked for in every case:
+step_geometry = len(sys.argv) > 3 and sys.argv[3] == "step"     # what the one-launch step takes (a camera view of 256 k / 128 / 64 rows, no top view), asked for in every case:
                                                                 # 1 .. 1,500 view columns (a wavefront per agent, a workgroup per agent, the table's tail), maps of up to 40 x 40 tiles
 one_launch_steps = 0
 two_kernel_forms = 0                                            # (rcw_set_top_view_form: by default it is taken only from 256 MiB a step)
@@ -49,7 +49,7 @@ for c in range(n_cfg):
     R = str(rng.choice(["Float32", "Float64", "Int32", "Int64"]))
     B = int(rng.integers(1, 40))
     if step_geometry:
-        kw.update(height_camera_view_pu=256, render_top_view=False, num_rays=int(rng.choice([1, 7, 64, 100, 255, 256, 257, 333, 512, 700, 1024, 1100, 1500])),
+        kw.update(height_camera_view_pu=int(rng.choice([256, 256, 256, 64, 128, 512, 768, 1024, 2048])), render_top_view=False, num_rays=int(rng.choice([1, 7, 64, 100, 255, 256, 257, 333, 512, 700, 1024, 1100, 1500])),
                   height_tile_map_tu=int(rng.integers(3, 41)), width_tile_map_tu=int(rng.integers(3, 41)))
         B = int(rng.choice([1, 3, 4, 5, 17, 64, 130]))
     if split_geometry:
