@@ -1725,7 +1725,7 @@ int rcw_set_step_form(rcw_handle* h, int32_t form)
 int rcw_fill_kernel_name(rcw_handle* h, char* buf, int32_t buflen)
 {
     if (!h || !buf || buflen < 1) return fail(RCW_ERR_INVALID_ARGUMENT, "bad argument");
-    std::snprintf(buf, (size_t)buflen, "%s", h->spec_on ? "rcw_fill256_cast_kernel" : rcw_fill_kernel_name(h->dev, (long long)h->dev.B * h->dev.N));
+    std::snprintf(buf, (size_t)buflen, "%s", h->spec_on ? (h->dev.Hc == 256 ? "rcw_fill256_cast_kernel" : "rcw_fill_window_cast_kernel") : rcw_fill_kernel_name(h->dev, (long long)h->dev.B * h->dev.N));
     return RCW_OK;
 }
 

@@ -66,7 +66,16 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
 
 // ---- the one-launch step's successors (rcw_fill256_cast_kernel) ----------------------------------------------------------
 // The word the fill reads for a column: its padding (SR:436, 0..H_cam; H_cam <= 8191 here) | colour id << 13.
-__device__ __forceinline__ uint32_t spec_word(int Hc, int h, int cid) { return (uint32_t)column_padding(Hc, h) | ((uint32_t)cid << 13); }
+// column_padding(Hc, h) for 1 <= Hc <= 8191 in four 32-bit vector instructions (clamp, subtract, halve, clamp) — the general form's 64-bit
+// difference and its compares, five fans a column, cost the launch 25 us at 16384 agents x 512 columns when the camera height stopped being a
+// compile-time 256 (profiles/r06_step_forms.txt (5)).  With g = clamp(h, -Hc - 2, Hc): Hc - g is in [0, 2 Hc + 2]; its half is 0 from
+// h >= Hc - 1 on (SR:433), (Hc - h) / 2 in between (SR:436), and Hc + 1 -> Hc where the general form clamps (tests/test_host_logic.py replays both).
+__device__ __forceinline__ int spec_padding(int Hc, int h)
+{
+    const int g = min(max(h, -Hc - 2), Hc);
+    return min((Hc - g) >> 1, Hc);
+}
+__device__ __forceinline__ uint32_t spec_word(int Hc, int h, int cid) { return (uint32_t)spec_padding(Hc, h) | ((uint32_t)cid << 13); }
 
 // Under the HBM-bound fill every vector-memory operation of the casting workgroups costs the launch several times what it costs alone,
 // every vector instruction next to nothing (profiles/r06_step_forms.txt): the casting half therefore LOADS only the ray's direction
@@ -575,18 +584,32 @@ __device__ __forceinline__ void cast_successors(const RcwDev& p, const uint8_t* 
 template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
 __global__ __launch_bounds__(kBlock) void rcw_fill256_cast_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
                                                                   u32x4* __restrict__ out, long long total_cols, int fill_blocks,
-                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift, int cols,
-                                                                  int window /* 0: 256 rows; else M of rcw_fill_window_kernel<M>, total_cols = its chunks */)
+                                                                  const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift, int cols)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 #ifdef RCW_DEV_SWITCHES
     if (p.spec_debug & ((int)blockIdx.x < fill_blocks ? 2 : 1)) return;     // (timing probes: one half of the launch alone)
 #endif
+    if ((int)blockIdx.x < fill_blocks) { fill256_spec_body<false>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift); return; }
+    cast_successors<T, TIE_LE, DIST_PRE, WAVE>(p, actions, mask, (int)blockIdx.x - fill_blocks, slots_out, lds, lds_words, cols);
+}
+
+// The same launch for the other camera heights of the moving window (256 k, 128, 64 rows): the fill workgroups run rcw_fill_window_kernel<M>'s
+// chunk logic (fill_window_spec_body<M>; M by a kernel argument: 1, 2 or 4).  A kernel of its own, so that rcw_fill256_cast_kernel — every
+// BASELINE configuration's step — carries nothing but its own code.  (The 20-25 us its launch lost at 8192 agents x 1024 columns when these heights
+// first went in was NOT these bodies: one box, four libraries, traced it to the slot word's padding computed from a run-time camera height —
+// spec_padding above; profiles/r06_step_forms.txt (5).)
+template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
+__global__ __launch_bounds__(kBlock) void rcw_fill_window_cast_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
+                                                                      u32x4* __restrict__ out, long long total_chunks, int fill_blocks,
+                                                                      const uint16_t* __restrict__ slots_in, uint16_t* __restrict__ slots_out, int lds_words, int n_shift, int cols,
+                                                                      int window)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((int)blockIdx.x < fill_blocks) {
-        if (window == 0) fill256_spec_body<false>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
-        else if (window == 1) fill_window_spec_body<1>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
-        else if (window == 2) fill_window_spec_body<2>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
-        else fill_window_spec_body<4>(p, actions, slots_in, out, total_cols, (int)blockIdx.x, fill_blocks, n_shift);
+        if (window == 1) fill_window_spec_body<1>(p, actions, slots_in, out, total_chunks, (int)blockIdx.x, fill_blocks, n_shift);
+        else if (window == 2) fill_window_spec_body<2>(p, actions, slots_in, out, total_chunks, (int)blockIdx.x, fill_blocks, n_shift);
+        else fill_window_spec_body<4>(p, actions, slots_in, out, total_chunks, (int)blockIdx.x, fill_blocks, n_shift);
         return;
     }
     cast_successors<T, TIE_LE, DIST_PRE, WAVE>(p, actions, mask, (int)blockIdx.x - fill_blocks, slots_out, lds, lds_words, cols);
@@ -748,10 +771,17 @@ hipError_t rcw_launch_step_spec(const RcwDev& p, const uint8_t* actions_dev, con
         const int window = rcw_fill_window_columns(p, total_cols);          // 0: the 256-row window; 1, 2, 4: rcw_fill_window_kernel<M>'s
         const long long units = window == 0 ? total_cols : total_cols * p.Hc / 256;   // view columns / 1 KiB chunks of the batch
         if (window < 0) return hipErrorInvalidValue;
-        if (wave) RCW_DISPATCH_W(rcw_fill256_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
-                                 out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols, window);
-        else      RCW_DISPATCH_W(rcw_fill256_cast_kernel, false, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
-                                 out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols, window);
+        if (window == 0) {
+            if (wave) RCW_DISPATCH_W(rcw_fill256_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
+                                     out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols);
+            else      RCW_DISPATCH_W(rcw_fill256_cast_kernel, false, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
+                                     out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols);
+        } else {
+            if (wave) RCW_DISPATCH_W(rcw_fill_window_cast_kernel, true, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
+                                     out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols, window);
+            else      RCW_DISPATCH_W(rcw_fill_window_cast_kernel, false, dim3(fill_blocks + cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev,
+                                     out, units, fill_blocks, slots_in, slots_out, lds_words, n_shift, icols, window);
+        }
     } else {
         if (wave) RCW_DISPATCH_W(rcw_cast_successors_kernel, true, dim3(cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev, slots_out, lds_words);
         else      RCW_DISPATCH_W(rcw_cast_successors_kernel, false, dim3(cast_blocks), dim3(kBlock), lds, p, actions_dev, mask_dev, slots_out, lds_words);

@@ -62,7 +62,7 @@ def test_the_rule_and_the_refusals(rcw):
     for hc in (64, 128, 512, 768, 1024):
         with SR(batch=4, seed=1, height_camera_view_pu=hc, **CFG1) as env:
             assert env.step_form() == "two-launches"                        # (4 agents: the rule)
-            env.set_step_form("one-launch"); assert env.step_form() == "one-launch" and env.fill_kernel_name() == "rcw_fill256_cast_kernel"
+            env.set_step_form("one-launch"); assert env.step_form() == "one-launch" and env.fill_kernel_name() == "rcw_fill_window_cast_kernel"
     # what the one-launch form does not take: a camera height of the flat / frame kernels, a slot word's 13 bits of padding, the top view (its
     # drawing needs the state the same launch commits)
     for kw in (dict(height_camera_view_pu=100, **CFG1), dict(height_camera_view_pu=20, **CFG1), dict(height_camera_view_pu=8192, **CFG1),

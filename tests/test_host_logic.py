@@ -757,3 +757,25 @@ def test_draw_kernel_leaves_out_only_pixels_that_other_lines_draw(oracle):
             total_all += sum(_line_geom(e, ip, jp)[0] + 1 for e in ends); total_walked += nwalk
         orc.close()
     assert total_walked < 0.75 * total_all          # (and it is worth it: a quarter of the pixel-steps, at least, over these shapes)
+
+
+def test_the_slot_words_padding_is_column_padding():
+    """rcw_cast.hip `spec_padding` (the one-launch step's slot word, four 32-bit instructions) against rcw_device.h `column_padding` (SR:433-436: 0 from
+    h >= H_cam - 1 on, else (H_cam - h) / 2 in 64 bits, clamped to H_cam), both replayed here: every camera height the one-launch step takes a sample of,
+    every height_line_pu around the boundaries and across the whole Int32 range."""
+    def column_padding(Hc, h):
+        h = h.astype(np.int64)
+        pad = (Hc - h) // 2                                                  # (Hc - h > 0 wherever it is used)
+        return np.where(h >= Hc - 1, 0, np.minimum(pad, Hc))
+
+    def spec_padding(Hc, h):
+        g = np.minimum(np.maximum(h.astype(np.int64), -Hc - 2), Hc)
+        assert (np.abs(Hc - g) < 2 ** 31).all()                              # (the device computes in Int32)
+        return np.minimum((Hc - g) >> 1, Hc)
+
+    rng = np.random.default_rng(1)
+    edge = np.array([-2 ** 31, -2 ** 31 + 1, -2 ** 30, -70000, -8194, -8193, -8192, -1, 0, 1, 2 ** 30, 2 ** 31 - 2, 2 ** 31 - 1], dtype=np.int64)
+    for Hc in [1, 2, 3, 63, 64, 100, 128, 255, 256, 257, 512, 768, 1024, 4096, 8190, 8191] + [int(v) for v in rng.integers(1, 8192, 40)]:
+        near = np.arange(-3 * Hc - 8, 3 * Hc + 8, dtype=np.int64)
+        h = np.concatenate([edge, near, rng.integers(-2 ** 31, 2 ** 31, 20000)]).astype(np.int64)
+        np.testing.assert_array_equal(spec_padding(Hc, h), column_padding(Hc, h), err_msg=f"H_cam {Hc}")

@@ -64,7 +64,7 @@ def test_the_case_lists_cover_every_shipped_instantiation_of_the_flat_kernels():
     assert "rcw_top_store_units_kernel<false, 2>" not in names
     assert not [n for n in names if re.match(r"rcw_fill_flat_kernel<\w+, \d+, true>", n)], names
     # the step's kernels: <T, TIE, DIST> of the cast kernel, <T, TIE, DIST, WAVE> of the one-launch step and of what primes its slots
-    for family, count in (("rcw_cast_kernel<", 8), ("rcw_fill256_cast_kernel<", 16), ("rcw_cast_successors_kernel<", 16)):
+    for family, count in (("rcw_cast_kernel<", 8), ("rcw_fill256_cast_kernel<", 16), ("rcw_fill_window_cast_kernel<", 16), ("rcw_cast_successors_kernel<", 16)):
         assert len([n for n in names if n.startswith(family)]) == count, (family, sorted(n for n in names if n.startswith(family)))
 
 
