@@ -155,18 +155,20 @@ def test_top_view_forms_under_every_unpinned_switch(rcw, oracle, T):
 @pytest.mark.gpu
 @pytest.mark.parametrize("T", ["Float32", "Float64"])
 def test_step_kernels_under_every_unpinned_switch(rcw, oracle, T):
-    """<T, TIE, DIST> of rcw_cast_kernel (the two-launch step) and <T, TIE, DIST, WAVE> of rcw_fill256_cast_kernel / rcw_cast_successors_kernel
-    (the one-launch step and what primes its slots; WAVE: a wavefront per agent up to 256 view columns, a workgroup per agent beyond): all four
+    """<T, TIE, DIST> of rcw_cast_kernel (the two-launch step) and <T, TIE, DIST, WAVE> of rcw_fill256_cast_kernel / rcw_fill_window_cast_kernel /
+    rcw_cast_successors_kernel (the one-launch step at 256 rows, at the window's other heights, and what primes its slots; WAVE: a wavefront per agent up to 256 view columns, a workgroup per agent beyond): all four
     settings of the two unpinned cast_ray switches, both casting shapes, both forms, a masked reset in between, auto_reset on."""
     rng = np.random.default_rng(12)
     for tie in (0, 1):
         for dist in (0, 1):
             for N in (96, 300):
-                for form in ("one-launch", "two-launches"):
+                for form, hc in (("one-launch", 256), ("one-launch", 128), ("two-launches", 256)):   # (128 rows: rcw_fill_window_cast_kernel)
                     env, orc = _make(rcw, oracle, 7, 18, T=T, auto_reset=True, out_of_bounds=1, dda_tie_break=tie, dda_distance=dist,
-                                     height_tile_map_tu=7, width_tile_map_tu=9, num_rays=N)
+                                     height_tile_map_tu=7, width_tile_map_tu=9, num_rays=N, height_camera_view_pu=hc)
                     env.set_step_form(form)
                     assert env.step_form() == form
+                    if form == "one-launch":
+                        assert env.fill_kernel_name() == ("rcw_fill256_cast_kernel" if hc == 256 else "rcw_fill_window_cast_kernel")
                     _steps(rcw, env, orc, rng, 5, False)
                     mask = np.array([1, 0, 1, 1, 0, 0, 1], dtype=np.uint8)
                     rcw.reset_(env, mask=mask, seed=8); orc.reset(mask=mask, seed=8)

@@ -75,6 +75,8 @@ def probe(w, bit):
     return float(re.search(rf"^{w} RCW_SPEC_DEBUG={bit}\s+([\d.]+) us/step", halves, re.M).group(1))
 alone = " / ".join(f"{probe(w, 2):.0f}" for w in ("cfg2", "cfg3", "cfg5"))
 inside = " / ".join(f"{probe(w, 0) - probe(w, 1):.0f}" for w in ("cfg2", "cfg3", "cfg5"))
+memops = " / ".join(f"{probe(w, 0) - probe(w, 12):.0f}" for w in ("cfg2", "cfg3", "cfg5"))
+fans = " / ".join(f"{probe(w, 0) - probe(w, 16):.0f}" for w in ("cfg2", "cfg3", "cfg5"))
 cast = " / ".join(re.search(rf"^{w} two launches.*?cast\s+([\d.]+) us", halves, re.M).group(1).split(".")[0] for w in ("cfg2", "cfg3", "cfg5"))
 earlier = open(f"{P}/r06_step_forms_development.txt").read() if os.path.exists(f"{P}/r06_step_forms_development.txt") else ""
 open(f"{P}/r06_step_forms.txt", "w").write(
@@ -91,9 +93,11 @@ open(f"{P}/r06_step_forms.txt", "w").write(
     "       8 = its turns' fans take no table loads, 16 = the current state's fan only; all but 0 give wrong frames)\n" + halves +
     f"\nReading.  The casting half alone is {alone} us of work at cfg-2 / cfg-3 / cfg-5 (five fans an agent, two divisions a column and heading in\n"
     f"place of three table loads); inside the launch it costs {inside} us (this table: whole launch - fill half alone), against {cast} us of cast\n"
-    "kernel (+ a boundary) in the two-launch step.  With its stores off (4) and its turns' loads off (8) — all five fans still marched — the launch is\n"
-    "within a few us of the fill alone: what the casting half costs is its memory operations (1.07 x the frames' bytes by WRITE_SIZE), not its vector work.\n"
-    "The shipped library (no probe code in its loops) runs the same launch 1-2 % faster than the development build measured here: block (1).\n" + earlier)
+    f"kernel (+ a boundary) in the two-launch step.  Of that, its stores and its turns' table loads (bits 4 + 8 off, all five fans still marched) are\n"
+    f"{memops} us and the four successors' fans (bit 16: the current state's fan only) {fans} us: at the large batches the cost follows the casting\n"
+    "wavefronts' instruction path, which shares each SIMD with a fill wavefront — (5) below is the same finding from the other side (thirty extra\n"
+    "branches in that path were 25 us).  The shipped library has no probe code in that path and runs the same launch 1-3 % faster than the development\n"
+    "build measured here: block (1) — so the shipped launch's cost of casting is below this table's.\n" + earlier)
 
 # ---- the top view, what it adds to a step now that the step beside it is one launch ------------------------------------------------------------
 if os.path.exists(f"{G}/r06_top_shapes_plain.txt"):
