@@ -214,7 +214,7 @@ def test_camera_height_sweep(rcw, oracle):
 
 @pytest.mark.gpu
 def test_turning_assignment_under_any_grid(rcw, oracle, monkeypatch):
-    """rcw_top_store_flat_kernel's wavefront -> chunk assignment turns by 33 slots a group (DESIGN.md §4.4); the walk through a group's
+    """rcw_top_store_flat_kernel's wavefront -> chunk assignment turns by 33 slots a group (docs/top_view.md); the walk through a group's
     slots wraps at the number of wavefronts, which follows the device's CU count: other grids (development build: RCW_TOP_STORE_GRID,
     1 .. 257 workgroups, i.e. turns of 33 mod 4 .. 33 mod 1028) and other turns (RCW_TOP_ROTATE 0 / 5) write the same pixels."""
     rng = np.random.default_rng(11)
