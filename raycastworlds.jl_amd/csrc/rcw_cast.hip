@@ -66,10 +66,10 @@ __device__ __forceinline__ bool cast_column(const RcwDev& p, const uint8_t* tb, 
 
 // ---- the one-launch step's successors (rcw_fill256_cast_kernel) ----------------------------------------------------------
 // The word the fill reads for a column: its padding (SR:436, 0..H_cam; H_cam <= 8191 here) | colour id << 13.
-// column_padding(Hc, h) for 1 <= Hc <= 8191 in four 32-bit vector instructions (clamp, subtract, halve, clamp) — the general form's 64-bit
-// difference and its compares, five fans a column, cost the launch 25 us at 16384 agents x 512 columns when the camera height stopped being a
-// compile-time 256 (profiles/r06_step_forms.txt (5)).  With g = clamp(h, -Hc - 2, Hc): Hc - g is in [0, 2 Hc + 2]; its half is 0 from
-// h >= Hc - 1 on (SR:433), (Hc - h) / 2 in between (SR:436), and Hc + 1 -> Hc where the general form clamps (tests/test_host_logic.py replays both).
+// column_padding(Hc, h) for 1 <= Hc <= 8191 in four 32-bit vector instructions (clamp, subtract, halve, clamp) instead of the general form's
+// 64-bit difference, two compares and a divergent branch — five fans a column.  With g = clamp(h, -Hc - 2, Hc): Hc - g is in [0, 2 Hc + 2]; its
+// half is 0 from h >= Hc - 1 on (SR:433), (Hc - h) / 2 in between (SR:436), and Hc + 1 -> Hc where the general form clamps
+// (tests/test_host_logic.py replays both over the Int32 range).
 __device__ __forceinline__ int spec_padding(int Hc, int h)
 {
     const int g = min(max(h, -Hc - 2), Hc);
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(kBlock) void rcw_fill256_cast_kernel(const RcwDev p
 // The same launch for the other camera heights of the moving window (256 k, 128, 64 rows): the fill workgroups run rcw_fill_window_kernel<M>'s
 // chunk logic (fill_window_spec_body<M>; M by a kernel argument: 1, 2 or 4).  A kernel of its own, so that rcw_fill256_cast_kernel — every
 // BASELINE configuration's step — carries nothing but its own code.  (The 20-25 us its launch lost at 8192 agents x 1024 columns when these heights
-// first went in was NOT these bodies: one box, four libraries, traced it to the slot word's padding computed from a run-time camera height —
-// spec_padding above; profiles/r06_step_forms.txt (5).)
+// first went in was NOT these bodies, nor anything else in the source: the changed casting code had moved the fill's chunk loop off the start of a
+// 64-byte line of the code — seven builds on one box, profiles/r06_step_forms.txt (5).  This file is compiled with -falign-loops=64 since.)
 template <typename T, bool TIE_LE, bool DIST_PRE, bool WAVE>
 __global__ __launch_bounds__(kBlock) void rcw_fill_window_cast_kernel(const RcwDev p, const uint8_t* __restrict__ actions, const uint8_t* __restrict__ mask,
                                                                       u32x4* __restrict__ out, long long total_chunks, int fill_blocks,
