@@ -94,10 +94,10 @@ open(f"{P}/r06_step_forms.txt", "w").write(
     f"\nReading.  The casting half alone is {alone} us of work at cfg-2 / cfg-3 / cfg-5 (five fans an agent, two divisions a column and heading in\n"
     f"place of three table loads); inside the launch it costs {inside} us (this table: whole launch - fill half alone), against {cast} us of cast\n"
     f"kernel (+ a boundary) in the two-launch step.  Of that, its stores and its turns' table loads (bits 4 + 8 off, all five fans still marched) are\n"
-    f"{memops} us and the four successors' fans (bit 16: the current state's fan only) {fans} us: at the large batches the cost follows the casting\n"
-    "wavefronts' instruction path, which shares each SIMD with a fill wavefront — (5) below is the same finding from the other side (thirty extra\n"
-    "branches in that path were 25 us).  The shipped library has no probe code in that path and runs the same launch 1-3 % faster than the development\n"
-    "build measured here: block (1) — so the shipped launch's cost of casting is below this table's.\n" + earlier)
+    f"{memops} us and the four successors' fans (bit 16: the current state's fan only) {fans} us: at cfg-5 the cost is mostly what the casting half\n"
+    "writes and reads (84 MB of slot words a launch beside 8 GiB of frames on an HBM-bound launch), at cfg-3 mostly the marching of the successors.\n"
+    "Both builds are compiled with every loop on a 64-byte line of the code since (5) below; before, the development build's chunk loop lay off a line\n"
+    "and its launch was 30-36 us longer than the shipped one's (1271 / 1297 us at cfg-3 / cfg-5).\n" + earlier)
 
 # ---- the top view, what it adds to a step now that the step beside it is one launch ------------------------------------------------------------
 if os.path.exists(f"{G}/r06_top_shapes_plain.txt"):
