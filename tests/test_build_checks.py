@@ -81,7 +81,7 @@ def test_the_fill_kernels_prefetch_keeps_its_three_dependent_round_trips():
         assert any(o.startswith("s_waitcnt vmcnt(0)") for o in ops[i_c + 1:i_k]), f"{name}: colour id and colour are requested together"
 
 
-def test_the_one_launch_steps_chunk_loops_start_on_a_line():
+def test_the_one_launch_steps_chunk_loops_start_on_a_line(rcw):
     """rcw_fill256_cast_kernel / rcw_fill_window_cast_kernel hold the fill's chunk loop and the casting half in one function; in builds where the chunk loop
     started 4 or 36 bytes into a 64-byte line of the code, the launch was 25-30 us (2 %) slower at 16384 x 512 and 8192 x 1024 view columns than in builds
     where it started at 0 or 28 — whatever the casting code in front of it had been changed by (profiles/r06_step_forms.txt (5)).  csrc/Makefile compiles
@@ -90,8 +90,9 @@ def test_the_one_launch_steps_chunk_loops_start_on_a_line():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import loop_lines
 
-    lib = os.path.join(ROOT, "raycastworlds.jl_amd", "lib", "librcw_hip.so")
-    assert os.path.exists(lib), "build first (python -c 'import __graft_entry__ as g; g.build()')"
+    from raycastworlds_jl_amd import _capi
+
+    lib = _capi.LIB_PATH                                                 # (the `rcw` fixture has built it if this checkout had none)
     seen = 0
     for family, sizes in (("rcw_fill256_cast_kernel", 2), ("rcw_fill_window_cast_kernel", 3)):
         per_kernel = loop_lines.chunk_loops(lib, family)
