@@ -85,7 +85,7 @@ def test_the_one_launch_steps_chunk_loops_start_on_a_line(rcw):
     """rcw_fill256_cast_kernel / rcw_fill_window_cast_kernel hold the fill's chunk loop and the casting half in one function; in builds where the chunk loop
     started 4 or 36 bytes into a 64-byte line of the code, the launch was 25-30 us (2 %) slower at 16384 x 512 and 8192 x 1024 view columns than in builds
     where it started at 0 or 28 — whatever the casting code in front of it had been changed by (profiles/r06_step_forms.txt (5)).  csrc/Makefile compiles
-    rcw_cast.hip with -falign-loops=64; this reads the shipped library's code objects (tools/loop_lines.py) and wants every chunk loop of every one of the 32
+    rcw_cast.hip (and rcw_top_draw.hip, whose rcw_fill256_draw_kernel is the same loop beside the top view's drawing) with -falign-loops=64; this reads the shipped library's code objects (tools/loop_lines.py) and wants every chunk loop of every one of the 32
     instantiations at byte 0 of a line."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import loop_lines
@@ -102,3 +102,9 @@ def test_the_one_launch_steps_chunk_loops_start_on_a_line(rcw):
             assert all(start == 0 for _, start in chunk), (name, chunk)
             seen += len(chunk)
     assert seen >= 16 * 5
+    # ... and rcw_fill256_draw_kernel (rcw_top_draw.hip, the same flag): the camera fill's chunk loop beside the top view's drawing
+    per_kernel = loop_lines.chunk_loops(lib, "rcw_fill256_draw_kernel")
+    assert len(per_kernel) == 8, sorted(per_kernel)
+    for name, chunk in per_kernel.items():
+        fill = [c for c in chunk if c[0] in (540, 684)]                  # (the other loops with 16-byte stores copy the bit plane out)
+        assert len(fill) == 2 and all(start == 0 for _, start in fill), (name, chunk)

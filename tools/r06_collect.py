@@ -107,8 +107,10 @@ if os.path.exists(f"{G}/r06_top_shapes_plain.txt"):
     csv.writer(open(f"{P}/r06_top_view_kernel_stats.csv", "w")).writerows(trows)
     open(f"{P}/r06_top_view_shapes.txt", "w").write(
         "update_top_view! (SR:446-483) over map / pixel-scale shapes (tools/top_view_shapes.py WITHOUT the profiler, 240 steps), 1 MI355X, round 6, the FINAL binary.\n"
-        "The top view's kernels are round 5's (profiles/r05_top_view_shapes.txt holds their per-kernel table (a); tools/isa_diff.py: byte-identical ISA but for\n"
-        "rcw_fill256_draw_kernel's equivalent compare in column_padding).  What changed is the step they are compared WITH: `without the top view` is now the\n"
+        "The top view's kernels are round 5's in their instructions (profiles/r05_top_view_shapes.txt holds their per-kernel table (a)); the draw kernels' translation\n"
+        "unit is compiled with -falign-loops=64 since this round (csrc/Makefile): rcw_fill256_draw_kernel is the camera fill's chunk loop beside the drawing in one\n"
+        "function, and with that loop on a 64-byte line of the code what the top view adds to a step fell from 261 / 245 / 223 / 211 us to 219 / 222 / 214 / 206 us on\n"
+        "the 80^2 / 96^2 / 104^2 / 128^2 px images (the other shapes: within a box's 1-2 %).  What else changed is the step they are compared WITH: `without the top view` is now the\n"
         "one-launch step (12-14 us shorter at these batches), so `it adds` — the whole step with the top view minus the whole step without one, the measure that\n"
         "does not depend on who hides whom — grows by that much where the handle with a top view still pays its cast kernel (every shape: the drawing needs\n"
         "the state the same launch would commit, include/rcw.h RCW_STEP_ONE_LAUNCH).  Lines as in r05 (b)/(c).\n\n" + shapes +
